@@ -1,0 +1,140 @@
+/*
+ * include/oswald_hip.h -- the drop-in boundary of the MI355X search path.
+ *
+ * C ABI of liboswald_hip.so: plain pointers and sizes, no C++ or torch types.
+ * It stands where OSWALD's host code talks to its accelerator: the Altera
+ * OpenCL bring-up in host/src/utils.c:99-191 and the enqueue path of
+ * fpga_search() in host/src/FPGAsearch.c:82-238 (the same sequence appears in
+ * the "FPGA thread" of host/src/HybridSearch.c:133-228, :640-754).  The
+ * reference has no formal plugin API; every entry point below names the
+ * reference call sequence it replaces.  INTEGRATION.md shows the binding a
+ * maintainer of the reference would write.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative OSWALD_HIP_E* code on
+ *     failure; oswald_hip_last_error() returns the message of the calling
+ *     thread's last failure.  (The reference prints and exit()s on every
+ *     error, utils.c:256-262; a caller that wants that behaviour does it on a
+ *     non-zero return.)
+ *   - host buffers stay owned by the caller; the layer copies what it needs
+ *     before the call returns unless the name says _async, in which case the
+ *     buffers must stay valid until oswald_hip_wait().
+ *   - one caller thread at a time per context; any thread may be that caller.
+ *   - database residues use the preprocessed alphabet (0..22, dummy 23,
+ *     reference host/src/sequences.c:165-175, sequences.h:16-17) and the
+ *     reference's interleaved group layout b[disp[g] + j*W + lane]
+ *     (host/src/sequences.c:479-498); scores come back as int32
+ *     [nq][ngroups*W], the layout of the reference's score table
+ *     (host/src/FPGAsearch.c:236-237).
+ */
+#ifndef OSWALD_HIP_H
+#define OSWALD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSWALD_HIP_OK 0
+#define OSWALD_HIP_EINVAL (-1)   /* bad argument */
+#define OSWALD_HIP_ENODEV (-2)   /* no usable GPU / device index out of range */
+#define OSWALD_HIP_ERUNTIME (-3) /* HIP runtime call failed */
+#define OSWALD_HIP_ENOMEM (-4)   /* host or device allocation failed */
+#define OSWALD_HIP_ESTATE (-5)   /* call sequence violated (e.g. search before set_queries) */
+
+#define OSWALD_HIP_ABI_VERSION 1
+
+typedef struct oswald_hip_ctx oswald_hip_ctx;
+
+/* ABI version of the loaded library (compare with OSWALD_HIP_ABI_VERSION). */
+int oswald_hip_abi_version(void);
+
+/* Message of the calling thread's last failed call ("" if none). */
+const char *oswald_hip_last_error(void);
+
+/* Number of visible GPUs.  Replaces getDevices() in utils.c:115-118. */
+int oswald_hip_device_count(int *count);
+
+/* Bring-up: one stream and one buffer set per device; device_ids == NULL means
+ * devices 0..ndev-1.  Replaces init(), utils.c:99-173 (platform, context,
+ * queues, program, kernels).  Nothing is retained after oswald_hip_finalize(). */
+int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **ctx);
+
+/* Releases every device and host resource.  Replaces cleanup(), utils.c:176-191
+ * and the clReleaseMemObject block of FPGAsearch.c:361-368. */
+int oswald_hip_finalize(oswald_hip_ctx *ctx);
+
+/* Human-readable device description for `-O info` (utils.c:216-253), written
+ * NUL-terminated into buf (truncated to buflen). */
+int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen);
+
+/* Scoring system.  submat is the reference's 24 x 32 int8 table
+ * (host/src/submat.c); open_gap / extend_gap as on the command line (a gap of
+ * length L costs open + L*extend).  Replaces the static kernel arguments 3 and
+ * 4 of FPGAsearch.c:101-109 and the score-profile build of :143-177 (done on
+ * the device here).  cell_bits selects the first-pass cell width: 16 (packed
+ * int16, default) or 32 (plain int32); results are exact in every mode because
+ * saturated cells are re-run wider on the device. */
+int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_gap, int extend_gap, int cell_bits);
+
+/* Query set: residues of all queries back to back (codes 0..23), lengths m[],
+ * offsets a_disp[] (nq entries used).  Replaces cl_a / kernel arguments 0-2,
+ * FPGAsearch.c:85, :206-210.  Queries may be given in any order. */
+int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, const uint16_t *m,
+                           const uint32_t *a_disp, uint32_t nq);
+
+/* One database chunk made resident on device `dev`: uploads the interleaved
+ * groups and re-tiles them for the kernels.  b: vD bytes; n[g]: (padded) group
+ * lengths; disp[g]: byte offset of group g in b; lane_width W: 16 or 32
+ * (128 % W == 0).  Replaces the four clEnqueueWriteBuffer + clFinish of
+ * FPGAsearch.c:180-198, minus the 23x score profile.  *chunk receives a handle
+ * valid until oswald_hip_chunk_release() or finalize. */
+int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
+                            const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int *chunk);
+
+/* All queries against a resident chunk, asynchronously on the device's stream.
+ * If scores_out != NULL the int32 scores [nq][ngroups*W] are copied there
+ * (valid after oswald_hip_wait).  Replaces the per-query clSetKernelArg +
+ * clEnqueueNDRangeKernel loop, clWaitForEvents, clEnqueueReadBuffer and the
+ * host-side overflow re-computation, FPGAsearch.c:204-274. */
+int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out);
+
+int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk);
+
+/* Convenience: upload + search + release in one asynchronous call, the exact
+ * per-chunk step of FPGAsearch.c:132-238. */
+int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
+                                  const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int32_t *scores_out);
+
+/* Blocks until everything queued on `dev` has finished (dev < 0: all devices).
+ * Replaces clFinish / clWaitForEvents, FPGAsearch.c:197, :223, :279. */
+int oswald_hip_wait(oswald_hip_ctx *ctx, int dev);
+
+/* Top-r selection on the device over the scores of the chunk's last search:
+ * for every query the r best (score, index-in-chunk) pairs, descending score,
+ * ties by DESCENDING index -- the order sort_scores() produces
+ * (host/src/utils.c:3-86).  nvalid = number of real sequences in the chunk
+ * (padding lanes beyond it are ignored).  scores/index: [nq][r], host memory.
+ * Replaces sort_scores() + the top-r print loop, FPGAsearch.c:312-321, for the
+ * per-GPU part of the multi-GPU merge. */
+int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nvalid, uint32_t r,
+                          int32_t *scores, uint32_t *index);
+
+/* Device time spent in the DP kernels since the last reset, measured with HIP
+ * events on the device's stream (enabled by oswald_hip_set_profiling). */
+int oswald_hip_set_profiling(oswald_hip_ctx *ctx, int enable);
+int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, uint64_t *dp_launches,
+                            uint64_t *rerun_items, int reset);
+
+/* Geometry of a resident chunk as the kernels see it (for roofline accounting):
+ * out[0] = wave blocks, out[1] = stored 4-column groups, out[2] = 4-column
+ * groups after trimming all-dummy tail columns, out[3] = bytes of re-tiled
+ * residues the DP kernel reads per query. */
+int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,173 @@
+"""ctypes binding of liboswald_hip.so (include/oswald_hip.h).
+
+This module is plumbing only: it loads the in-tree shared library built by
+`__graft_entry__.build()` / `make -C oswald_amd/csrc` and exposes the C ABI.
+There is no fallback: if the library is missing, or no GPU is present at
+`Context()` time, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboswald_hip.so")
+
+# every symbol include/oswald_hip.h declares
+SYMBOLS = (
+    "oswald_hip_abi_version", "oswald_hip_last_error", "oswald_hip_device_count", "oswald_hip_init", "oswald_hip_finalize",
+    "oswald_hip_info", "oswald_hip_set_scoring", "oswald_hip_set_queries", "oswald_hip_chunk_upload", "oswald_hip_chunk_search",
+    "oswald_hip_chunk_release", "oswald_hip_search_chunk_async", "oswald_hip_wait", "oswald_hip_chunk_topr",
+    "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry",
+)
+
+
+class OswaldHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load liboswald_hip.so (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OswaldHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
+    lib.oswald_hip_abi_version.restype = i32
+    lib.oswald_hip_last_error.restype = C.c_char_p
+    lib.oswald_hip_device_count.argtypes = [C.POINTER(i32)]
+    lib.oswald_hip_init.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+    lib.oswald_hip_finalize.argtypes = [vp]
+    lib.oswald_hip_info.argtypes = [vp, i32, C.c_char_p, sz]
+    lib.oswald_hip_set_scoring.argtypes = [vp, vp, i32, i32, i32]
+    lib.oswald_hip_set_queries.argtypes = [vp, vp, u64, vp, vp, u32]
+    lib.oswald_hip_chunk_upload.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, C.POINTER(i32)]
+    lib.oswald_hip_chunk_search.argtypes = [vp, i32, i32, vp]
+    lib.oswald_hip_chunk_release.argtypes = [vp, i32, i32]
+    lib.oswald_hip_search_chunk_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, vp]
+    lib.oswald_hip_wait.argtypes = [vp, i32]
+    lib.oswald_hip_chunk_topr.argtypes = [vp, i32, i32, u32, u32, vp, vp]
+    lib.oswald_hip_set_profiling.argtypes = [vp, i32]
+    lib.oswald_hip_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), i32]
+    lib.oswald_hip_chunk_geometry.argtypes = [vp, i32, i32, C.POINTER(u64)]
+    for name in SYMBOLS:
+        if name != "oswald_hip_last_error":
+            getattr(lib, name).restype = i32
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OswaldHipError(f"liboswald_hip: error {rc}: {load().oswald_hip_last_error().decode(errors='replace')}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().oswald_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    """One oswald_hip_ctx: the operation sequence of the reference's search
+    driver (reference host/src/FPGAsearch.c:82-238) through the C ABI."""
+
+    def __init__(self, ndev: int = 1, device_ids=None):
+        self.lib = load()
+        self.h = C.c_void_p()
+        ids = None
+        if device_ids is not None:
+            ids = (C.c_int * ndev)(*device_ids)
+        _chk(self.lib.oswald_hip_init(ndev, ids, C.byref(self.h)))
+        self.ndev = ndev
+        self.nq = 0
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.oswald_hip_finalize(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self, dev: int = 0) -> str:
+        buf = C.create_string_buffer(2048)
+        _chk(self.lib.oswald_hip_info(self.h, dev, buf, len(buf)))
+        return buf.value.decode()
+
+    def set_scoring(self, submat: np.ndarray, open_gap: int, extend_gap: int, cell_bits: int = 16):
+        sm = np.ascontiguousarray(submat, dtype=np.int8).reshape(-1)
+        assert sm.size == 24 * 32
+        _chk(self.lib.oswald_hip_set_scoring(self.h, _ptr(sm), open_gap, extend_gap, cell_bits))
+
+    def set_queries(self, a: np.ndarray, m: np.ndarray, a_disp: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        m = np.ascontiguousarray(m, dtype=np.uint16)
+        a_disp = np.ascontiguousarray(a_disp, dtype=np.uint32)
+        _chk(self.lib.oswald_hip_set_queries(self.h, _ptr(a), a.size, _ptr(m), _ptr(a_disp), m.size))
+        self.nq = int(m.size)
+
+    def chunk_upload(self, b, n, disp, lane_width: int = 16, dev: int = 0) -> int:
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        n = np.ascontiguousarray(n, dtype=np.uint16)
+        disp = np.ascontiguousarray(disp, dtype=np.uint32)
+        h = C.c_int(-1)
+        _chk(self.lib.oswald_hip_chunk_upload(self.h, dev, _ptr(b), b.size, _ptr(n), _ptr(disp), n.size, lane_width, C.byref(h)))
+        return h.value
+
+    def chunk_search(self, chunk: int, out: np.ndarray | None = None, dev: int = 0):
+        """Asynchronous; `out` (int32 [nq][ngroups*W]) is valid after wait()."""
+        if out is not None:
+            assert out.dtype == np.int32 and out.flags.c_contiguous
+            self._keep.append(out)
+        _chk(self.lib.oswald_hip_chunk_search(self.h, dev, chunk, _ptr(out)))
+
+    def chunk_release(self, chunk: int, dev: int = 0):
+        _chk(self.lib.oswald_hip_chunk_release(self.h, dev, chunk))
+
+    def search_chunk_async(self, b, n, disp, out: np.ndarray, lane_width: int = 16, dev: int = 0):
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        n = np.ascontiguousarray(n, dtype=np.uint16)
+        disp = np.ascontiguousarray(disp, dtype=np.uint32)
+        assert out.dtype == np.int32 and out.flags.c_contiguous
+        self._keep.append(out)
+        _chk(self.lib.oswald_hip_search_chunk_async(self.h, dev, _ptr(b), b.size, _ptr(n), _ptr(disp), n.size, lane_width, _ptr(out)))
+
+    def wait(self, dev: int = -1):
+        _chk(self.lib.oswald_hip_wait(self.h, dev))
+        self._keep.clear()
+
+    def chunk_topr(self, chunk: int, nvalid: int, r: int, dev: int = 0):
+        sc = np.empty((self.nq, r), dtype=np.int32)
+        ix = np.empty((self.nq, r), dtype=np.uint32)
+        _chk(self.lib.oswald_hip_chunk_topr(self.h, dev, chunk, nvalid, r, _ptr(sc), _ptr(ix)))
+        return sc, ix
+
+    def set_profiling(self, on: bool):
+        _chk(self.lib.oswald_hip_set_profiling(self.h, 1 if on else 0))
+
+    def kernel_stats(self, dev: int = 0, reset: bool = False):
+        ms, n, re = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _chk(self.lib.oswald_hip_kernel_stats(self.h, dev, C.byref(ms), C.byref(n), C.byref(re), 1 if reset else 0))
+        return ms.value, n.value, re.value
+
+    def chunk_geometry(self, chunk: int, dev: int = 0):
+        out = (C.c_uint64 * 4)()
+        _chk(self.lib.oswald_hip_chunk_geometry(self.h, dev, chunk, out))
+        return {"blocks": out[0], "col4_stored": out[1], "col4_live": out[2], "residue_bytes_per_query": out[3]}

@@ -1,0 +1,59 @@
+// oswald_amd/csrc/sw_kernels.h -- device-side data layout shared by the HIP
+// kernels (sw_kernels.hip) and the C-ABI layer (oswald_hip.cpp).
+#ifndef OSWALD_SW_KERNELS_H
+#define OSWALD_SW_KERNELS_H
+
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define OSW_WG_THREADS 256   // 4 waves per workgroup, each wave independent
+#define OSW_RMAX16 32        // query rows per strip, packed int16 kernel
+#define OSW_RMAX32 16        // query rows per strip, int32 kernel
+#define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
+
+// device counters (uint32), zeroed before every search launch pair
+#define OSW_CTR_WORK 0       // next item of the pk16 queue
+#define OSW_CTR_OVF 1        // number of items queued for the int32 re-run
+#define OSW_CTR_WORK32 2     // next item of the int32 queue
+#define OSW_CTR_COUNT 8
+
+// One wave block of the re-tiled chunk: 128 consecutive sequences of the
+// (length-sorted) chunk, stored column-major in groups of 4 columns.
+struct OswBlock {
+    uint32_t col4_off;      // first 4-column group of the block in `tiled`
+    uint32_t ncols4_alloc;  // groups stored (from the caller's padded lengths)
+    uint32_t ncols4;        // groups that hold at least one real residue
+    uint32_t seq0;          // first sequence (column of the score row)
+};
+
+struct OswSearchArgs {
+    const uint2 *tiled;        // [col4][64 lanes] {4 residues seq 2l, 4 residues seq 2l+1}
+    const OswBlock *blocks;
+    const uint2 *items;        // work queue: {query, block}, heaviest first
+    uint32_t nitems;
+    uint32_t force_all;        // int32 kernel: run `items` instead of the overflow queue
+    const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16
+    const uint32_t *prof_off;
+    const uint16_t *qlen;
+    uint4 *bnd;                // strip-boundary spill, one region per resident wave
+    uint64_t bnd_stride;       // uint4 per region
+    int32_t *scores;           // [nq][score_stride]
+    uint32_t score_stride;
+    uint32_t *counters;
+    uint2 *ovf_items;
+    uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves
+    int32_t goe, ge;
+};
+
+// host-side launchers, defined in sw_kernels.hip
+hipError_t osw_launch_pk16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
+                             OswBlock *blocks, uint32_t nblocks, uint2 *tiled, hipStream_t s);
+hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint2 *prof, hipStream_t s);
+hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
+                           int32_t *out_scores, uint32_t *out_index, hipStream_t s);
+int osw_occupancy_pk16(int *blocks_per_cu);
+
+#endif

@@ -1,0 +1,514 @@
+// oswald_amd/csrc/sw_kernels.hip
+//
+// Hand-written HIP kernels for gfx950 (MI355X / CDNA4) that replace OSWALD's
+// FPGA kernel `sw` (reference device/sw.cl:16-94) and the host-side score
+// profile build feeding it (reference host/src/FPGAsearch.c:143-177).
+//
+// Formulation (MI355X-first, not a translation of the 28-wide FPGA pipeline):
+//   * inter-sequence parallel: one wave = one "block" of 128 database
+//     sequences, 2 per lane, packed as the two 16-bit halves of a VGPR
+//     (v_pk_add_i16 clamp / v_pk_max_i16 / v_pk_sub_u16 clamp).  No MFMA: this
+//     is integer DP.
+//   * the query is cut into strips of R<=32 rows held in registers (H and E
+//     of every row, 2 VGPRs per row); the database columns stream through.
+//     The strip's slice of the query profile (R x 32 codes x int16 = 2 KB)
+//     lives in a wave-private LDS region and is read with conflict-free
+//     ds_read_b64 (4 rows per read, address = residue*8 + imm).
+//   * between strips the bottom row (H,F per column) spills to a wave-private
+//     HBM scratch, coalesced 32 B per lane per 4 columns, prefetched one
+//     group ahead.
+//   * work items (query, block) are pulled from an atomic queue sorted by
+//     cost, so one launch covers all queries of a chunk; every wave exits
+//     when the queue is drained (no inter-wave waits anywhere).
+//   * cells that hit the int16 ceiling are queued on the device and re-run by
+//     the int32 kernel (the reference's int8->int16->int32 escalation,
+//     host/src/HybridSearch.c:1670-1680,:1774-1784, gives exact scores; so
+//     does this).
+//
+// Recurrence (reference sw.cl:60-78): H = max(0, Hdiag + S, E, F);
+// E,F <- max(E|F - ge, H - (go+ge)).  E and F are kept clamped at >= 0, which
+// is equivalent because they only ever enter a max with H >= 0; it turns the
+// max(.,0) into the saturation of the unsigned packed subtract.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sw_kernels.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2 *lds_u2p;
+
+static __device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+
+// ---------------------------------------------------------------------------
+// Cell arithmetic.  PK16: two sequences per lane in packed int16.  I32: one
+// sequence per lane, plain int32 (the exact fallback).
+// ---------------------------------------------------------------------------
+struct CellPK16 {
+    typedef v2s T;
+    static constexpr int kRows = OSW_RMAX16;
+    static __device__ __forceinline__ T zero() { return (T)(0); }
+    static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
+    static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
+    static __device__ __forceinline__ T splat(int x) { return (T)((short)x); }
+    // H candidates: signed saturating add, signed max (all operands of max are in [ -128, 32767 ])
+    static __device__ __forceinline__ T add_sat(T a, T b) { return __builtin_elementwise_add_sat(a, b); }
+    static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
+    // gap states stay in [0, 32767]: unsigned saturating subtract clamps at 0
+    static __device__ __forceinline__ T sub_floor0(T a, T b)
+    {
+        return __builtin_bit_cast(T, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b)));
+    }
+    static __device__ __forceinline__ T hmax(T h, T e, T f) { return vmax(vmax(h, e), f); }
+    // four rows of substitution scores for both sequences of the lane
+    static __device__ __forceinline__ void load_s(lds_u2p lp, uint32_t alo, uint32_t ahi, int rb, int /*half*/, T (&s)[4])
+    {
+        const u32x2 plo = *(lds_u2p)((__attribute__((address_space(3))) const char *)lp + alo + rb * 256);
+        const u32x2 phi = *(lds_u2p)((__attribute__((address_space(3))) const char *)lp + ahi + rb * 256);
+        s[0] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x05040100u));
+        s[1] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x07060302u));
+        s[2] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x05040100u));
+        s[3] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x07060302u));
+    }
+};
+
+struct CellI32 {
+    typedef int T;
+    static constexpr int kRows = OSW_RMAX32;
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
+    static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
+    static __device__ __forceinline__ T splat(int x) { return x; }
+    static __device__ __forceinline__ T add_sat(T a, T b) { return a + b; }
+    static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
+    static __device__ __forceinline__ T sub_floor0(T a, T b) { return vmax(a - b, 0); }
+    static __device__ __forceinline__ T hmax(T h, T e, T f) { return vmax(vmax(h, e), f); }
+    static __device__ __forceinline__ void load_s(lds_u2p lp, uint32_t alo, uint32_t ahi, int rb, int half, T (&s)[4])
+    {
+        const uint32_t a = half ? ahi : alo;
+        const u32x2 p = *(lds_u2p)((__attribute__((address_space(3))) const char *)lp + a + rb * 256);
+        s[0] = (int)(short)(p.x & 0xffffu);
+        s[1] = (int)p.x >> 16;
+        s[2] = (int)(short)(p.y & 0xffffu);
+        s[3] = (int)p.y >> 16;
+    }
+};
+
+// One database column against the R rows of the strip.
+//   diag_top = H(i0-1, j-1), h_top = H(i0-1, j), f = F(i0, j) on entry;
+//   on exit f = F(i0+R, j) and H[R-1] = H(i0+R-1, j): the next strip's top.
+template <class C, int R>
+static __device__ __forceinline__ void sw_column(lds_u2p lp, uint32_t rlo, uint32_t rhi, int half,
+                                                 typename C::T (&H)[R], typename C::T (&E)[R],
+                                                 typename C::T diag, typename C::T &f,
+                                                 typename C::T goe, typename C::T ge, typename C::T &score)
+{
+    typedef typename C::T T;
+    const uint32_t alo = (rlo & 31u) * 8u, ahi = (rhi & 31u) * 8u;
+#pragma unroll
+    for (int rb = 0; rb < R / 4; ++rb) {
+        T s[4];
+        C::load_s(lp, alo, ahi, rb, half, s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = rb * 4 + k;
+            T h = C::add_sat(diag, s[k]);
+            h = C::hmax(h, E[r], f);
+            const T t = C::sub_floor0(h, goe);
+            E[r] = C::vmax(C::sub_floor0(E[r], ge), t);
+            f = C::vmax(C::sub_floor0(f, ge), t);
+            score = C::vmax(score, h);
+            diag = H[r];
+            H[r] = h;
+        }
+    }
+}
+
+// All columns of one block against one strip of R rows.
+//   tb  : tiled residues of the block, already offset by lane; [c4*64] uint2
+//   bnd : this wave's spill scratch, already offset by lane*2; [c4*128 + {0,1}] uint4
+template <class C, int R>
+static __device__ __forceinline__ void sw_strip(const uint2 *__restrict__ tb, uint32_t ncols4, lds_u2p lp, uint4 *bnd,
+                                                bool first, bool last, int half,
+                                                typename C::T goe, typename C::T ge, typename C::T &score)
+{
+    typedef typename C::T T;
+    T H[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { H[r] = C::zero(); E[r] = C::zero(); }
+    T top_prev = C::zero(); // H(i0-1, j-1)
+    uint2 res = tb[0];
+    uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+    if (!first) { b0 = bnd[0]; b1 = bnd[1]; }
+    for (uint32_t c = 0; c < ncols4; ++c) {
+        // prefetch the next group of 4 columns (buffers are padded by one group)
+        const uint2 res_n = tb[(size_t)(c + 1) * 64];
+        uint4 b0n = make_uint4(0, 0, 0, 0), b1n = b0n;
+        if (!first) { b0n = bnd[(size_t)(c + 1) * 128]; b1n = bnd[(size_t)(c + 1) * 128 + 1]; }
+        uint4 o0, o1;
+        T f, top;
+        // column 0
+        top = C::from_bits(b0.x); f = C::from_bits(b0.y);
+        sw_column<C, R>(lp, res.x, res.y, half, H, E, top_prev, f, goe, ge, score);
+        top_prev = top; o0.x = C::to_bits(H[R - 1]); o0.y = C::to_bits(f);
+        // column 1
+        top = C::from_bits(b0.z); f = C::from_bits(b0.w);
+        sw_column<C, R>(lp, res.x >> 8, res.y >> 8, half, H, E, top_prev, f, goe, ge, score);
+        top_prev = top; o0.z = C::to_bits(H[R - 1]); o0.w = C::to_bits(f);
+        // column 2
+        top = C::from_bits(b1.x); f = C::from_bits(b1.y);
+        sw_column<C, R>(lp, res.x >> 16, res.y >> 16, half, H, E, top_prev, f, goe, ge, score);
+        top_prev = top; o1.x = C::to_bits(H[R - 1]); o1.y = C::to_bits(f);
+        // column 3
+        top = C::from_bits(b1.z); f = C::from_bits(b1.w);
+        sw_column<C, R>(lp, res.x >> 24, res.y >> 24, half, H, E, top_prev, f, goe, ge, score);
+        top_prev = top; o1.z = C::to_bits(H[R - 1]); o1.w = C::to_bits(f);
+        if (!last) { bnd[(size_t)c * 128] = o0; bnd[(size_t)c * 128 + 1] = o1; }
+        res = res_n; b0 = b0n; b1 = b1n;
+    }
+}
+
+template <class C>
+static __device__ __forceinline__ void sw_strip_dispatch(int R, const uint2 *tb, uint32_t ncols4, lds_u2p lp, uint4 *bnd,
+                                                         bool first, bool last, int half,
+                                                         typename C::T goe, typename C::T ge, typename C::T &score)
+{
+    switch (R) {
+    case 4: sw_strip<C, 4>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+    case 8: sw_strip<C, 8>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+    case 12: sw_strip<C, 12>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+    case 16: sw_strip<C, 16>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+    default:
+        if constexpr (C::kRows > 16) {
+            switch (R) {
+            case 20: sw_strip<C, 20>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+            case 24: sw_strip<C, 24>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+            case 28: sw_strip<C, 28>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+            case 32: sw_strip<C, 32>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+            default: break;
+            }
+        }
+        break;
+    }
+}
+
+// Strip schedule shared by both kernels: S strips of Rb rows, the last one
+// shorter; every height is a multiple of 4 (the profile is padded with
+// all-zero rows, which cannot raise a maximum).
+static __device__ __forceinline__ void strip_plan(uint32_t m, int rmax, uint32_t &S, uint32_t &Rb, uint32_t &m4)
+{
+    m4 = (m + 3u) & ~3u;
+    if (m4 == 0) m4 = 4;
+    S = (m4 + rmax - 1) / rmax;
+    Rb = (((m4 + S - 1) / S) + 3u) & ~3u;
+}
+
+// Copy the strip's profile slice (R rows = R/4 row-blocks of 256 B) into the
+// wave's LDS region.  Only this wave touches the region; LDS operations of one
+// wave execute in order, the wave barriers only pin the compiler's order.
+static __device__ __forceinline__ void load_profile_strip(const uint2 *prof, uint32_t rowblock0, int R, uint2 *lds_wave, int lane)
+{
+    __builtin_amdgcn_wave_barrier();
+    const uint4 *src = (const uint4 *)(prof + (size_t)rowblock0 * 32);
+    uint4 *dst = (uint4 *)lds_wave;
+    const int n16 = (R / 4) * 16;
+    for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------
+// Main kernel: packed int16, all (query, block) items of a chunk.
+// ---------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_pk16(OswSearchArgs p)
+{
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_RMAX16 / 4 * 32];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
+    uint4 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane * 2;
+    uint2 *lds_wave = lds_prof[wv];
+    const lds_u2p lp = (lds_u2p)lds_wave;
+    const v2s goe = as_v2s(p.goe_pk), ge = as_v2s(p.ge_pk);
+
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= p.nitems) break;
+        const uint2 item = p.items[it];
+        const uint32_t q = item.x, B = item.y;
+        const OswBlock blk = p.blocks[B];
+        const uint32_t ncols4 = __builtin_amdgcn_readfirstlane(blk.ncols4);
+        const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + lane;
+        uint32_t S, Rb, m4;
+        strip_plan(p.qlen[q], OSW_RMAX16, S, Rb, m4);
+        const uint32_t prof0 = p.prof_off[q];
+        v2s score = (v2s)(0);
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint32_t row0 = s * Rb;
+            const int R = (int)((m4 - row0) < Rb ? (m4 - row0) : Rb);
+            load_profile_strip(p.prof, prof0 + row0 / 4, R, lds_wave, lane);
+            sw_strip_dispatch<CellPK16>(R, tb, ncols4, lp, bnd, s == 0, s + 1 == S, 0, goe, ge, score);
+        }
+        // exact unless the int16 ceiling was touched
+        int2 out;
+        out.x = score.x;
+        out.y = score.y;
+        *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lane) = out;
+        const bool ovf = (score.x == 32767) | (score.y == 32767);
+        if (__any(ovf)) {
+            if (lane == 0) {
+                const uint32_t k = atomicAdd(&p.counters[OSW_CTR_OVF], 1u);
+                p.ovf_items[k] = item;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exact re-run of the items queued by osw_sw_pk16, plain int32, one sequence
+// per lane, the block's two sequence halves one after the other.
+// ---------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearchArgs p)
+{
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_RMAX32 / 4 * 32];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
+    uint4 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane * 2;
+    uint2 *lds_wave = lds_prof[wv];
+    const lds_u2p lp = (lds_u2p)lds_wave;
+    const int goe = p.goe, ge = p.ge;
+    // the queue length was produced by the previous kernel on this stream
+    const uint32_t nitems = p.force_all ? p.nitems : p.counters[OSW_CTR_OVF];
+    const uint2 *items = p.force_all ? p.items : p.ovf_items;
+
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK32], 1u);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= nitems) break;
+        const uint2 item = items[it];
+        const uint32_t q = item.x, B = item.y;
+        const OswBlock blk = p.blocks[B];
+        const uint32_t ncols4 = __builtin_amdgcn_readfirstlane(blk.ncols4);
+        const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + lane;
+        uint32_t S, Rb, m4;
+        strip_plan(p.qlen[q], OSW_RMAX32, S, Rb, m4);
+        const uint32_t prof0 = p.prof_off[q];
+        for (int half = 0; half < 2; ++half) {
+            int score = 0;
+            for (uint32_t s = 0; s < S; ++s) {
+                const uint32_t row0 = s * Rb;
+                const int R = (int)((m4 - row0) < Rb ? (m4 - row0) : Rb);
+                load_profile_strip(p.prof, prof0 + row0 / 4, R, lds_wave, lane);
+                sw_strip_dispatch<CellI32>(R, tb, ncols4, lp, bnd, s == 0, s + 1 == S, half, goe, ge, score);
+            }
+            p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * lane + half] = score;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Upload-side kernels.
+// ---------------------------------------------------------------------------
+
+// Re-tile the reference's W-lane interleaved groups (a4: b[disp_g + j*W + l],
+// reference host/src/sequences.c:479-498) into 128-sequence wave blocks:
+// tiled[(col4_off + c4)*64 + lane] = { 4 residues of seq 2*lane, 4 residues of
+// seq 2*lane+1 }.  Missing groups / columns past a group's length read as the
+// dummy residue 23, exactly the reference's padding value.
+extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
+                                                              const uint32_t *__restrict__ disp, uint32_t ngroups, uint32_t W,
+                                                              const OswBlock *__restrict__ blocks, uint2 *__restrict__ tiled)
+{
+    const uint32_t B = blockIdx.x;
+    const OswBlock blk = blocks[B];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t gpb = 128 / W;                  // groups per block
+    const uint32_t g = B * gpb + (2 * lane) / W;   // this lane's group
+    const uint32_t l = (2 * lane) % W;             // lane pair inside the group
+    const bool have = g < ngroups;
+    const uint32_t ng = have ? n[g] : 0;
+    const uint8_t *src = b + (have ? disp[g] : 0) + l;
+    // one extra (all-dummy) group past the end: the search kernels prefetch it
+    for (uint32_t c4 = wv; c4 <= blk.ncols4_alloc; c4 += 4) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t j = c4 * 4 + k;
+            uint32_t r0 = 23, r1 = 23;
+            if (j < ng && c4 < blk.ncols4_alloc) {
+                r0 = src[(size_t)j * W];
+                r1 = src[(size_t)j * W + 1];
+            }
+            lo |= r0 << (8 * k);
+            hi |= r1 << (8 * k);
+        }
+        tiled[(size_t)(blk.col4_off + c4) * 64 + lane] = make_uint2(lo, hi);
+    }
+}
+
+// Trailing columns in which every sequence of the block holds the dummy
+// residue score 0 against everything (reference submat.c: column 23 is zero)
+// and therefore cannot raise any maximum: drop them from the block's extent.
+extern "C" __global__ __launch_bounds__(64) void osw_block_extent(OswBlock *blocks, const uint2 *__restrict__ tiled)
+{
+    const uint32_t B = blockIdx.x;
+    const int lane = threadIdx.x;
+    const OswBlock blk = blocks[B];
+    uint32_t c4 = blk.ncols4_alloc;
+    while (c4 > 0) {
+        const uint2 v = tiled[(size_t)(blk.col4_off + c4 - 1) * 64 + lane];
+        const bool live = (v.x != 0x17171717u) | (v.y != 0x17171717u);
+        if (__any(live)) break;
+        --c4;
+    }
+    if (lane == 0) blocks[B].ncols4 = c4;
+}
+
+// Query profile in the layout the search kernels read:
+// prof[(prof_off[q] + i/4)*32 + code] = 4 x int16 = S(a[i..i+3], code);
+// rows past the query end and query codes >= 24 score 0 (the reference's
+// 24th matrix row is all zero, submat.c).
+extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_t *__restrict__ a, const uint32_t *__restrict__ a_disp,
+                                                                     const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ prof_off,
+                                                                     const int8_t *__restrict__ submat, uint32_t nq, uint2 *__restrict__ prof)
+{
+    const uint32_t q = blockIdx.y;
+    if (q >= nq) return;
+    const uint32_t m = qlen[q];
+    const uint32_t nrb = (m + 3) / 4 > 0 ? (m + 3) / 4 : 1;
+    const uint8_t *aq = a + a_disp[q];
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < nrb * 32; e += gridDim.x * blockDim.x) {
+        const uint32_t rb = e >> 5, code = e & 31;
+        short s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = rb * 4 + k;
+            int v = 0;
+            if (i < m) {
+                const uint32_t ai = aq[i];
+                if (ai < 24) v = submat[ai * 32 + code];
+            }
+            s[k] = (short)v;
+        }
+        uint2 o;
+        o.x = (uint32_t)(uint16_t)s[0] | ((uint32_t)(uint16_t)s[1] << 16);
+        o.y = (uint32_t)(uint16_t)s[2] | ((uint32_t)(uint16_t)s[3] << 16);
+        prof[(size_t)(prof_off[q] + rb) * 32 + code] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Top-r selection with the reference's tie rule (reference host/src/utils.c:
+// 3-86 sorts descending and, on equal scores, puts the LATER database index
+// first).  key = score << 32 | index, so "descending key" is exactly that
+// order.  One workgroup per query; round k picks the largest key below the
+// key of round k-1.  r rounds of one coalesced pass over the score row.
+// ---------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(1024) void osw_topr(const int32_t *__restrict__ scores, uint32_t score_stride,
+                                                             uint32_t nvalid, uint32_t r, int32_t *__restrict__ out_scores,
+                                                             uint32_t *__restrict__ out_index)
+{
+    __shared__ unsigned long long red[16];
+    __shared__ unsigned long long bound_s;
+    const uint32_t q = blockIdx.x;
+    const int32_t *row = scores + (size_t)q * score_stride;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long bound = ~0ull;
+    for (uint32_t k = 0; k < r; ++k) {
+        unsigned long long best = 0;
+        bool found = false;
+        for (uint32_t i = threadIdx.x; i < nvalid; i += blockDim.x) {
+            const unsigned long long key = ((unsigned long long)(uint32_t)row[i] << 32) | i;
+            if (key < bound && (!found || key > best)) { best = key; found = true; }
+        }
+        // encode "found" in bit 0 of a shifted key so that an empty thread loses
+        unsigned long long v = found ? ((best << 1) | 1ull) : 0ull;
+        // scores are >= 0 and < 2^31, so best < 2^63 and the shift is lossless
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(v, off);
+            v = o > v ? o : v;
+        }
+        if (lane == 0) red[wv] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long m = 0;
+            for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) m = red[w] > m ? red[w] : m;
+            bound_s = m;
+        }
+        __syncthreads();
+        const unsigned long long m = bound_s;
+        if (threadIdx.x == 0) {
+            if (m & 1ull) {
+                out_scores[(size_t)q * r + k] = (int32_t)((m >> 1) >> 32);
+                out_index[(size_t)q * r + k] = (uint32_t)((m >> 1) & 0xffffffffull);
+            } else {
+                out_scores[(size_t)q * r + k] = -1;
+                out_index[(size_t)q * r + k] = 0xffffffffu;
+            }
+        }
+        bound = (m & 1ull) ? (m >> 1) : 0ull;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Host-side launchers (the kernels are only launched from this translation
+// unit; oswald_hip.cpp calls these).
+// ---------------------------------------------------------------------------
+#define OSW_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t osw_launch_pk16(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_pk16, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_i32, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
+                             OswBlock *blocks, uint32_t nblocks, uint2 *tiled, hipStream_t s)
+{
+    if (nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(osw_retile, dim3(nblocks), dim3(256), 0, s, b, n, disp, ngroups, W, (const OswBlock *)blocks, tiled);
+    OSW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(64), 0, s, blocks, (const uint2 *)tiled);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint2 *prof, hipStream_t s)
+{
+    if (nq == 0) return hipSuccess;
+    uint32_t gx = (max_rowblocks * 32 + 255) / 256;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, prof);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
+                           int32_t *out_scores, uint32_t *out_index, hipStream_t s)
+{
+    if (nq == 0 || r == 0) return hipSuccess;
+    hipLaunchKernelGGL(osw_topr, dim3(nq), dim3(1024), 0, s, scores, score_stride, nvalid, r, out_scores, out_index);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+int osw_occupancy_pk16(int *blocks_per_cu)
+{
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, osw_sw_pk16, OSW_WG_THREADS, 0);
+}

@@ -1,0 +1,184 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle.
+
+Bar: bit-exact int32 scores for every (query, database sequence), i.e. exactly
+what the reference's host path reports after its int8->int16->int32 escalation
+(reference host/src/HybridSearch.c:1573-1880).
+"""
+import numpy as np
+import pytest
+
+from oswald_amd import dblayout, submat, synth
+
+from helpers import db_from_sequences, layout, pack_queries, random_db
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(ctx, queries, b, n, disp, W, sm, go, ge, cell_bits=16, resident=False):
+    a, m, ad = pack_queries(queries)
+    ctx.set_scoring(sm, go, ge, cell_bits)
+    ctx.set_queries(a, m, ad)
+    out = np.full((len(queries), len(n) * W), -7, dtype=np.int32)
+    if resident:
+        h = ctx.chunk_upload(b, n, disp, W)
+        ctx.chunk_search(h, out)
+        ctx.wait()
+        ctx.chunk_release(h)
+    else:
+        ctx.search_chunk_async(b, n, disp, out, W)
+        ctx.wait()
+    return out
+
+
+def expect(oracle, queries, b, n, disp, W, sm, go, ge):
+    a, m, ad = pack_queries(queries)
+    return oracle.search_chunk_scalar(a, m, ad, b, n, disp, W, sm, go, ge)
+
+
+@pytest.mark.parametrize("nseq", [1, 15, 16, 17, 127, 128, 129, 300])
+def test_small_databases_all_group_shapes(hip_ctx, oracle, nseq):
+    qs = synth.make_queries([1, 3, 4, 5, 31, 32, 33, 64, 97, 100], seed=11)
+    L, R, O = random_db(nseq, seed=nseq, max_len=120, queries=qs[-3:], homologs=1)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("matrix,go,ge", [("blosum62", 10, 2), ("pam250", 14, 2), ("blosum45", 0, 0), ("pam30", 30, 5), ("blosum90", 3, 1)])
+def test_matrices_and_gaps(hip_ctx, oracle, matrix, go, ge):
+    qs = synth.make_queries([50, 129, 375], seed=5)
+    L, R, O = random_db(200, seed=77, max_len=400, queries=qs, homologs=3)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load(matrix)
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge, resident=True)
+    want = expect(oracle, qs, b, n, disp, 16, sm, go, ge)
+    np.testing.assert_array_equal(got, want)
+    assert want.max() > 127  # the planted copies are beyond the int8 range
+
+
+def test_lane_width_32_layout(hip_ctx, oracle):
+    qs = synth.make_queries([40, 200], seed=8)
+    L, R, O = random_db(150, seed=9, max_len=150, queries=qs, homologs=2)
+    b, n, disp, _, _ = layout(L, R, O, 32, round_to=1)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 32, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 32, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_int16_ceiling_forces_exact_int32_rerun(hip_ctx, oracle):
+    """Scores around and beyond 32767: all-W sequences score 11 per cell on the
+    diagonal with BLOSUM62; 2978 W's = 32758, 2979 = 32769."""
+    w = synth.ALPHABET.index("W")
+    q = np.full(3100, w, dtype=np.uint8)
+    seqs = [np.full(k, w, dtype=np.uint8) for k in (1, 11, 2977, 2978, 2979, 2980, 3100)]
+    seqs += [synth.random_residues(3, 0, 500), synth.mutate(q, 0.05, 4)]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, sl, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, [q, q[:700]], b, n, disp, 16, sm, 10, 2, resident=True)
+    want = expect(oracle, [q, q[:700]], b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want.max() == 11 * 3100 and (want == 32758).any() and (want == 32769).any()
+    _, _, rerun = hip_ctx.kernel_stats()
+    assert rerun >= 1
+
+
+def test_exact_score_32767_is_rerun_and_kept(hip_ctx, oracle):
+    """A true score of exactly 32767 is indistinguishable from saturation in the
+    int16 pass; like the reference (== 32767 test, HybridSearch.c:1774) it is
+    re-run and must come back as 32767."""
+    sm = submat.load("blosum62").copy()
+    w = synth.ALPHABET.index("W")
+    sm[w, w] = 127   # 258 * 127 = 32766, +1 via a custom cell
+    c = synth.ALPHABET.index("C")
+    sm[c, c] = 1
+    q = np.concatenate([np.full(258, w, np.uint8), np.full(1, c, np.uint8)])
+    L, R, O = db_from_sequences([q.copy(), q[:258].copy(), q[:100].copy()])
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    got = run_gpu(hip_ctx, [q], b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, [q], b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want.max() == 32767
+
+
+def test_int32_mode_equals_int16_mode(hip_ctx, oracle):
+    qs = synth.make_queries([17, 260], seed=21)
+    L, R, O = random_db(140, seed=31, max_len=300, queries=qs, homologs=2)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("pam250")
+    got32 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=32)
+    got16 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=16)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 14, 2)
+    np.testing.assert_array_equal(got32, want)
+    np.testing.assert_array_equal(got16, want)
+
+
+def test_long_query_many_strips(hip_ctx, oracle):
+    """m = 2500: 79 strips, every one spilling its bottom row through HBM."""
+    q = synth.make_queries([2500], seed=99)[0]
+    L, R, O = random_db(130, seed=41, min_len=20, max_len=700, queries=[q], homologs=3)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, [q], b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, [q], b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_dummy_residues_and_odd_codes(hip_ctx, oracle):
+    """J/O/U map to code 23 (reference sequences.c:167-169) in queries and in the
+    database; 23 scores 0 everywhere (submat.c row/col 23)."""
+    rng = np.random.default_rng(5)
+    qs = [rng.integers(0, 24, 90).astype(np.uint8), np.full(10, 23, np.uint8)]
+    seqs = [rng.integers(0, 24, int(l)).astype(np.uint8) for l in rng.integers(1, 90, 40)]
+    seqs.append(np.full(30, 23, np.uint8))
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_topr_on_device_tie_order(hip_ctx, oracle):
+    qs = synth.make_queries([30, 60], seed=2)
+    L, R, O = random_db(500, seed=6, max_len=60)
+    b, n, disp, sl, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    hip_ctx.set_scoring(sm, 10, 2, 16)
+    hip_ctx.set_queries(a, m, ad)
+    h = hip_ctx.chunk_upload(b, n, disp, 16)
+    out = np.zeros((2, len(n) * 16), np.int32)
+    hip_ctx.chunk_search(h, out)
+    hip_ctx.wait()
+    sc, ix = hip_ctx.chunk_topr(h, 500, 25)
+    hip_ctx.chunk_release(h)
+    for q in range(2):
+        wsc, wix = dblayout.topr_reference_order(out[q, :500], 25)
+        np.testing.assert_array_equal(sc[q], wsc)
+        np.testing.assert_array_equal(ix[q], wix)
+        osc, oix = oracle.sort_scores(out[q, :500])
+        np.testing.assert_array_equal(sc[q], osc[:25])
+        np.testing.assert_array_equal(ix[q], oix[:25])
+    assert len(np.unique(out[0, :500])) < 400  # ties are present
+
+
+def test_chunks_equal_single_chunk(hip_ctx, oracle):
+    """Cutting the database into chunks the reference's way (sequences.c:505-541)
+    and searching them one by one gives the same score table."""
+    qs = synth.make_queries([80, 33], seed=14)
+    L, R, O = random_db(700, seed=15, max_len=180)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
+    sm = submat.load("blosum62")
+    whole = run_gpu(hip_ctx, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
+    plan = dblayout.chunk_plan(nfull, 16, 40000, 1)
+    assert len(plan) >= 3
+    parts = []
+    for g0, g1 in plan:
+        b, n, disp = dblayout.interleave(sl, sr, so, 16, g_begin=g0, g_end=g1)
+        parts.append(run_gpu(hip_ctx, qs, b, n, disp.astype(np.uint32), 16, sm, 10, 2))
+    np.testing.assert_array_equal(np.concatenate(parts, axis=1), whole)

@@ -1,0 +1,102 @@
+// tools/ubench.hip -- instruction-rate microbenchmarks that size the DP kernel
+// on gfx950: packed-int16 VALU rate vs. waves per SIMD, dependent-issue cost,
+// and LDS profile-read rate.  Build: hipcc --offload-arch=gfx950 -O3 -o ubench tools/ubench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
+template <int ILP>
+__global__ __launch_bounds__(256) void pk_rate(uint32_t *out, uint32_t c1, uint32_t c2, int iters)
+{
+    v2s x[ILP];
+    const v2s a = __builtin_bit_cast(v2s, c1), b = __builtin_bit_cast(v2s, c2);
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) x[i] = __builtin_bit_cast(v2s, (uint32_t)(threadIdx.x + i));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) {
+            x[i] = __builtin_elementwise_add_sat(x[i], a);
+            x[i] = __builtin_elementwise_max(x[i], b);
+            x[i] = __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, x[i]), __builtin_bit_cast(v2u, a)));
+            x[i] = __builtin_elementwise_max(x[i], a);
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc ^= __builtin_bit_cast(uint32_t, x[i]);
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
+// LDS: ds_read_b64 of 4 profile rows at residue*8 + imm, 16 reads per "column"
+__global__ __launch_bounds__(256) void lds_rate(uint32_t *out, const uint32_t *res, int iters)
+{
+    __shared__ uint2 prof[4][8 * 32];
+    for (int i = threadIdx.x; i < 4 * 8 * 32; i += 256) ((uint2 *)prof)[i] = make_uint2(i, i * 3);
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    uint32_t r = res[threadIdx.x];
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t a = (r & 31);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) {
+            uint2 p = prof[wv][rb * 32 + a];
+            acc += p.x ^ p.y;
+        }
+        r = (r >> 5) | (r << 27);
+    }
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
+template <class F>
+static double time_ms(F f, int reps)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    f();
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) f();
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms / reps;
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    printf("device %s, %d CUs, clock %d MHz\n", p.name, cus, p.clockRate / 1000);
+    uint32_t *out, *res;
+    hipMalloc(&out, 4096);
+    hipMalloc(&res, 4096);
+    std::vector<uint32_t> h(1024);
+    for (int i = 0; i < 1024; ++i) h[i] = 2654435761u * (i + 1);
+    hipMemcpy(res, h.data(), 4096, hipMemcpyHostToDevice);
+    const int iters = 20000;
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        auto run = [&](auto kern, int ilp, const char *name) {
+            double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(cus * wps), dim3(256), 0, 0, out, 0x00030003u, 0x00010001u, iters); }, 3);
+            double ops = (double)cus * wps * 4 /*waves*/ * iters * ilp * 4.0;
+            printf("pk_rate %-6s waves/SIMD=%d : %.3f ms  %.2f T wave-instr... %.1f Gwaveinstr/s  = %.2f cycles/instr/SIMD at 2.4GHz\n", name, wps, ms,
+                   ops / 1e12, ops / ms / 1e6, (double)cus * 4 * 2.4e9 / (ops / (ms * 1e-3)));
+        };
+        run(pk_rate<1>, 1, "ilp1");
+        run(pk_rate<2>, 2, "ilp2");
+        run(pk_rate<8>, 8, "ilp8");
+    }
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        double ms = time_ms([&] { hipLaunchKernelGGL(lds_rate, dim3(cus * wps), dim3(256), 0, 0, out, res, iters); }, 3);
+        double reads = (double)cus * wps * 4 * iters * 8;
+        printf("lds_rate ds_read_b64 waves/SIMD=%d : %.3f ms, %.2f cycles per wave-read per CU at 2.4GHz\n", wps, ms,
+               (double)cus * 2.4e9 / (reads / (ms * 1e-3)));
+    }
+    return 0;
+}
