@@ -79,7 +79,7 @@ struct Device {
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index;
-    uint64_t bnd_stride = 0;         // uint4 per wave slot
+    uint64_t bnd_stride = 0;         // uint2 per wave slot
     uint64_t queries_version = ~0ull; // what is currently uploaded
     uint64_t scoring_version = ~0ull;
     std::vector<Chunk> chunks;
@@ -345,7 +345,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         blocks[B].seq0 = B * OSW_BLOCK_SEQS;
         c.ncols4_alloc[B] = nc4;
         c.max_ncols4 = std::max(c.max_ncols4, nc4);
-        off += (uint64_t)nc4 + 1; // + the prefetch pad group
+        off += (uint64_t)nc4 + 2; // + the two prefetch pad groups
     }
     c.total_col4 = off;
     HIP_TRY(c.tiled.reserve(off * 64 * sizeof(uint2) + 1024));
@@ -362,11 +362,11 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint2 *)c.tiled.p, d.stream));
     }
     // strip-boundary scratch: one region per resident wave, sized for the longest block
-    const uint64_t stride = ((uint64_t)c.max_ncols4 + 2) * 128; // uint4 per wave slot
+    const uint64_t stride = ((uint64_t)c.max_ncols4 * 4 + 8) * 64; // uint2 per wave slot
     if (stride > d.bnd_stride) {
         const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
         HIP_TRY(hipStreamSynchronize(d.stream));
-        HIP_TRY(d.bnd.reserve(slots * stride * sizeof(uint4)));
+        HIP_TRY(d.bnd.reserve(slots * stride * sizeof(uint2)));
         d.bnd_stride = stride;
     }
     HIP_TRY(hipStreamSynchronize(d.stream)); // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
@@ -398,7 +398,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;
     a.qlen = (const uint16_t *)d.qlen.p;
-    a.bnd = (uint4 *)d.bnd.p;
+    a.bnd = (uint2 *)d.bnd.p;
     a.bnd_stride = d.bnd_stride;
     a.scores = (int32_t *)c.scores.p;
     a.score_stride = c.score_stride;

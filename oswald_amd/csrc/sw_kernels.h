@@ -35,8 +35,8 @@ struct OswSearchArgs {
     const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16
     const uint32_t *prof_off;
     const uint16_t *qlen;
-    uint4 *bnd;                // strip-boundary spill, one region per resident wave
-    uint64_t bnd_stride;       // uint4 per region
+    uint2 *bnd;                // strip-boundary spill {H,F} per column and lane, one region per resident wave
+    uint64_t bnd_stride;       // uint2 per region
     int32_t *scores;           // [nq][score_stride]
     uint32_t score_stride;
     uint32_t *counters;

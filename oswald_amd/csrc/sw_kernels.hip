@@ -127,9 +127,12 @@ static __device__ __forceinline__ void sw_column(lds_u2p lp, uint32_t rlo, uint3
 
 // All columns of one block against one strip of R rows.
 //   tb  : tiled residues of the block, already offset by lane; [c4*64] uint2
-//   bnd : this wave's spill scratch, already offset by lane*2; [c4*128 + {0,1}] uint4
+//   bnd : this wave's spill scratch, already offset by lane; [col*64] uint2 = {H, F}
+// One column per loop iteration (not unrolled: the 2R state registers are
+// updated in place, which keeps the kernel at 4 waves per SIMD); residues
+// arrive 4 columns per load, boundary values one column ahead.
 template <class C, int R>
-static __device__ __forceinline__ void sw_strip(const uint2 *__restrict__ tb, uint32_t ncols4, lds_u2p lp, uint4 *bnd,
+static __device__ __forceinline__ void sw_strip(const uint2 *__restrict__ tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
                                                 bool first, bool last, int half,
                                                 typename C::T goe, typename C::T ge, typename C::T &score)
 {
@@ -138,39 +141,137 @@ static __device__ __forceinline__ void sw_strip(const uint2 *__restrict__ tb, ui
 #pragma unroll
     for (int r = 0; r < R; ++r) { H[r] = C::zero(); E[r] = C::zero(); }
     T top_prev = C::zero(); // H(i0-1, j-1)
-    uint2 res = tb[0];
-    uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
-    if (!first) { b0 = bnd[0]; b1 = bnd[1]; }
-    for (uint32_t c = 0; c < ncols4; ++c) {
-        // prefetch the next group of 4 columns (buffers are padded by one group)
-        const uint2 res_n = tb[(size_t)(c + 1) * 64];
-        uint4 b0n = make_uint4(0, 0, 0, 0), b1n = b0n;
-        if (!first) { b0n = bnd[(size_t)(c + 1) * 128]; b1n = bnd[(size_t)(c + 1) * 128 + 1]; }
-        uint4 o0, o1;
-        T f, top;
-        // column 0
-        top = C::from_bits(b0.x); f = C::from_bits(b0.y);
+    uint2 res = tb[0], res_n = tb[64];
+    uint2 bcur = make_uint2(0, 0);
+    if (!first) bcur = bnd[0];
+    const uint32_t ncols = ncols4 * 4;
+#pragma unroll 1
+    for (uint32_t j = 0; j < ncols; ++j) {
+        uint2 bnxt = make_uint2(0, 0);
+        if (!first) bnxt = bnd[(size_t)(j + 1) * 64]; // scratch is padded by one column
+        const T top = C::from_bits(bcur.x);
+        T f = C::from_bits(bcur.y);
         sw_column<C, R>(lp, res.x, res.y, half, H, E, top_prev, f, goe, ge, score);
-        top_prev = top; o0.x = C::to_bits(H[R - 1]); o0.y = C::to_bits(f);
-        // column 1
-        top = C::from_bits(b0.z); f = C::from_bits(b0.w);
-        sw_column<C, R>(lp, res.x >> 8, res.y >> 8, half, H, E, top_prev, f, goe, ge, score);
-        top_prev = top; o0.z = C::to_bits(H[R - 1]); o0.w = C::to_bits(f);
-        // column 2
-        top = C::from_bits(b1.x); f = C::from_bits(b1.y);
-        sw_column<C, R>(lp, res.x >> 16, res.y >> 16, half, H, E, top_prev, f, goe, ge, score);
-        top_prev = top; o1.x = C::to_bits(H[R - 1]); o1.y = C::to_bits(f);
-        // column 3
-        top = C::from_bits(b1.z); f = C::from_bits(b1.w);
-        sw_column<C, R>(lp, res.x >> 24, res.y >> 24, half, H, E, top_prev, f, goe, ge, score);
-        top_prev = top; o1.z = C::to_bits(H[R - 1]); o1.w = C::to_bits(f);
-        if (!last) { bnd[(size_t)c * 128] = o0; bnd[(size_t)c * 128 + 1] = o1; }
-        res = res_n; b0 = b0n; b1 = b1n;
+        top_prev = top;
+        if (!last) bnd[(size_t)j * 64] = make_uint2(C::to_bits(H[R - 1]), C::to_bits(f));
+        res.x >>= 8;
+        res.y >>= 8;
+        if ((j & 3u) == 3u) {
+            res = res_n;
+            res_n = tb[(size_t)((j >> 2) + 2) * 64]; // tiled is padded by two groups
+        }
+        bcur = bnxt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Packed-int16 strip with a hand-scheduled cell.  State per row r: E[r] and
+// D[r] = H(i0+r-1, j-1), the diagonal input of row r (D[0] comes from the strip
+// above).  The cell of row r is 9 VOP3P instructions; it also issues the
+// diagonal add of row r+1 *before* it overwrites D[r+1] with its own H, so
+// every state register is updated in place (no copies), and every result is
+// consumed at a distance of >= 2 issue slots, which is what gfx950 needs
+// between a packed-math write and a dependent VALU read (no s_nop).
+//   x   in: D[r] + S[r]          out: D[r+1] + S[r+1]
+//   Dn  in: D[r+1] (old column)  out: H(i0+r, j)  (= D[r+1] of the next column)
+// ---------------------------------------------------------------------------
+#define OSW_PK16_ROW(x, Er, Dn, f, sc, s_next, ge, goe)                                      \
+    do {                                                                                     \
+        v2s tmp_;                                                                            \
+        asm volatile("v_pk_max_i16 %[tmp], %[x_], %[E_]\n\t"                                 \
+                     "v_pk_add_i16 %[x_], %[Dn_], %[sn_] clamp\n\t"                          \
+                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
+                     "v_pk_max_i16 %[Dn_], %[tmp], %[f_]\n\t"                                \
+                     "v_pk_sub_u16 %[f_], %[f_], %[ge_] clamp\n\t"                           \
+                     "v_pk_sub_u16 %[tmp], %[Dn_], %[goe_] clamp\n\t"                        \
+                     "v_pk_max_i16 %[sc_], %[sc_], %[Dn_]\n\t"                               \
+                     "v_pk_max_i16 %[E_], %[E_], %[tmp]\n\t"                                 \
+                     "v_pk_max_i16 %[f_], %[f_], %[tmp]"                                     \
+                     : [tmp] "=&v"(tmp_), [x_] "+v"(x), [E_] "+v"(Er), [Dn_] "+v"(Dn), [f_] "+v"(f), [sc_] "+v"(sc) \
+                     : [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe));                   \
+    } while (0)
+
+// last row of the strip: its H goes to `hl` (the spill), there is no next row
+#define OSW_PK16_ROW_LAST(x, Er, hl, f, sc, ge, goe)                                         \
+    do {                                                                                     \
+        v2s tmp_;                                                                            \
+        asm volatile("v_pk_max_i16 %[tmp], %[x_], %[E_]\n\t"                                 \
+                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
+                     "v_pk_max_i16 %[hl_], %[tmp], %[f_]\n\t"                                \
+                     "v_pk_sub_u16 %[f_], %[f_], %[ge_] clamp\n\t"                           \
+                     "v_pk_sub_u16 %[tmp], %[hl_], %[goe_] clamp\n\t"                        \
+                     "v_pk_max_i16 %[sc_], %[sc_], %[hl_]\n\t"                               \
+                     "v_pk_max_i16 %[E_], %[E_], %[tmp]\n\t"                                 \
+                     "v_pk_max_i16 %[f_], %[f_], %[tmp]"                                     \
+                     : [tmp] "=&v"(tmp_), [hl_] "=&v"(hl), [E_] "+v"(Er), [f_] "+v"(f), [sc_] "+v"(sc) \
+                     : [x_] "v"(x), [ge_] "s"(ge), [goe_] "s"(goe));                         \
+    } while (0)
+
+template <int R>
+static __device__ __forceinline__ void sw_strip_pk16(const uint2 *__restrict__ tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
+                                                     bool first, bool last, uint32_t goe, uint32_t ge, v2s &score)
+{
+    v2s D[R], E[R]; // D[0] is only a name for the top input
+#pragma unroll
+    for (int r = 0; r < R; ++r) { D[r] = (v2s)(0); E[r] = (v2s)(0); }
+    v2s top_prev = (v2s)(0); // H(i0-1, j-1)
+    uint2 res = tb[0], res_n = tb[64];
+    uint2 bcur = make_uint2(0, 0);
+    if (!first) bcur = bnd[0];
+    const uint32_t ncols = ncols4 * 4;
+#pragma unroll 1
+    for (uint32_t j = 0; j < ncols; ++j) {
+        uint2 bnxt = make_uint2(0, 0);
+        if (!first) bnxt = bnd[(size_t)(j + 1) * 64]; // scratch is padded by one column
+        const uint32_t alo = (res.x & 31u) * 8u, ahi = (res.y & 31u) * 8u;
+        v2s f = as_v2s(bcur.y);
+        v2s s[4], sn[4], hl;
+        CellPK16::load_s(lp, alo, ahi, 0, 0, s);
+        v2s x = __builtin_elementwise_add_sat(top_prev, s[0]);
+#pragma unroll
+        for (int rb = 0; rb < R / 4; ++rb) {
+            if (rb + 1 < R / 4) CellPK16::load_s(lp, alo, ahi, rb + 1, 0, sn);
+            OSW_PK16_ROW(x, E[rb * 4 + 0], D[rb * 4 + 1], f, score, s[1], ge, goe);
+            OSW_PK16_ROW(x, E[rb * 4 + 1], D[rb * 4 + 2], f, score, s[2], ge, goe);
+            OSW_PK16_ROW(x, E[rb * 4 + 2], D[rb * 4 + 3], f, score, s[3], ge, goe);
+            if (rb + 1 < R / 4) {
+                OSW_PK16_ROW(x, E[rb * 4 + 3], D[rb * 4 + 4], f, score, sn[0], ge, goe);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = sn[k];
+            } else {
+                OSW_PK16_ROW_LAST(x, E[rb * 4 + 3], hl, f, score, ge, goe);
+            }
+        }
+        top_prev = as_v2s(bcur.x);
+        if (!last) bnd[(size_t)j * 64] = make_uint2(as_u32(hl), as_u32(f));
+        res.x >>= 8;
+        res.y >>= 8;
+        if ((j & 3u) == 3u) {
+            res = res_n;
+            res_n = tb[(size_t)((j >> 2) + 2) * 64]; // tiled is padded by two groups
+        }
+        bcur = bnxt;
+    }
+}
+
+static __device__ __forceinline__ void sw_strip_dispatch_pk16(int R, const uint2 *tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
+                                                              bool first, bool last, uint32_t goe, uint32_t ge, v2s &score)
+{
+    switch (R) {
+    case 4: sw_strip_pk16<4>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    case 8: sw_strip_pk16<8>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    case 12: sw_strip_pk16<12>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    case 16: sw_strip_pk16<16>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    case 20: sw_strip_pk16<20>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    case 24: sw_strip_pk16<24>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    case 28: sw_strip_pk16<28>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    case 32: sw_strip_pk16<32>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
+    default: break;
     }
 }
 
 template <class C>
-static __device__ __forceinline__ void sw_strip_dispatch(int R, const uint2 *tb, uint32_t ncols4, lds_u2p lp, uint4 *bnd,
+static __device__ __forceinline__ void sw_strip_dispatch(int R, const uint2 *tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
                                                          bool first, bool last, int half,
                                                          typename C::T goe, typename C::T ge, typename C::T &score)
 {
@@ -221,16 +322,15 @@ static __device__ __forceinline__ void load_profile_strip(const uint2 *prof, uin
 // ---------------------------------------------------------------------------
 // Main kernel: packed int16, all (query, block) items of a chunk.
 // ---------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_pk16(OswSearchArgs p)
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_RMAX16 / 4 * 32];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
-    uint4 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane * 2;
+    uint2 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane;
     uint2 *lds_wave = lds_prof[wv];
     const lds_u2p lp = (lds_u2p)lds_wave;
-    const v2s goe = as_v2s(p.goe_pk), ge = as_v2s(p.ge_pk);
 
     for (;;) {
         uint32_t it = 0;
@@ -250,7 +350,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_pk16(OswSear
             const uint32_t row0 = s * Rb;
             const int R = (int)((m4 - row0) < Rb ? (m4 - row0) : Rb);
             load_profile_strip(p.prof, prof0 + row0 / 4, R, lds_wave, lane);
-            sw_strip_dispatch<CellPK16>(R, tb, ncols4, lp, bnd, s == 0, s + 1 == S, 0, goe, ge, score);
+            sw_strip_dispatch_pk16(R, tb, ncols4, lp, bnd, s == 0, s + 1 == S, p.goe_pk, p.ge_pk, score);
         }
         // exact unless the int16 ceiling was touched
         int2 out;
@@ -277,7 +377,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
-    uint4 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane * 2;
+    uint2 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane;
     uint2 *lds_wave = lds_prof[wv];
     const lds_u2p lp = (lds_u2p)lds_wave;
     const int goe = p.goe, ge = p.ge;
@@ -333,8 +433,8 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__re
     const bool have = g < ngroups;
     const uint32_t ng = have ? n[g] : 0;
     const uint8_t *src = b + (have ? disp[g] : 0) + l;
-    // one extra (all-dummy) group past the end: the search kernels prefetch it
-    for (uint32_t c4 = wv; c4 <= blk.ncols4_alloc; c4 += 4) {
+    // two extra (all-dummy) groups past the end: the search kernels prefetch them
+    for (uint32_t c4 = wv; c4 < blk.ncols4_alloc + 2; c4 += 4) {
         uint32_t lo = 0, hi = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -175,8 +175,8 @@ def test_chunks_equal_single_chunk(hip_ctx, oracle):
     bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
     sm = submat.load("blosum62")
     whole = run_gpu(hip_ctx, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
-    plan = dblayout.chunk_plan(nfull, 16, 40000, 1)
-    assert len(plan) >= 3
+    plan = dblayout.chunk_plan(nfull, 16, 30000, 1)
+    assert len(plan) >= 2
     parts = []
     for g0, g1 in plan:
         b, n, disp = dblayout.interleave(sl, sr, so, 16, g_begin=g0, g_end=g1)
