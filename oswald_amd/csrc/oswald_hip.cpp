@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -67,6 +68,7 @@ struct Chunk {
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     uint32_t nitems = 0;
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
+    int items_bits = 0;                 // cell width it was planned for
     bool searched = false;
 };
 
@@ -143,30 +145,66 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     return 0;
 }
 
-// Work queue of a chunk for the current query set: (query, block) pairs,
-// heaviest (rows x columns) first so that the tail of the launch is short.
+// Work queue of a chunk for the current query set.  An item is (query, block,
+// sub-block, geometry G): G = 1 is a whole 128-sequence block on one wave; a
+// heavy item (many strips x many columns) is cut into G sub-blocks of 128/G
+// sequences whose G strips run side by side in the wave, so that no item is
+// longer than about half a wave's fair share of the launch.  Heaviest first.
 int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
 {
-    if (c.items_version == ctx->queries_version) return 0;
+    if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0;
     const uint32_t nq = ctx->nq;
-    struct It { uint64_t cost; uint32_t q, b; };
+    const bool i32 = ctx->cell_bits == 32;
+    const uint32_t rmax = i32 ? OSW_RMAX32 : OSW_RMAX16, ldsr = i32 ? OSW_LDS_ROWS32 : OSW_LDS_ROWS16;
+    std::vector<uint32_t> strips(nq), lgmax(nq);
+    double total = 0;
+    uint64_t cols = 0;
+    for (uint32_t b = 0; b < c.nblocks; ++b) cols += (uint64_t)c.ncols4_alloc[b] * 4;
+    for (uint32_t q = 0; q < nq; ++q) {
+        uint32_t rounds, R, m4;
+        osw_plan(ctx->m[q], 1, ldsr, rmax, &rounds, &R, &m4);
+        strips[q] = rounds;
+        total += (double)rounds * (double)cols;
+        // widest geometry that keeps strips of >= 8 rows (per-column overhead) and G <= 16
+        uint32_t lg = 0;
+        while (lg < 4) {
+            osw_plan(ctx->m[q], 2u << lg, ldsr, rmax, &rounds, &R, &m4);
+            if (R < 8 || (2u << lg) * 8 > m4) break;
+            ++lg;
+        }
+        lgmax[q] = lg;
+    }
+    const double nwaves = (double)d.grid * (OSW_WG_THREADS / 64);
+    const double target = std::max(total / nwaves / 2.0, 2048.0);
+    // test hook: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k
+    int force_lg = -1;
+    if (const char *e = getenv("OSWALD_HIP_FORCE_LG")) force_lg = atoi(e);
+    if (force_lg > (i32 ? 6 : 5)) force_lg = i32 ? 6 : 5;
+    struct It { double cost; uint32_t x, b; };
     std::vector<It> its;
-    its.reserve((size_t)nq * c.nblocks);
+    its.reserve((size_t)nq * c.nblocks + 1024);
     for (uint32_t q = 0; q < nq; ++q)
-        for (uint32_t b = 0; b < c.nblocks; ++b)
-            its.push_back({(uint64_t)(ctx->m[q] ? ctx->m[q] : 1) * (c.ncols4_alloc[b] + 1), q, b});
+        for (uint32_t b = 0; b < c.nblocks; ++b) {
+            const double steps = (double)strips[q] * (c.ncols4_alloc[b] * 4.0 + 1.0);
+            uint32_t lg = 0;
+            while (lg < lgmax[q] && steps / (double)(1u << lg) > target) ++lg;
+            if (force_lg >= 0) lg = (uint32_t)force_lg;
+            const uint32_t G = 1u << lg;
+            for (uint32_t s = 0; s < G; ++s) its.push_back({steps / G, OSW_ITEM_PACK(q, s, lg, 3u), b});
+        }
     std::stable_sort(its.begin(), its.end(), [](const It &x, const It &y) { return x.cost > y.cost; });
     std::vector<uint2> flat(its.size());
-    for (size_t i = 0; i < its.size(); ++i) flat[i] = make_uint2(its[i].q, its[i].b);
+    for (size_t i = 0; i < its.size(); ++i) flat[i] = make_uint2(its[i].x, its[i].b);
     c.nitems = (uint32_t)flat.size();
     HIP_TRY(c.items.reserve(flat.size() * sizeof(uint2) + 16));
-    HIP_TRY(c.ovf.reserve(flat.size() * sizeof(uint2) + 16));
+    HIP_TRY(c.ovf.reserve((size_t)nq * c.nblocks * 64 * sizeof(uint2) + 16));
     HIP_TRY(c.scores.reserve((size_t)nq * c.score_stride * sizeof(int32_t) + 16));
     if (!flat.empty()) {
         HIP_TRY(hipMemcpyAsync(c.items.p, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipStreamSynchronize(d.stream));
     }
     c.items_version = ctx->queries_version;
+    c.items_bits = ctx->cell_bits;
     return 0;
 }
 
@@ -348,7 +386,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         off += (uint64_t)nc4 + 2; // + the two prefetch pad groups
     }
     c.total_col4 = off;
-    HIP_TRY(c.tiled.reserve(off * 64 * sizeof(uint2) + 1024));
+    HIP_TRY(c.tiled.reserve((off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2)));
     HIP_TRY(c.blocks.reserve(c.nblocks * sizeof(OswBlock) + 16));
     HIP_TRY(d.staging_b.reserve(vD + 64));
     HIP_TRY(d.staging_n.reserve(ngroups * sizeof(uint16_t) + 16));
@@ -362,7 +400,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint2 *)c.tiled.p, d.stream));
     }
     // strip-boundary scratch: one region per resident wave, sized for the longest block
-    const uint64_t stride = ((uint64_t)c.max_ncols4 * 4 + 8) * 64; // uint2 per wave slot
+    const uint64_t stride = ((uint64_t)c.max_ncols4 * 4 + OSW_SCRATCH_PAD_COLS) * 64; // uint2 per wave slot
     if (stride > d.bnd_stride) {
         const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
         HIP_TRY(hipStreamSynchronize(d.stream));

@@ -9,7 +9,40 @@
 #define OSW_WG_THREADS 256   // 4 waves per workgroup, each wave independent
 #define OSW_RMAX16 32        // query rows per strip, packed int16 kernel
 #define OSW_RMAX32 16        // query rows per strip, int32 kernel
+#define OSW_LDS_ROWS16 128   // profile rows a wave keeps in LDS per round (8 KB), packed int16 kernel
+#define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
 #define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
+#define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64)
+#define OSW_TILED_TAIL_GROUPS 24 // readable 4-column groups past the last block (drain of G <= 64)
+
+// Work item: x = query | sub-block << 16 | log2(G) << 24 | halves << 28, y = block.
+// G = lane groups of the wave geometry; sub-block = which 64/G lanes (sequence
+// pairs) of the block; halves (int32 kernel) = which sequence of each pair.
+#define OSW_ITEM_PACK(q, sigma, lg, halves) ((uint32_t)(q) | ((uint32_t)(sigma) << 16) | ((uint32_t)(lg) << 24) | ((uint32_t)(halves) << 28))
+#define OSW_ITEM_Q(x) ((x) & 0xffffu)
+#define OSW_ITEM_SIGMA(x) (((x) >> 16) & 0xffu)
+#define OSW_ITEM_LG(x) (((x) >> 24) & 0xfu)
+#define OSW_ITEM_HALVES(x) (((x) >> 28) & 3u)
+
+// Strip plan of a query of m rows at geometry G: `rounds` rounds of G strips of
+// R rows each (R a multiple of 4, G*R <= lds_rows, R <= rmax).  Rows past the
+// query are zero-score rows: they cannot raise a maximum.  Shared by the host
+// (work-queue costs) and the kernels.
+static __host__ __device__ inline void osw_plan(uint32_t m, uint32_t G, uint32_t lds_rows, uint32_t rmax, uint32_t *rounds,
+                                                uint32_t *R, uint32_t *m4_out)
+{
+    uint32_t m4 = (m + 3u) & ~3u;
+    if (m4 == 0) m4 = 4;
+    uint32_t rcap = (lds_rows / G) & ~3u;
+    if (rcap > rmax) rcap = rmax;
+    if (rcap < 4) rcap = 4;
+    const uint32_t nr = (m4 + G * rcap - 1) / (G * rcap);
+    uint32_t r = (m4 + G * nr - 1) / (G * nr);
+    r = (r + 3u) & ~3u;
+    *rounds = nr;
+    *R = r;
+    *m4_out = m4;
+}
 
 // device counters (uint32), zeroed before every search launch pair
 #define OSW_CTR_WORK 0       // next item of the pk16 queue

@@ -5,24 +5,33 @@
 // profile build feeding it (reference host/src/FPGAsearch.c:143-177).
 //
 // Formulation (MI355X-first, not a translation of the 28-wide FPGA pipeline):
-//   * inter-sequence parallel: one wave = one "block" of 128 database
+//   * inter-sequence parallel: a wave works on a "block" of 128 database
 //     sequences, 2 per lane, packed as the two 16-bit halves of a VGPR
 //     (v_pk_add_i16 clamp / v_pk_max_i16 / v_pk_sub_u16 clamp).  No MFMA: this
-//     is integer DP.
-//   * the query is cut into strips of R<=32 rows held in registers (H and E
-//     of every row, 2 VGPRs per row); the database columns stream through.
-//     The strip's slice of the query profile (R x 32 codes x int16 = 2 KB)
-//     lives in a wave-private LDS region and is read with conflict-free
-//     ds_read_b64 (4 rows per read, address = residue*8 + imm).
-//   * between strips the bottom row (H,F per column) spills to a wave-private
-//     HBM scratch, coalesced 32 B per lane per 4 columns, prefetched one
-//     group ahead.
-//   * work items (query, block) are pulled from an atomic queue sorted by
-//     cost, so one launch covers all queries of a chunk; every wave exits
-//     when the queue is drained (no inter-wave waits anywhere).
-//   * cells that hit the int16 ceiling are queued on the device and re-run by
+//     is integer DP.  Packed-int16 VALU issues at 4 cycles per wave
+//     instruction per SIMD on gfx950 (measured, tools/ubench.hip), so the cell
+//     is kept at 9 VOP3P instructions + 1 v_perm_b32 and hand-scheduled.
+//   * the query is cut into strips of R <= 32 rows held in registers (E and
+//     the diagonal H of every row, 2 VGPRs per row); database columns stream
+//     through.  The strip's slice of the query profile lives in a wave-private
+//     LDS region and is read with conflict-free ds_read_b64 (4 rows per read,
+//     address = residue*8 + imm).
+//   * "wave geometry" G (1,2,4,...,64): the 64 lanes form G groups of 64/G
+//     lanes.  Group g runs strip (round*G + g) of the SAME 128/G sequences, one
+//     column behind group g-1, and receives that group's bottom row (H, F) and
+//     residues through ds_bpermute -- a systolic array inside the wave, no
+//     inter-wave synchronisation anywhere.  G = 1 is the plain case; larger G
+//     shortens the critical path of heavy (long query x long sequence) items by
+//     G so that the work queue balances, and G = 64 is the exact int32 re-run
+//     of single lanes.
+//   * between rounds the bottom row of the last group spills to a wave-private
+//     HBM scratch {H, F} per column and lane, read back one column ahead.
+//   * work items (query, block, sub-block, G) are pulled from an atomic queue
+//     sorted by cost, so one launch covers all queries of a chunk; every wave
+//     exits when the queue is drained.
+//   * lanes that hit the int16 ceiling are queued on the device and re-run by
 //     the int32 kernel (the reference's int8->int16->int32 escalation,
-//     host/src/HybridSearch.c:1670-1680,:1774-1784, gives exact scores; so
+//     host/src/HybridSearch.c:1670-1680,:1774-1784, yields exact scores; so
 //     does this).
 //
 // Recurrence (reference sw.cl:60-78): H = max(0, Hdiag + S, E, F);
@@ -37,141 +46,20 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const u32x2 *lds_u2p;
+typedef __attribute__((address_space(3))) const char *lds_cp;
 
 static __device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
 static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
 
 // ---------------------------------------------------------------------------
-// Cell arithmetic.  PK16: two sequences per lane in packed int16.  I32: one
-// sequence per lane, plain int32 (the exact fallback).
-// ---------------------------------------------------------------------------
-struct CellPK16 {
-    typedef v2s T;
-    static constexpr int kRows = OSW_RMAX16;
-    static __device__ __forceinline__ T zero() { return (T)(0); }
-    static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
-    static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
-    static __device__ __forceinline__ T splat(int x) { return (T)((short)x); }
-    // H candidates: signed saturating add, signed max (all operands of max are in [ -128, 32767 ])
-    static __device__ __forceinline__ T add_sat(T a, T b) { return __builtin_elementwise_add_sat(a, b); }
-    static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
-    // gap states stay in [0, 32767]: unsigned saturating subtract clamps at 0
-    static __device__ __forceinline__ T sub_floor0(T a, T b)
-    {
-        return __builtin_bit_cast(T, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b)));
-    }
-    static __device__ __forceinline__ T hmax(T h, T e, T f) { return vmax(vmax(h, e), f); }
-    // four rows of substitution scores for both sequences of the lane
-    static __device__ __forceinline__ void load_s(lds_u2p lp, uint32_t alo, uint32_t ahi, int rb, int /*half*/, T (&s)[4])
-    {
-        const u32x2 plo = *(lds_u2p)((__attribute__((address_space(3))) const char *)lp + alo + rb * 256);
-        const u32x2 phi = *(lds_u2p)((__attribute__((address_space(3))) const char *)lp + ahi + rb * 256);
-        s[0] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x05040100u));
-        s[1] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x07060302u));
-        s[2] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x05040100u));
-        s[3] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x07060302u));
-    }
-};
-
-struct CellI32 {
-    typedef int T;
-    static constexpr int kRows = OSW_RMAX32;
-    static __device__ __forceinline__ T zero() { return 0; }
-    static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
-    static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
-    static __device__ __forceinline__ T splat(int x) { return x; }
-    static __device__ __forceinline__ T add_sat(T a, T b) { return a + b; }
-    static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
-    static __device__ __forceinline__ T sub_floor0(T a, T b) { return vmax(a - b, 0); }
-    static __device__ __forceinline__ T hmax(T h, T e, T f) { return vmax(vmax(h, e), f); }
-    static __device__ __forceinline__ void load_s(lds_u2p lp, uint32_t alo, uint32_t ahi, int rb, int half, T (&s)[4])
-    {
-        const uint32_t a = half ? ahi : alo;
-        const u32x2 p = *(lds_u2p)((__attribute__((address_space(3))) const char *)lp + a + rb * 256);
-        s[0] = (int)(short)(p.x & 0xffffu);
-        s[1] = (int)p.x >> 16;
-        s[2] = (int)(short)(p.y & 0xffffu);
-        s[3] = (int)p.y >> 16;
-    }
-};
-
-// One database column against the R rows of the strip.
-//   diag_top = H(i0-1, j-1), h_top = H(i0-1, j), f = F(i0, j) on entry;
-//   on exit f = F(i0+R, j) and H[R-1] = H(i0+R-1, j): the next strip's top.
-template <class C, int R>
-static __device__ __forceinline__ void sw_column(lds_u2p lp, uint32_t rlo, uint32_t rhi, int half,
-                                                 typename C::T (&H)[R], typename C::T (&E)[R],
-                                                 typename C::T diag, typename C::T &f,
-                                                 typename C::T goe, typename C::T ge, typename C::T &score)
-{
-    typedef typename C::T T;
-    const uint32_t alo = (rlo & 31u) * 8u, ahi = (rhi & 31u) * 8u;
-#pragma unroll
-    for (int rb = 0; rb < R / 4; ++rb) {
-        T s[4];
-        C::load_s(lp, alo, ahi, rb, half, s);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = rb * 4 + k;
-            T h = C::add_sat(diag, s[k]);
-            h = C::hmax(h, E[r], f);
-            const T t = C::sub_floor0(h, goe);
-            E[r] = C::vmax(C::sub_floor0(E[r], ge), t);
-            f = C::vmax(C::sub_floor0(f, ge), t);
-            score = C::vmax(score, h);
-            diag = H[r];
-            H[r] = h;
-        }
-    }
-}
-
-// All columns of one block against one strip of R rows.
-//   tb  : tiled residues of the block, already offset by lane; [c4*64] uint2
-//   bnd : this wave's spill scratch, already offset by lane; [col*64] uint2 = {H, F}
-// One column per loop iteration (not unrolled: the 2R state registers are
-// updated in place, which keeps the kernel at 4 waves per SIMD); residues
-// arrive 4 columns per load, boundary values one column ahead.
-template <class C, int R>
-static __device__ __forceinline__ void sw_strip(const uint2 *__restrict__ tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
-                                                bool first, bool last, int half,
-                                                typename C::T goe, typename C::T ge, typename C::T &score)
-{
-    typedef typename C::T T;
-    T H[R], E[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { H[r] = C::zero(); E[r] = C::zero(); }
-    T top_prev = C::zero(); // H(i0-1, j-1)
-    uint2 res = tb[0], res_n = tb[64];
-    uint2 bcur = make_uint2(0, 0);
-    if (!first) bcur = bnd[0];
-    const uint32_t ncols = ncols4 * 4;
-#pragma unroll 1
-    for (uint32_t j = 0; j < ncols; ++j) {
-        uint2 bnxt = make_uint2(0, 0);
-        if (!first) bnxt = bnd[(size_t)(j + 1) * 64]; // scratch is padded by one column
-        const T top = C::from_bits(bcur.x);
-        T f = C::from_bits(bcur.y);
-        sw_column<C, R>(lp, res.x, res.y, half, H, E, top_prev, f, goe, ge, score);
-        top_prev = top;
-        if (!last) bnd[(size_t)j * 64] = make_uint2(C::to_bits(H[R - 1]), C::to_bits(f));
-        res.x >>= 8;
-        res.y >>= 8;
-        if ((j & 3u) == 3u) {
-            res = res_n;
-            res_n = tb[(size_t)((j >> 2) + 2) * 64]; // tiled is padded by two groups
-        }
-        bcur = bnxt;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Packed-int16 strip with a hand-scheduled cell.  State per row r: E[r] and
-// D[r] = H(i0+r-1, j-1), the diagonal input of row r (D[0] comes from the strip
-// above).  The cell of row r is 9 VOP3P instructions; it also issues the
-// diagonal add of row r+1 *before* it overwrites D[r+1] with its own H, so
-// every state register is updated in place (no copies), and every result is
-// consumed at a distance of >= 2 issue slots, which is what gfx950 needs
-// between a packed-math write and a dependent VALU read (no s_nop).
+// Packed-int16 cell, hand-scheduled.  State per row r: E[r] and D[r] =
+// H(i0+r-1, j-1), the diagonal input of row r (D[0] is only a name: the top
+// input comes from the strip above).  The cell of row r is 9 VOP3P
+// instructions; it also issues the diagonal add of row r+1 *before* it
+// overwrites D[r+1] with its own H, so every state register is updated in
+// place (no copies), and every result is consumed at a distance of >= 2 issue
+// slots, which is what gfx950 needs between a packed-math write and a dependent
+// VALU read (no s_nop inside the cell).
 //   x   in: D[r] + S[r]          out: D[r+1] + S[r+1]
 //   Dn  in: D[r+1] (old column)  out: H(i0+r, j)  (= D[r+1] of the next column)
 // ---------------------------------------------------------------------------
@@ -191,7 +79,7 @@ static __device__ __forceinline__ void sw_strip(const uint2 *__restrict__ tb, ui
                      : [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe));                   \
     } while (0)
 
-// last row of the strip: its H goes to `hl` (the spill), there is no next row
+// last row of the strip: its H goes to `hl` (handed to the next strip)
 #define OSW_PK16_ROW_LAST(x, Er, hl, f, sc, ge, goe)                                         \
     do {                                                                                     \
         v2s tmp_;                                                                            \
@@ -207,30 +95,40 @@ static __device__ __forceinline__ void sw_strip(const uint2 *__restrict__ tb, ui
                      : [x_] "v"(x), [ge_] "s"(ge), [goe_] "s"(goe));                         \
     } while (0)
 
-template <int R>
-static __device__ __forceinline__ void sw_strip_pk16(const uint2 *__restrict__ tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
-                                                     bool first, bool last, uint32_t goe, uint32_t ge, v2s &score)
-{
-    v2s D[R], E[R]; // D[0] is only a name for the top input
-#pragma unroll
-    for (int r = 0; r < R; ++r) { D[r] = (v2s)(0); E[r] = (v2s)(0); }
-    v2s top_prev = (v2s)(0); // H(i0-1, j-1)
-    uint2 res = tb[0], res_n = tb[64];
-    uint2 bcur = make_uint2(0, 0);
-    if (!first) bcur = bnd[0];
-    const uint32_t ncols = ncols4 * 4;
-#pragma unroll 1
-    for (uint32_t j = 0; j < ncols; ++j) {
-        uint2 bnxt = make_uint2(0, 0);
-        if (!first) bnxt = bnd[(size_t)(j + 1) * 64]; // scratch is padded by one column
-        const uint32_t alo = (res.x & 31u) * 8u, ahi = (res.y & 31u) * 8u;
-        v2s f = as_v2s(bcur.y);
-        v2s s[4], sn[4], hl;
-        CellPK16::load_s(lp, alo, ahi, 0, 0, s);
-        v2s x = __builtin_elementwise_add_sat(top_prev, s[0]);
+struct CellPK16 {
+    typedef v2s T;
+    typedef uint32_t GapT; // (value, value) packed, wave-uniform
+    static constexpr int kRows = OSW_RMAX16;
+    static constexpr int kLdsRows = OSW_LDS_ROWS16;
+    static __device__ __forceinline__ T zero() { return (T)(0); }
+    static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
+    static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
+    static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
+
+    // four rows of substitution scores for both sequences of the lane:
+    // two ds_read_b64 + four v_perm_b32 that pair up (seq lo, seq hi)
+    static __device__ __forceinline__ void load_s(lds_u2p lp, uint32_t alo, uint32_t ahi, int rb, T (&s)[4])
+    {
+        const u32x2 plo = *(lds_u2p)((lds_cp)lp + alo + rb * 256);
+        const u32x2 phi = *(lds_u2p)((lds_cp)lp + ahi + rb * 256);
+        s[0] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x05040100u));
+        s[1] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x07060302u));
+        s[2] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x05040100u));
+        s[3] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x07060302u));
+    }
+
+    // One database column against the R rows of the strip.
+    //   top_prev = H(i0-1, j-1); f in: F(i0, j), out: F(i0+R, j); hl = H(i0+R-1, j)
+    template <int R>
+    static __device__ __forceinline__ void column(lds_u2p lp, uint32_t alo, uint32_t ahi, int /*half*/, T (&D)[R], T (&E)[R],
+                                                  T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
+    {
+        T s[4], sn[4];
+        load_s(lp, alo, ahi, 0, s);
+        T x = __builtin_elementwise_add_sat(top_prev, s[0]);
 #pragma unroll
         for (int rb = 0; rb < R / 4; ++rb) {
-            if (rb + 1 < R / 4) CellPK16::load_s(lp, alo, ahi, rb + 1, 0, sn);
+            if (rb + 1 < R / 4) load_s(lp, alo, ahi, rb + 1, sn);
             OSW_PK16_ROW(x, E[rb * 4 + 0], D[rb * 4 + 1], f, score, s[1], ge, goe);
             OSW_PK16_ROW(x, E[rb * 4 + 1], D[rb * 4 + 2], f, score, s[2], ge, goe);
             OSW_PK16_ROW(x, E[rb * 4 + 2], D[rb * 4 + 3], f, score, s[3], ge, goe);
@@ -242,51 +140,116 @@ static __device__ __forceinline__ void sw_strip_pk16(const uint2 *__restrict__ t
                 OSW_PK16_ROW_LAST(x, E[rb * 4 + 3], hl, f, score, ge, goe);
             }
         }
-        top_prev = as_v2s(bcur.x);
-        if (!last) bnd[(size_t)j * 64] = make_uint2(as_u32(hl), as_u32(f));
+    }
+};
+
+// Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.
+struct CellI32 {
+    typedef int T;
+    typedef int GapT;
+    static constexpr int kRows = OSW_RMAX32;
+    static constexpr int kLdsRows = OSW_LDS_ROWS32;
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
+    static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
+    static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
+
+    template <int R>
+    static __device__ __forceinline__ void column(lds_u2p lp, uint32_t alo, uint32_t ahi, int half, T (&D)[R], T (&E)[R],
+                                                  T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
+    {
+        const uint32_t a = half ? ahi : alo;
+        T diag = top_prev;
+#pragma unroll
+        for (int rb = 0; rb < R / 4; ++rb) {
+            const u32x2 p = *(lds_u2p)((lds_cp)lp + a + rb * 256);
+            const int s[4] = {(int)(short)(p.x & 0xffffu), (int)p.x >> 16, (int)(short)(p.y & 0xffffu), (int)p.y >> 16};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rb * 4 + k;
+                T h = vmax(vmax(diag + s[k], E[r]), f);
+                const T t = vmax(h - goe, 0);
+                E[r] = vmax(vmax(E[r] - ge, 0), t);
+                f = vmax(vmax(f - ge, 0), t);
+                score = vmax(score, h);
+                if (r + 1 < R) { diag = D[r + 1]; D[r + 1] = h; } else { hl = h; }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// One round: G lane groups, group g runs R rows of strip (round*G + g), one
+// column behind group g-1.
+//   tb   : tiled residues of the lane's sequences (lane-offset applied), [c4*64]
+//   lp   : this lane's profile slice in LDS (wave region + g*R rows)
+//   bnd  : wave scratch, lane-offset u = lane % gl applied, [col*64] = {H, F}
+// ---------------------------------------------------------------------------
+template <class C, int R>
+static __device__ __forceinline__ void sw_round(const uint2 *__restrict__ tb, uint32_t ncols, lds_u2p lp, uint2 *bnd,
+                                                bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
+                                                typename C::GapT goe, typename C::GapT ge, typename C::T &score)
+{
+    typedef typename C::T T;
+    T D[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { D[r] = C::zero(); E[r] = C::zero(); }
+    T top_prev = C::zero(); // H(i0-1, j-1)
+    const bool g0 = (uint32_t)lane < gl;
+    const bool glast = (uint32_t)lane >= 64u - gl;
+    const int src = ((lane - (int)gl) & 63) << 2; // ds_bpermute source: the lane one group below
+    uint32_t hand_h = 0, hand_f = 0, hand_c = 0x1717u;
+    uint2 res = tb[0], res_n = tb[64];
+    uint2 bcur = make_uint2(0, 0);
+    if (!first) bcur = bnd[0];
+    const uint32_t nsteps = ncols + G - 1;
+#pragma unroll 1
+    for (uint32_t t = 0; t < nsteps; ++t) {
+        uint2 bnxt = make_uint2(0, 0);
+        if (!first) bnxt = bnd[(size_t)(t + 1) * 64]; // scratch is padded past the last column
+        // inputs of group 0: column t of the stream (dummy residues / zeros once it has ended)
+        uint32_t codes = (res.x & 0xffu) | ((res.y & 0xffu) << 8);
+        uint32_t topb = bcur.x, fb = bcur.y;
+        if (t >= ncols) { codes = 0x1717u; topb = 0; fb = 0; }
+        // every other group takes what the group below produced in the previous step
+        if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
+        const uint32_t alo = (codes & 31u) * 8u, ahi = ((codes >> 8) & 31u) * 8u;
+        T f = C::from_bits(fb), hl;
+        C::template column<R>(lp, alo, ahi, half, D, E, top_prev, f, hl, goe, ge, score);
+        top_prev = C::from_bits(topb);
+        if (!last && t + 1 >= G && glast) bnd[(size_t)(t + 1 - G) * 64] = make_uint2(C::to_bits(hl), C::to_bits(f));
+        if (G > 1) {
+            hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(hl));
+            hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(f));
+            hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
+        }
         res.x >>= 8;
         res.y >>= 8;
-        if ((j & 3u) == 3u) {
+        if ((t & 3u) == 3u) {
             res = res_n;
-            res_n = tb[(size_t)((j >> 2) + 2) * 64]; // tiled is padded by two groups
+            res_n = tb[(size_t)((t >> 2) + 2) * 64]; // tiled is padded at its end
         }
         bcur = bnxt;
     }
 }
 
-static __device__ __forceinline__ void sw_strip_dispatch_pk16(int R, const uint2 *tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
-                                                              bool first, bool last, uint32_t goe, uint32_t ge, v2s &score)
-{
-    switch (R) {
-    case 4: sw_strip_pk16<4>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    case 8: sw_strip_pk16<8>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    case 12: sw_strip_pk16<12>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    case 16: sw_strip_pk16<16>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    case 20: sw_strip_pk16<20>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    case 24: sw_strip_pk16<24>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    case 28: sw_strip_pk16<28>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    case 32: sw_strip_pk16<32>(tb, ncols4, lp, bnd, first, last, goe, ge, score); break;
-    default: break;
-    }
-}
-
 template <class C>
-static __device__ __forceinline__ void sw_strip_dispatch(int R, const uint2 *tb, uint32_t ncols4, lds_u2p lp, uint2 *bnd,
-                                                         bool first, bool last, int half,
-                                                         typename C::T goe, typename C::T ge, typename C::T &score)
+static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint2 *tb, uint32_t ncols, lds_u2p lp, uint2 *bnd,
+                                                         bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
+                                                         typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
     switch (R) {
-    case 4: sw_strip<C, 4>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
-    case 8: sw_strip<C, 8>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
-    case 12: sw_strip<C, 12>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
-    case 16: sw_strip<C, 16>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+    case 4: sw_round<C, 4>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+    case 8: sw_round<C, 8>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+    case 12: sw_round<C, 12>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+    case 16: sw_round<C, 16>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
     default:
         if constexpr (C::kRows > 16) {
             switch (R) {
-            case 20: sw_strip<C, 20>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
-            case 24: sw_strip<C, 24>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
-            case 28: sw_strip<C, 28>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
-            case 32: sw_strip<C, 32>(tb, ncols4, lp, bnd, first, last, half, goe, ge, score); break;
+            case 20: sw_round<C, 20>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+            case 24: sw_round<C, 24>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+            case 28: sw_round<C, 28>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+            case 32: sw_round<C, 32>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
             default: break;
             }
         }
@@ -294,43 +257,64 @@ static __device__ __forceinline__ void sw_strip_dispatch(int R, const uint2 *tb,
     }
 }
 
-// Strip schedule shared by both kernels: S strips of Rb rows, the last one
-// shorter; every height is a multiple of 4 (the profile is padded with
-// all-zero rows, which cannot raise a maximum).
-static __device__ __forceinline__ void strip_plan(uint32_t m, int rmax, uint32_t &S, uint32_t &Rb, uint32_t &m4)
-{
-    m4 = (m + 3u) & ~3u;
-    if (m4 == 0) m4 = 4;
-    S = (m4 + rmax - 1) / rmax;
-    Rb = (((m4 + S - 1) / S) + 3u) & ~3u;
-}
-
-// Copy the strip's profile slice (R rows = R/4 row-blocks of 256 B) into the
-// wave's LDS region.  Only this wave touches the region; LDS operations of one
-// wave execute in order, the wave barriers only pin the compiler's order.
-static __device__ __forceinline__ void load_profile_strip(const uint2 *prof, uint32_t rowblock0, int R, uint2 *lds_wave, int lane)
+// Copy the round's profile slice (nrb row-blocks of 256 B from row-block rb0;
+// row-blocks at or past rb_end are beyond the query and read as zero scores)
+// into the wave's LDS region.  Only this wave touches the region; LDS
+// operations of one wave execute in order, the wave barriers only pin the
+// compiler's order.
+static __device__ __forceinline__ void load_profile_round(const uint2 *prof_q, uint32_t rb0, uint32_t nrb, uint32_t rb_end,
+                                                          uint2 *lds_wave, int lane)
 {
     __builtin_amdgcn_wave_barrier();
-    const uint4 *src = (const uint4 *)(prof + (size_t)rowblock0 * 32);
+    const uint4 *src = (const uint4 *)(prof_q + (size_t)rb0 * 32);
     uint4 *dst = (uint4 *)lds_wave;
-    const int n16 = (R / 4) * 16;
-    for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+    const uint32_t n16 = nrb * 16;
+    const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * 16 : 0;
+    for (uint32_t i = lane; i < n16; i += 64) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
+// One work item: all rounds of (query q, block B, sub-block sigma) at geometry G.
+// Returns the lane's best score (valid in the lanes of group 0 after the
+// cross-group reduction).
+template <class C>
+static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, uint32_t q, const OswBlock &blk, uint32_t sigma,
+                                                         uint32_t lg, int lane, int half, uint2 *lds_wave, uint2 *bnd_wave,
+                                                         typename C::GapT goe, typename C::GapT ge)
+{
+    typedef typename C::T T;
+    const uint32_t G = 1u << lg, gl = 64u >> lg;
+    const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
+    const uint32_t ncols = __builtin_amdgcn_readfirstlane(blk.ncols4) * 4;
+    const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + sigma * gl + u;
+    uint2 *bnd = bnd_wave + u;
+    uint32_t rounds, R, m4;
+    osw_plan(p.qlen[q], G, C::kLdsRows, C::kRows, &rounds, &R, &m4);
+    const uint2 *prof_q = p.prof + (size_t)p.prof_off[q] * 32;
+    const lds_u2p lp = (lds_u2p)((lds_cp)lds_wave + g * R * 64);
+    T score = C::zero();
+    for (uint32_t rho = 0; rho < rounds; ++rho) {
+        load_profile_round(prof_q, rho * G * R / 4, G * R / 4, m4 / 4, lds_wave, lane);
+        sw_round_dispatch<C>(R, tb, ncols, lp, bnd, rho == 0, rho + 1 == rounds, G, gl, lane, half, goe, ge, score);
+    }
+    // best over the strips = best over the lane groups
+    for (uint32_t off = gl; off < 64; off <<= 1)
+        score = C::vmax(score, C::from_bits((uint32_t)__shfl_xor((int)C::to_bits(score), (int)off)));
+    return score;
+}
+
 // ---------------------------------------------------------------------------
-// Main kernel: packed int16, all (query, block) items of a chunk.
+// Main kernel: packed int16.
 // ---------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p)
 {
-    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_RMAX16 / 4 * 32];
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
-    uint2 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane;
+    uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
     uint2 *lds_wave = lds_prof[wv];
-    const lds_u2p lp = (lds_u2p)lds_wave;
 
     for (;;) {
         uint32_t it = 0;
@@ -338,49 +322,39 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
         it = __builtin_amdgcn_readfirstlane(it);
         if (it >= p.nitems) break;
         const uint2 item = p.items[it];
-        const uint32_t q = item.x, B = item.y;
+        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
-        const uint32_t ncols4 = __builtin_amdgcn_readfirstlane(blk.ncols4);
-        const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + lane;
-        uint32_t S, Rb, m4;
-        strip_plan(p.qlen[q], OSW_RMAX16, S, Rb, m4);
-        const uint32_t prof0 = p.prof_off[q];
-        v2s score = (v2s)(0);
-        for (uint32_t s = 0; s < S; ++s) {
-            const uint32_t row0 = s * Rb;
-            const int R = (int)((m4 - row0) < Rb ? (m4 - row0) : Rb);
-            load_profile_strip(p.prof, prof0 + row0 / 4, R, lds_wave, lane);
-            sw_strip_dispatch_pk16(R, tb, ncols4, lp, bnd, s == 0, s + 1 == S, p.goe_pk, p.ge_pk, score);
-        }
-        // exact unless the int16 ceiling was touched
-        int2 out;
-        out.x = score.x;
-        out.y = score.y;
-        *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lane) = out;
-        const bool ovf = (score.x == 32767) | (score.y == 32767);
-        if (__any(ovf)) {
-            if (lane == 0) {
+        const v2s score = run_item<CellPK16>(p, q, blk, sigma, lg, lane, 0, lds_wave, bnd_wave, p.goe_pk, p.ge_pk);
+        const uint32_t gl = 64u >> lg;
+        if ((uint32_t)lane < gl) {
+            const uint32_t lam = sigma * gl + lane; // lane of the block = sequence pair
+            int2 out;
+            out.x = score.x;
+            out.y = score.y;
+            *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lam) = out;
+            // exact unless the int16 ceiling was touched: queue the pair for the int32 kernel
+            const uint32_t hm = (score.x == 32767 ? 1u : 0u) | (score.y == 32767 ? 2u : 0u);
+            if (hm) {
                 const uint32_t k = atomicAdd(&p.counters[OSW_CTR_OVF], 1u);
-                p.ovf_items[k] = item;
+                p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// Exact re-run of the items queued by osw_sw_pk16, plain int32, one sequence
-// per lane, the block's two sequence halves one after the other.
+// Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at
+// geometry 64 (each lane one strip of the same sequence: the whole wave works
+// on one sequence at a time).  force_all: run `items` (cell_bits = 32 mode).
 // ---------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearchArgs p)
 {
-    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_RMAX32 / 4 * 32];
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS32 * 8];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
-    uint2 *bnd = p.bnd + (size_t)slot * p.bnd_stride + lane;
+    uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
     uint2 *lds_wave = lds_prof[wv];
-    const lds_u2p lp = (lds_u2p)lds_wave;
-    const int goe = p.goe, ge = p.ge;
     // the queue length was produced by the previous kernel on this stream
     const uint32_t nitems = p.force_all ? p.nitems : p.counters[OSW_CTR_OVF];
     const uint2 *items = p.force_all ? p.items : p.ovf_items;
@@ -391,22 +365,15 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
         it = __builtin_amdgcn_readfirstlane(it);
         if (it >= nitems) break;
         const uint2 item = items[it];
-        const uint32_t q = item.x, B = item.y;
+        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
+        const uint32_t hm = OSW_ITEM_HALVES(item.x);
         const OswBlock blk = p.blocks[B];
-        const uint32_t ncols4 = __builtin_amdgcn_readfirstlane(blk.ncols4);
-        const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + lane;
-        uint32_t S, Rb, m4;
-        strip_plan(p.qlen[q], OSW_RMAX32, S, Rb, m4);
-        const uint32_t prof0 = p.prof_off[q];
+        const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
-            int score = 0;
-            for (uint32_t s = 0; s < S; ++s) {
-                const uint32_t row0 = s * Rb;
-                const int R = (int)((m4 - row0) < Rb ? (m4 - row0) : Rb);
-                load_profile_strip(p.prof, prof0 + row0 / 4, R, lds_wave, lane);
-                sw_strip_dispatch<CellI32>(R, tb, ncols4, lp, bnd, s == 0, s + 1 == S, half, goe, ge, score);
-            }
-            p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * lane + half] = score;
+            if (!((hm >> half) & 1u)) continue;
+            const int score = run_item<CellI32>(p, q, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge);
+            if ((uint32_t)lane < gl)
+                p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }
     }
 }
@@ -526,9 +493,9 @@ extern "C" __global__ __launch_bounds__(1024) void osw_topr(const int32_t *__res
             const unsigned long long key = ((unsigned long long)(uint32_t)row[i] << 32) | i;
             if (key < bound && (!found || key > best)) { best = key; found = true; }
         }
-        // encode "found" in bit 0 of a shifted key so that an empty thread loses
-        unsigned long long v = found ? ((best << 1) | 1ull) : 0ull;
+        // "found" goes into bit 0 of the shifted key so that an empty thread loses;
         // scores are >= 0 and < 2^31, so best < 2^63 and the shift is lossless
+        unsigned long long v = found ? ((best << 1) | 1ull) : 0ull;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = __shfl_xor(v, off);

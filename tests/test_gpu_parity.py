@@ -182,3 +182,29 @@ def test_chunks_equal_single_chunk(hip_ctx, oracle):
         b, n, disp = dblayout.interleave(sl, sr, so, 16, g_begin=g0, g_end=g1)
         parts.append(run_gpu(hip_ctx, qs, b, n, disp.astype(np.uint32), 16, sm, 10, 2))
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), whole)
+
+
+@pytest.mark.parametrize("lg", [0, 1, 2, 3, 4, 5])
+def test_every_wave_geometry(hip_ctx, oracle, lg, monkeypatch):
+    """G = 2^lg lane groups per wave (systolic strips inside the wave): the
+    result must not depend on the geometry."""
+    monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
+    qs = synth.make_queries([3, 8, 37, 130, 301], seed=40 + lg)
+    L, R, O = random_db(260, seed=50 + lg, max_len=90, queries=qs[-2:], homologs=2)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("lg", [0, 3, 6])
+def test_every_wave_geometry_int32(hip_ctx, oracle, lg, monkeypatch):
+    monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
+    qs = synth.make_queries([5, 70, 260], seed=60 + lg)
+    L, R, O = random_db(140, seed=70 + lg, max_len=80, queries=qs[-1:], homologs=2)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("pam250")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=32)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 14, 2)
+    np.testing.assert_array_equal(got, want)
