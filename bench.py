@@ -176,7 +176,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
                                   "note": "integer DP is VALU-issue bound: 10 packed-int16 ops per 2 cells"}},
-            "rerun_items_int32": int(rerun), "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
+            "rerun_items_int32": int(rerun), "work_items": int(ctx.chunk_geometry(chunk)["work_items"]), "max_log2_geometry": int(ctx.chunk_geometry(chunk)["max_log2_geometry"]), "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
             "setup_s": round(t_gen, 1),
         }
         if args.cpu_seconds > 0:

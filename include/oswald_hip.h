@@ -131,8 +131,9 @@ int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, 
 /* Geometry of a resident chunk as the kernels see it (for roofline accounting):
  * out[0] = wave blocks, out[1] = stored 4-column groups, out[2] = 4-column
  * groups after trimming all-dummy tail columns, out[3] = bytes of re-tiled
- * residues the DP kernel reads per query. */
-int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out4);
+ * residues the DP kernel reads per query, out[4] = work items of the last
+ * search's queue, out[5] = log2 of the widest wave geometry in it. */
+int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out6);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,7 @@ class Context:
         return ms.value, n.value, re.value
 
     def chunk_geometry(self, chunk: int, dev: int = 0):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 6)()
         _chk(self.lib.oswald_hip_chunk_geometry(self.h, dev, chunk, out))
-        return {"blocks": out[0], "col4_stored": out[1], "col4_live": out[2], "residue_bytes_per_query": out[3]}
+        return {"blocks": out[0], "col4_stored": out[1], "col4_live": out[2], "residue_bytes_per_query": out[3],
+                "work_items": out[4], "max_log2_geometry": out[5]}

@@ -66,9 +66,10 @@ struct Chunk {
     uint64_t total_col4 = 0;     // stored 4-column groups incl. the pad group per block
     DevBuf tiled, blocks, items, scores, ovf;
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
-    uint32_t nitems = 0;
+    uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
     int items_bits = 0;                 // cell width it was planned for
+    uint32_t max_lg = 0;                // widest geometry in the item list
     bool searched = false;
 };
 
@@ -147,55 +148,95 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
 
 // Work queue of a chunk for the current query set.  An item is (query, block,
 // sub-block, geometry G): G = 1 is a whole 128-sequence block on one wave; a
-// heavy item (many strips x many columns) is cut into G sub-blocks of 128/G
+// heavier item (many strips x many columns) is cut into G sub-blocks of 128/G
 // sequences whose G strips run side by side in the wave, so that no item is
-// longer than about half a wave's fair share of the launch.  Heaviest first.
+// longer than a fraction of a wave's fair share of the launch.  The heaviest
+// ones become workgroup items: four sub-blocks on the four waves of a workgroup
+// sharing one 4x larger profile slice (taller rounds at high G).
+// Cost model in VALU issue slots: rounds x (columns + pipeline fill) x (10 per
+// row + ~35 per column).  Heaviest first within each class.
 int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
 {
     if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0;
     const uint32_t nq = ctx->nq;
     const bool i32 = ctx->cell_bits == 32;
     const uint32_t rmax = i32 ? OSW_RMAX32 : OSW_RMAX16, ldsr = i32 ? OSW_LDS_ROWS32 : OSW_LDS_ROWS16;
-    std::vector<uint32_t> strips(nq), lgmax(nq);
-    double total = 0;
-    uint64_t cols = 0;
-    for (uint32_t b = 0; b < c.nblocks; ++b) cols += (uint64_t)c.ncols4_alloc[b] * 4;
-    for (uint32_t q = 0; q < nq; ++q) {
+    const uint32_t ldsr_wg = ldsr * (OSW_WG_THREADS / 64);
+    auto item_cost = [&](uint32_t m, uint32_t lg, uint32_t ncols, uint32_t lds_rows) {
         uint32_t rounds, R, m4;
-        osw_plan(ctx->m[q], 1, ldsr, rmax, &rounds, &R, &m4);
-        strips[q] = rounds;
-        total += (double)rounds * (double)cols;
-        // widest geometry that keeps strips of >= 8 rows (per-column overhead) and G <= 16
-        uint32_t lg = 0;
-        while (lg < 4) {
-            osw_plan(ctx->m[q], 2u << lg, ldsr, rmax, &rounds, &R, &m4);
-            if (R < 8 || (2u << lg) * 8 > m4) break;
+        osw_plan(m, 1u << lg, lds_rows, rmax, &rounds, &R, &m4);
+        return (double)rounds * (double)(ncols + (1u << lg)) * (10.0 * R + 35.0);
+    };
+    // widest useful geometry per query: strips of >= 8 rows for wave items (per-column
+    // overhead), >= 4 for workgroup items, and no lane group entirely past the query
+    auto lg_limit = [&](uint32_t m, uint32_t lds_rows, uint32_t min_rows) {
+        uint32_t lg = 0, rounds, R, m4;
+        while (lg < 6) {
+            const uint32_t G2 = 2u << lg;
+            osw_plan(m, G2, lds_rows, rmax, &rounds, &R, &m4);
+            if (G2 * R > lds_rows || R < min_rows || G2 * min_rows > m4) break;
             ++lg;
         }
-        lgmax[q] = lg;
+        return lg;
+    };
+    std::vector<uint32_t> lgmax(nq), lgmax_wg(nq);
+    double total = 0;
+    for (uint32_t q = 0; q < nq; ++q) {
+        lgmax[q] = lg_limit(ctx->m[q], ldsr, 8);
+        lgmax_wg[q] = lg_limit(ctx->m[q], ldsr_wg, 4);
+        for (uint32_t b = 0; b < c.nblocks; ++b) total += item_cost(ctx->m[q], 0, c.ncols4_alloc[b] * 4, ldsr);
     }
     const double nwaves = (double)d.grid * (OSW_WG_THREADS / 64);
-    const double target = std::max(total / nwaves / 2.0, 2048.0);
-    // test hook: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k
-    int force_lg = -1;
+    const double target = std::max(total / nwaves / 3.0, 1.0e6);
+    // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
+    // OSWALD_HIP_FORCE_WG=1 runs every item as a workgroup item (G >= 4)
+    int force_lg = -1, force_wg = 0;
     if (const char *e = getenv("OSWALD_HIP_FORCE_LG")) force_lg = atoi(e);
-    if (force_lg > (i32 ? 6 : 5)) force_lg = i32 ? 6 : 5;
+    if (const char *e = getenv("OSWALD_HIP_FORCE_WG")) force_wg = atoi(e);
+    if (force_lg > 6) force_lg = 6;
+    if (i32) force_wg = 0; // the int32 kernel has no workgroup phase
     struct It { double cost; uint32_t x, b; };
-    std::vector<It> its;
+    std::vector<It> its, its_wg;
     its.reserve((size_t)nq * c.nblocks + 1024);
+    c.max_lg = 0;
     for (uint32_t q = 0; q < nq; ++q)
         for (uint32_t b = 0; b < c.nblocks; ++b) {
-            const double steps = (double)strips[q] * (c.ncols4_alloc[b] * 4.0 + 1.0);
+            const uint32_t ncols = c.ncols4_alloc[b] * 4, m = ctx->m[q];
             uint32_t lg = 0;
-            while (lg < lgmax[q] && steps / (double)(1u << lg) > target) ++lg;
+            bool wg = false;
+            while (lg < lgmax[q] && item_cost(m, lg, ncols, ldsr) > target) ++lg;
+            if (!i32 && item_cost(m, lg, ncols, ldsr) > target && lgmax_wg[q] >= 2) {
+                // too heavy for a lone wave: smallest workgroup geometry that fits, else the cheapest
+                uint32_t best = 2;
+                double best_cost = item_cost(m, 2, ncols, ldsr_wg);
+                for (uint32_t k = 2; k <= lgmax_wg[q]; ++k) {
+                    const double ck = item_cost(m, k, ncols, ldsr_wg);
+                    if (ck < best_cost) { best = k; best_cost = ck; }
+                    if (ck <= target) { best = k; best_cost = ck; break; }
+                }
+                if (best_cost < item_cost(m, lg, ncols, ldsr)) { lg = best; wg = true; }
+            }
             if (force_lg >= 0) lg = (uint32_t)force_lg;
+            if (force_wg) { wg = true; if (lg < 2) lg = 2; }
             const uint32_t G = 1u << lg;
-            for (uint32_t s = 0; s < G; ++s) its.push_back({steps / G, OSW_ITEM_PACK(q, s, lg, 3u), b});
+            c.max_lg = std::max(c.max_lg, lg);
+            if (wg) {
+                const double cost = item_cost(m, lg, ncols, ldsr_wg);
+                for (uint32_t s = 0; s < G; s += 4) its_wg.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
+            } else {
+                const double cost = item_cost(m, lg, ncols, ldsr);
+                for (uint32_t s = 0; s < G; ++s) its.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
+            }
         }
-    std::stable_sort(its.begin(), its.end(), [](const It &x, const It &y) { return x.cost > y.cost; });
-    std::vector<uint2> flat(its.size());
-    for (size_t i = 0; i < its.size(); ++i) flat[i] = make_uint2(its[i].x, its[i].b);
-    c.nitems = (uint32_t)flat.size();
+    auto by_cost = [](const It &x, const It &y) { return x.cost > y.cost; };
+    std::stable_sort(its.begin(), its.end(), by_cost);
+    std::stable_sort(its_wg.begin(), its_wg.end(), by_cost);
+    std::vector<uint2> flat;
+    flat.reserve(its.size() + its_wg.size());
+    for (const It &i : its_wg) flat.push_back(make_uint2(i.x, i.b));
+    for (const It &i : its) flat.push_back(make_uint2(i.x, i.b));
+    c.nitems_wg = (uint32_t)its_wg.size();
+    c.nitems = (uint32_t)its.size();
     HIP_TRY(c.items.reserve(flat.size() * sizeof(uint2) + 16));
     HIP_TRY(c.ovf.reserve((size_t)nq * c.nblocks * 64 * sizeof(uint2) + 16));
     HIP_TRY(c.scores.reserve((size_t)nq * c.score_stride * sizeof(int32_t) + 16));
@@ -424,7 +465,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     HIP_TRY(hipSetDevice(d.id));
     if (int r = sync_queries(ctx, d)) return r;
     if (int r = build_items(ctx, d, c)) return r;
-    if (c.nitems == 0) { c.searched = true; return 0; }
+    if (c.nitems + c.nitems_wg == 0) { c.searched = true; return 0; }
 
     OswSearchArgs a;
     memset(&a, 0, sizeof a);
@@ -432,6 +473,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.blocks = (const OswBlock *)c.blocks.p;
     a.items = (const uint2 *)c.items.p;
     a.nitems = c.nitems;
+    a.nitems_wg = c.nitems_wg;
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;
@@ -456,7 +498,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         } else { ev = d.ev_pool.back(); d.ev_pool.pop_back(); }
     }
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, OSW_CTR_COUNT * sizeof(uint32_t), d.stream));
-    const uint32_t grid = std::min<uint32_t>(d.grid, (c.nitems + 3) / 4);
+    const uint32_t grid = std::min<uint32_t>(d.grid, (c.nitems + 3) / 4 + c.nitems_wg);
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
     if (ctx->cell_bits == 16) HIP_TRY(osw_launch_pk16(a, grid, d.stream));
     HIP_TRY(osw_launch_i32(a, grid, d.stream));
@@ -549,12 +591,12 @@ int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, 
     return 0;
 }
 
-int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out4)
+int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out6)
 {
     if (int r = check_dev(ctx, dev)) return r;
     Device &d = ctx->dev[dev];
     if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
-    if (!out4) return fail(OSWALD_HIP_EINVAL, "null output");
+    if (!out6) return fail(OSWALD_HIP_EINVAL, "null output");
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
     HIP_TRY(hipStreamSynchronize(d.stream));
@@ -562,10 +604,12 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
     if (c.nblocks) HIP_TRY(hipMemcpy(blocks.data(), c.blocks.p, c.nblocks * sizeof(OswBlock), hipMemcpyDeviceToHost));
     uint64_t alloc = 0, live = 0;
     for (const OswBlock &b : blocks) { alloc += b.ncols4_alloc; live += b.ncols4; }
-    out4[0] = c.nblocks;
-    out4[1] = alloc;
-    out4[2] = live;
-    out4[3] = live * 64 * sizeof(uint2);
+    out6[0] = c.nblocks;
+    out6[1] = alloc;
+    out6[2] = live;
+    out6[3] = live * 64 * sizeof(uint2);
+    out6[4] = c.nitems + c.nitems_wg;
+    out6[5] = c.max_lg;
     return 0;
 }
 

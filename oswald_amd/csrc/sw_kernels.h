@@ -48,6 +48,7 @@ static __host__ __device__ inline void osw_plan(uint32_t m, uint32_t G, uint32_t
 #define OSW_CTR_WORK 0       // next item of the pk16 queue
 #define OSW_CTR_OVF 1        // number of items queued for the int32 re-run
 #define OSW_CTR_WORK32 2     // next item of the int32 queue
+#define OSW_CTR_WORK_WG 3     // next workgroup-cooperative (heavy) item of the pk16 queue
 #define OSW_CTR_COUNT 8
 
 // One wave block of the re-tiled chunk: 128 consecutive sequences of the
@@ -62,8 +63,9 @@ struct OswBlock {
 struct OswSearchArgs {
     const uint2 *tiled;        // [col4][64 lanes] {4 residues seq 2l, 4 residues seq 2l+1}
     const OswBlock *blocks;
-    const uint2 *items;        // work queue: {query, block}, heaviest first
+    const uint2 *items;        // work queue, heaviest first: nitems_wg workgroup items, then nitems wave items
     uint32_t nitems;
+    uint32_t nitems_wg;
     uint32_t force_all;        // int32 kernel: run `items` instead of the overflow queue
     const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16
     const uint32_t *prof_off;

@@ -278,24 +278,43 @@ static __device__ __forceinline__ void load_profile_round(const uint2 *prof_q, u
 // One work item: all rounds of (query q, block B, sub-block sigma) at geometry G.
 // Returns the lane's best score (valid in the lanes of group 0 after the
 // cross-group reduction).
-template <class C>
+//   WG = false: the wave works alone; its profile slice lives in its private
+//               LDS region (kLdsRows rows).
+//   WG = true : the four waves of the workgroup run four sub-blocks of the same
+//               (query, block, G) item in step; they share ONE profile slice in
+//               the workgroup's whole LDS (4 x kLdsRows rows), which allows
+//               4x taller rounds for heavy items.  The only synchronisation
+//               is a pair of workgroup barriers around the slice reload.
+template <class C, bool WG>
 static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, uint32_t q, const OswBlock &blk, uint32_t sigma,
-                                                         uint32_t lg, int lane, int half, uint2 *lds_wave, uint2 *bnd_wave,
+                                                         uint32_t lg, int lane, int half, uint2 *lds_region, uint2 *bnd_wave,
                                                          typename C::GapT goe, typename C::GapT ge)
 {
     typedef typename C::T T;
+    constexpr uint32_t kLds = WG ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
     const uint32_t G = 1u << lg, gl = 64u >> lg;
     const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
     const uint32_t ncols = __builtin_amdgcn_readfirstlane(blk.ncols4) * 4;
     const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + sigma * gl + u;
     uint2 *bnd = bnd_wave + u;
     uint32_t rounds, R, m4;
-    osw_plan(p.qlen[q], G, C::kLdsRows, C::kRows, &rounds, &R, &m4);
+    osw_plan(p.qlen[q], G, kLds, C::kRows, &rounds, &R, &m4);
     const uint2 *prof_q = p.prof + (size_t)p.prof_off[q] * 32;
-    const lds_u2p lp = (lds_u2p)((lds_cp)lds_wave + g * R * 64);
+    const lds_u2p lp = (lds_u2p)((lds_cp)lds_region + g * R * 64);
     T score = C::zero();
     for (uint32_t rho = 0; rho < rounds; ++rho) {
-        load_profile_round(prof_q, rho * G * R / 4, G * R / 4, m4 / 4, lds_wave, lane);
+        if constexpr (WG) {
+            __syncthreads(); // every wave is done with the previous slice
+            const uint32_t rb0 = rho * G * R / 4, nrb = G * R / 4, rb_end = m4 / 4;
+            const uint4 *src = (const uint4 *)(prof_q + (size_t)rb0 * 32);
+            uint4 *dst = (uint4 *)lds_region;
+            const uint32_t n16 = nrb * 16;
+            const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * 16 : 0;
+            for (uint32_t i = threadIdx.x; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        } else {
+            load_profile_round(prof_q, rho * G * R / 4, G * R / 4, m4 / 4, lds_region, lane);
+        }
         sw_round_dispatch<C>(R, tb, ncols, lp, bnd, rho == 0, rho + 1 == rounds, G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups
@@ -304,41 +323,64 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     return score;
 }
 
+// Scores of one packed-int16 item: written for the lanes of group 0; lanes at
+// the int16 ceiling are queued for the exact int32 kernel.
+static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
+                                                   uint32_t lg, int lane, v2s score)
+{
+    const uint32_t gl = 64u >> lg;
+    if ((uint32_t)lane < gl) {
+        const uint32_t lam = sigma * gl + lane; // lane of the block = sequence pair
+        int2 out;
+        out.x = score.x;
+        out.y = score.y;
+        *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lam) = out;
+        const uint32_t hm = (score.x == 32767 ? 1u : 0u) | (score.y == 32767 ? 2u : 0u);
+        if (hm) {
+            const uint32_t k = atomicAdd(&p.counters[OSW_CTR_OVF], 1u);
+            p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Main kernel: packed int16.
 // ---------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8];
+    __shared__ uint32_t wg_item;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
-    uint2 *lds_wave = lds_prof[wv];
 
+    // phase 1: heavy items, the workgroup's four waves on four sub-blocks of one item
+    for (;;) {
+        if (threadIdx.x == 0) wg_item = atomicAdd(&p.counters[OSW_CTR_WORK_WG], 1u);
+        __syncthreads();
+        const uint32_t it = wg_item;
+        __syncthreads();
+        if (it >= p.nitems_wg) break;
+        const uint2 item = p.items[it];
+        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x) + wv, lg = OSW_ITEM_LG(item.x), B = item.y;
+        const OswBlock blk = p.blocks[B];
+        const v2s score = run_item<CellPK16, true>(p, q, blk, sigma, lg, lane, 0, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
+        pk16_finish(p, q, B, blk, sigma, lg, lane, score);
+    }
+
+    // phase 2: every wave on its own
+    const uint2 *items = p.items + p.nitems_wg;
     for (;;) {
         uint32_t it = 0;
         if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
         it = __builtin_amdgcn_readfirstlane(it);
         if (it >= p.nitems) break;
-        const uint2 item = p.items[it];
+        const uint2 item = items[it];
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
-        const v2s score = run_item<CellPK16>(p, q, blk, sigma, lg, lane, 0, lds_wave, bnd_wave, p.goe_pk, p.ge_pk);
-        const uint32_t gl = 64u >> lg;
-        if ((uint32_t)lane < gl) {
-            const uint32_t lam = sigma * gl + lane; // lane of the block = sequence pair
-            int2 out;
-            out.x = score.x;
-            out.y = score.y;
-            *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lam) = out;
-            // exact unless the int16 ceiling was touched: queue the pair for the int32 kernel
-            const uint32_t hm = (score.x == 32767 ? 1u : 0u) | (score.y == 32767 ? 2u : 0u);
-            if (hm) {
-                const uint32_t k = atomicAdd(&p.counters[OSW_CTR_OVF], 1u);
-                p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
-            }
-        }
+        const v2s score = run_item<CellPK16, false>(p, q, blk, sigma, lg, lane, 0, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
+        pk16_finish(p, q, B, blk, sigma, lg, lane, score);
     }
 }
 
@@ -357,7 +399,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
     uint2 *lds_wave = lds_prof[wv];
     // the queue length was produced by the previous kernel on this stream
     const uint32_t nitems = p.force_all ? p.nitems : p.counters[OSW_CTR_OVF];
-    const uint2 *items = p.force_all ? p.items : p.ovf_items;
+    const uint2 *items = p.force_all ? p.items + p.nitems_wg : p.ovf_items;
 
     for (;;) {
         uint32_t it = 0;
@@ -371,7 +413,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
         const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
-            const int score = run_item<CellI32>(p, q, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge);
+            const int score = run_item<CellI32, false>(p, q, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge);
             if ((uint32_t)lane < gl)
                 p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }

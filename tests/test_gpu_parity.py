@@ -208,3 +208,18 @@ def test_every_wave_geometry_int32(hip_ctx, oracle, lg, monkeypatch):
     got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=32)
     want = expect(oracle, qs, b, n, disp, 16, sm, 14, 2)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("lg", [2, 4, 6])
+def test_workgroup_items(hip_ctx, oracle, lg, monkeypatch):
+    """Heavy-item path: four waves of a workgroup on four sub-blocks of one item,
+    sharing the profile slice (forced here on a small input)."""
+    monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
+    monkeypatch.setenv("OSWALD_HIP_FORCE_WG", "1")
+    qs = synth.make_queries([9, 64, 700, 1500], seed=80 + lg)
+    L, R, O = random_db(200, seed=90 + lg, max_len=150, queries=qs[-2:], homologs=2)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)

@@ -34,4 +34,6 @@ for _ in range(a_.reps):
 ctx.wait()
 ms, nl, _ = ctx.kernel_stats()
 cells = float(a_.nq) * a_.m * a_.nseq * a_.len
+g = ctx.chunk_geometry(h)
+print(f"items={g['work_items']} maxlg={g['max_log2_geometry']}", end=" ")
 print(f"uniform nseq={a_.nseq} len={a_.len} nq={a_.nq} m={a_.m} bits={a_.bits}: {ms/nl:.3f} ms/launch, {cells/(ms/nl*1e-3)/1e9:.1f} GCUPS")
