@@ -231,12 +231,33 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     auto by_cost = [](const It &x, const It &y) { return x.cost > y.cost; };
     std::stable_sort(its.begin(), its.end(), by_cost);
     std::stable_sort(its_wg.begin(), its_wg.end(), by_cost);
+    // issue priority of the long items (see set_wave_prio in sw_kernels.hip)
+    double planned = 0;
+    for (const It &i : its) planned += i.cost;
+    for (const It &i : its_wg) planned += i.cost * 4;
+    const double fair = planned / nwaves;
+    auto prio_of = [&](double cost) { return cost > fair / 2 ? 3u : cost > fair / 4 ? 2u : cost > fair / 8 ? 1u : 0u; };
     std::vector<uint2> flat;
     flat.reserve(its.size() + its_wg.size());
-    for (const It &i : its_wg) flat.push_back(make_uint2(i.x, i.b));
-    for (const It &i : its) flat.push_back(make_uint2(i.x, i.b));
+    for (const It &i : its_wg) flat.push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
+    for (const It &i : its) flat.push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
     c.nitems_wg = (uint32_t)its_wg.size();
     c.nitems = (uint32_t)its.size();
+    if (getenv("OSWALD_HIP_DEBUG")) {
+        double sw = 0, sg = 0;
+        for (const It &i : its) sw += i.cost;
+        for (const It &i : its_wg) sg += i.cost * 4;
+        fprintf(stderr, "[oswald_hip] plan: total(G=1) %.3g slots, %.0f waves, target %.3g; wave items %zu (sum %.3g, max %.3g), "
+                        "workgroup items %zu (sum %.3g, max %.3g), max lg %u\n",
+                total, nwaves, target, its.size(), sw, its.empty() ? 0.0 : its[0].cost, its_wg.size(), sg,
+                its_wg.empty() ? 0.0 : its_wg[0].cost, c.max_lg);
+        uint32_t hist[2][8] = {{0}};
+        for (const It &i : its) hist[0][OSW_ITEM_LG(i.x)]++;
+        for (const It &i : its_wg) hist[1][OSW_ITEM_LG(i.x)]++;
+        for (int w = 0; w < 2; ++w)
+            for (int k = 0; k < 7; ++k)
+                if (hist[w][k]) fprintf(stderr, "[oswald_hip]   %s lg=%d: %u items\n", w ? "workgroup" : "wave", k, hist[w][k]);
+    }
     HIP_TRY(c.items.reserve(flat.size() * sizeof(uint2) + 16));
     HIP_TRY(c.ovf.reserve((size_t)nq * c.nblocks * 64 * sizeof(uint2) + 16));
     HIP_TRY(c.scores.reserve((size_t)nq * c.score_stride * sizeof(int32_t) + 16));

@@ -15,7 +15,7 @@
 #define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64)
 #define OSW_TILED_TAIL_GROUPS 24 // readable 4-column groups past the last block (drain of G <= 64)
 
-// Work item: x = query | sub-block << 16 | log2(G) << 24 | halves << 28, y = block.
+// Work item: x = query | sub-block << 16 | log2(G) << 24 | halves << 28 | priority << 30, y = block.
 // G = lane groups of the wave geometry; sub-block = which 64/G lanes (sequence
 // pairs) of the block; halves (int32 kernel) = which sequence of each pair.
 #define OSW_ITEM_PACK(q, sigma, lg, halves) ((uint32_t)(q) | ((uint32_t)(sigma) << 16) | ((uint32_t)(lg) << 24) | ((uint32_t)(halves) << 28))
@@ -23,6 +23,7 @@
 #define OSW_ITEM_SIGMA(x) (((x) >> 16) & 0xffu)
 #define OSW_ITEM_LG(x) (((x) >> 24) & 0xfu)
 #define OSW_ITEM_HALVES(x) (((x) >> 28) & 3u)
+#define OSW_ITEM_PRIO(x) (((x) >> 30) & 3u)
 
 // Strip plan of a query of m rows at geometry G: `rounds` rounds of G strips of
 // R rows each (R a multiple of 4, G*R <= lds_rows, R <= rmax).  Rows past the

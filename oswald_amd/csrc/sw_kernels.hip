@@ -323,6 +323,21 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     return score;
 }
 
+// Issue priority of the wave for the duration of an item (0..3).  The queue
+// planner raises it for the few items that are long compared with a wave's fair
+// share of the launch: up to four waves share a SIMD's VALU issue, and a long
+// item that had to take turns with three short-item waves would define the
+// launch time.
+static __device__ __forceinline__ void set_wave_prio(uint32_t prio)
+{
+    switch (prio) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // Scores of one packed-int16 item: written for the lanes of group 0; lanes at
 // the int16 ceiling are queued for the exact int32 kernel.
 static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
@@ -365,7 +380,9 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
         const uint2 item = p.items[it];
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x) + wv, lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
+        set_wave_prio(OSW_ITEM_PRIO(item.x));
         const v2s score = run_item<CellPK16, true>(p, q, blk, sigma, lg, lane, 0, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
+        set_wave_prio(0);
         pk16_finish(p, q, B, blk, sigma, lg, lane, score);
     }
 
@@ -379,7 +396,9 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
         const uint2 item = items[it];
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
+        set_wave_prio(OSW_ITEM_PRIO(item.x));
         const v2s score = run_item<CellPK16, false>(p, q, blk, sigma, lg, lane, 0, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
+        set_wave_prio(0);
         pk16_finish(p, q, B, blk, sigma, lg, lane, score);
     }
 }
