@@ -32,10 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
-VALU_LANEOPS_PER_CLK_CU = 128    # 4 SIMD-32 per CU
-CLOCK_HZ = 2.4e9
+CLOCK_HZ = 2.4e9                 # max clock (MI355X_MICROARCH.md)
 N_CU = 256
-PK_OPS_PER_2CELLS = 10           # packed-int16 instructions per lane per two cells (sw_kernels.hip)
+SIMD_PER_CU = 4
+PK_ISSUE_CYCLES = 4.0            # packed-int16 VOP3P: one wave instruction per 4 cycles per SIMD (tools/ubench.hip, measured 4.2-4.4)
+PK_OPS_PER_128CELLS = 10         # VALU instructions per wave per column row: 9 VOP3P + 1 v_perm_b32 for 64 lanes x 2 cells
 
 
 def parse():
@@ -77,7 +78,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the search path is HIP only (no CPU fallback)")
     dev = torch.device("cuda", local_rank)
 
-    from oswald_amd import capi, dblayout, submat, synth
+    from oswald_amd import capi, dblayout, multigpu, submat, synth
 
     wl = workload(args.workload)
     qlens = wl["qlens"] or synth.default_query_lengths()
@@ -115,20 +116,7 @@ def main():
         ctx.chunk_search(chunk, None)
         sc, ix = ctx.chunk_topr(chunk, args.nseq, args.top)   # syncs the library's stream
         gix = ix.astype(np.int64) + rank * args.nseq          # global index = shard base + sorted position
-        if dist is None:
-            return sc, gix
-        mine = torch.from_numpy(np.stack([sc.astype(np.int64), gix], axis=0)).to(dev)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        if rank != 0:
-            return None
-        allp = torch.stack(parts).cpu().numpy()
-        out_s = np.empty((len(qlens), args.top), np.int32)
-        out_i = np.empty((len(qlens), args.top), np.int64)
-        for q in range(len(qlens)):
-            s_, i_ = dblayout.merge_topr([(allp[r, 0, q].astype(np.int32), allp[r, 1, q]) for r in range(world)], args.top)
-            out_s[q], out_i[q] = s_, i_
-        return out_s, out_i
+        return multigpu.gather_topr(sc, gix, args.top, dist, dev if dist is not None else None)
 
     for _ in range(args.warmup):
         step()
@@ -162,7 +150,8 @@ def main():
         kern_s = kern_ms / max(1, kern_launches) / 1e3
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         kern_gcups = sum_m * d_local / kern_s / 1e9 if kern_s > 0 else 0.0
-        valu_ceiling = N_CU * VALU_LANEOPS_PER_CLK_CU * CLOCK_HZ / (PK_OPS_PER_2CELLS / 2.0) / 1e9
+        valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / PK_OPS_PER_128CELLS / 1e9
+        traffic = measured_traffic(args.workload, args.nseq)
         result = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -171,11 +160,11 @@ def main():
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
                        "top": args.top, "sharding": f"db-shard x{world}, RCCL all_gather of top-{args.top}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "osw_sw_pk16(+osw_sw_i32)", "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
-                                  "note": "integer DP is VALU-issue bound: 10 packed-int16 ops per 2 cells"}},
+                                  "note": "integer DP is VALU-issue bound: 10 VALU instructions per wave per 128 cells, packed-int16 issues every 4 cycles per SIMD"}},
             "rerun_items_int32": int(rerun), "work_items": int(ctx.chunk_geometry(chunk)["work_items"]), "max_log2_geometry": int(ctx.chunk_geometry(chunk)["max_log2_geometry"]), "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
             "setup_s": round(t_gen, 1),
         }
@@ -188,6 +177,20 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def measured_traffic(workload_name, nseq):
+    """HBM bytes per launch of the DP kernel from rocprofv3 PMC passes
+    (FETCH_SIZE / WRITE_SIZE, separate runs, see tools/profile_gpu.sh and
+    DESIGN.md for the unit and the gfx950 correction), if a summary for this
+    exact workload has been committed under profiles/; else None."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload_name}_{nseq}.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(args, a, m, a_disp, sl, sr, so, sm, wl, sum_m, ctx, chunk, n_gpu):

@@ -163,26 +163,28 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     const uint32_t rmax = i32 ? OSW_RMAX32 : OSW_RMAX16, ldsr = i32 ? OSW_LDS_ROWS32 : OSW_LDS_ROWS16;
     const uint32_t ldsr_wg = ldsr * (OSW_WG_THREADS / 64);
     auto item_cost = [&](uint32_t m, uint32_t lg, uint32_t ncols, uint32_t lds_rows) {
-        uint32_t rounds, R, m4;
-        osw_plan(m, 1u << lg, lds_rows, rmax, &rounds, &R, &m4);
-        return (double)rounds * (double)(ncols + (1u << lg)) * (10.0 * R + 35.0);
+        const OswPlan pl = osw_plan(m, 1u << lg, lds_rows, rmax);
+        const double rows = 4.0 * (pl.base * pl.rounds + pl.extra); // rows per lane group over all rounds
+        return (double)(ncols + (1u << lg)) * (10.0 * rows + 35.0 * pl.rounds);
     };
     // widest useful geometry per query: strips of >= 8 rows for wave items (per-column
     // overhead), >= 4 for workgroup items, and no lane group entirely past the query
     auto lg_limit = [&](uint32_t m, uint32_t lds_rows, uint32_t min_rows) {
-        uint32_t lg = 0, rounds, R, m4;
+        uint32_t lg = 0;
         while (lg < 6) {
             const uint32_t G2 = 2u << lg;
-            osw_plan(m, G2, lds_rows, rmax, &rounds, &R, &m4);
-            if (G2 * R > lds_rows || R < min_rows || G2 * min_rows > m4) break;
+            const OswPlan pl = osw_plan(m, G2, lds_rows, rmax);
+            if (G2 * osw_plan_maxrows(pl) > lds_rows || 4 * pl.base < min_rows || G2 * min_rows > pl.m4) break;
             ++lg;
         }
         return lg;
     };
-    std::vector<uint32_t> lgmax(nq), lgmax_wg(nq);
+    std::vector<uint32_t> lgmax(nq), lgmax_wg(nq), lg_floor(nq);
     double total = 0;
     for (uint32_t q = 0; q < nq; ++q) {
         lgmax[q] = lg_limit(ctx->m[q], ldsr, 8);
+        lg_floor[q] = 0;
+        while (lg_floor[q] < 2 && lg_floor[q] < lgmax[q] && (2u << lg_floor[q]) * rmax <= ((ctx->m[q] + 3u) & ~3u)) ++lg_floor[q];
         lgmax_wg[q] = lg_limit(ctx->m[q], ldsr_wg, 4);
         for (uint32_t b = 0; b < c.nblocks; ++b) total += item_cost(ctx->m[q], 0, c.ncols4_alloc[b] * 4, ldsr);
     }
@@ -202,7 +204,9 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     for (uint32_t q = 0; q < nq; ++q)
         for (uint32_t b = 0; b < c.nblocks; ++b) {
             const uint32_t ncols = c.ncols4_alloc[b] * 4, m = ctx->m[q];
-            uint32_t lg = 0;
+            // even light items run at G = 4 when the query has >= 4 full strips: the groups hand their
+            // bottom rows to each other in registers, so only every 4th strip boundary spills to HBM
+            uint32_t lg = lg_floor[q];
             bool wg = false;
             while (lg < lgmax[q] && item_cost(m, lg, ncols, ldsr) > target) ++lg;
             if (!i32 && item_cost(m, lg, ncols, ldsr) > target && lgmax_wg[q] >= 2) {

@@ -25,25 +25,37 @@
 #define OSW_ITEM_HALVES(x) (((x) >> 28) & 3u)
 #define OSW_ITEM_PRIO(x) (((x) >> 30) & 3u)
 
-// Strip plan of a query of m rows at geometry G: `rounds` rounds of G strips of
-// R rows each (R a multiple of 4, G*R <= lds_rows, R <= rmax).  Rows past the
-// query are zero-score rows: they cannot raise a maximum.  Shared by the host
-// (work-queue costs) and the kernels.
-static __host__ __device__ inline void osw_plan(uint32_t m, uint32_t G, uint32_t lds_rows, uint32_t rmax, uint32_t *rounds,
-                                                uint32_t *R, uint32_t *m4_out)
+// Strip plan of a query of m rows at geometry G: every lane group owns
+// T = ceil4(ceil4(m) / G) rows, cut into `rounds` strips whose heights are
+// multiples of 4, differ by at most 4 and never exceed min(rmax, lds_rows / G)
+// (G x height rows of profile must fit the LDS slice).  Rows past the query are
+// zero-score rows: they cannot raise a maximum; at most 4G-1 of them exist.
+// Shared by the host (work-queue costs) and the kernels.
+struct OswPlan {
+    uint32_t rounds;  // strips per lane group
+    uint32_t base;    // every round has 4*base rows ...
+    uint32_t extra;   // ... and the first `extra` rounds 4 more
+    uint32_t m4;      // query rows rounded up to a multiple of 4
+};
+
+static __host__ __device__ inline OswPlan osw_plan(uint32_t m, uint32_t G, uint32_t lds_rows, uint32_t rmax)
 {
-    uint32_t m4 = (m + 3u) & ~3u;
-    if (m4 == 0) m4 = 4;
+    OswPlan p;
+    p.m4 = (m + 3u) & ~3u;
+    if (p.m4 == 0) p.m4 = 4;
     uint32_t rcap = (lds_rows / G) & ~3u;
     if (rcap > rmax) rcap = rmax;
     if (rcap < 4) rcap = 4;
-    const uint32_t nr = (m4 + G * rcap - 1) / (G * rcap);
-    uint32_t r = (m4 + G * nr - 1) / (G * nr);
-    r = (r + 3u) & ~3u;
-    *rounds = nr;
-    *R = r;
-    *m4_out = m4;
+    const uint32_t units = ((p.m4 + G - 1) / G + 3u) / 4u; // rows per group / 4
+    p.rounds = (units * 4 + rcap - 1) / rcap;
+    p.base = units / p.rounds;
+    p.extra = units % p.rounds;
+    return p;
 }
+// height of round rho and the number of rows each group has done before it
+static __host__ __device__ inline uint32_t osw_round_rows(const OswPlan &p, uint32_t rho) { return 4u * (p.base + (rho < p.extra ? 1u : 0u)); }
+static __host__ __device__ inline uint32_t osw_round_row0(const OswPlan &p, uint32_t rho) { return 4u * (rho * p.base + (rho < p.extra ? rho : p.extra)); }
+static __host__ __device__ inline uint32_t osw_plan_maxrows(const OswPlan &p) { return 4u * (p.base + (p.extra ? 1u : 0u)); }
 
 // device counters (uint32), zeroed before every search launch pair
 #define OSW_CTR_WORK 0       // next item of the pk16 queue

@@ -297,15 +297,14 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     const uint32_t ncols = __builtin_amdgcn_readfirstlane(blk.ncols4) * 4;
     const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + sigma * gl + u;
     uint2 *bnd = bnd_wave + u;
-    uint32_t rounds, R, m4;
-    osw_plan(p.qlen[q], G, kLds, C::kRows, &rounds, &R, &m4);
+    const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
     const uint2 *prof_q = p.prof + (size_t)p.prof_off[q] * 32;
-    const lds_u2p lp = (lds_u2p)((lds_cp)lds_region + g * R * 64);
     T score = C::zero();
-    for (uint32_t rho = 0; rho < rounds; ++rho) {
+    for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
+        // round rho: group g runs rows [G*row0 + g*R, +R) of the query
+        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, nrb = G * R / 4, rb_end = plan.m4 / 4;
         if constexpr (WG) {
             __syncthreads(); // every wave is done with the previous slice
-            const uint32_t rb0 = rho * G * R / 4, nrb = G * R / 4, rb_end = m4 / 4;
             const uint4 *src = (const uint4 *)(prof_q + (size_t)rb0 * 32);
             uint4 *dst = (uint4 *)lds_region;
             const uint32_t n16 = nrb * 16;
@@ -313,9 +312,10 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             for (uint32_t i = threadIdx.x; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
             __syncthreads();
         } else {
-            load_profile_round(prof_q, rho * G * R / 4, G * R / 4, m4 / 4, lds_region, lane);
+            load_profile_round(prof_q, rb0, nrb, rb_end, lds_region, lane);
         }
-        sw_round_dispatch<C>(R, tb, ncols, lp, bnd, rho == 0, rho + 1 == rounds, G, gl, lane, half, goe, ge, score);
+        const lds_u2p lp = (lds_u2p)((lds_cp)lds_region + g * R * 64);
+        sw_round_dispatch<C>(R, tb, ncols, lp, bnd, rho == 0, rho + 1 == plan.rounds, G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups
     for (uint32_t off = gl; off < 64; off <<= 1)

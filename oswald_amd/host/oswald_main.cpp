@@ -1,0 +1,282 @@
+// oswald_amd/host/oswald_main.cpp -- the `oswald` command line tool on MI355X.
+//
+// Keeps the reference's command line (reference host/src/arguments.c:14-35:
+// -O preprocess|search|info, -i -o / -q -d -s -g -e -m -c -v -b -f -k -p -r),
+// its preprocessed database format and its report (reference
+// host/src/FPGAsearch.c:27-28, :60-65, :312-331).  The accelerator side of
+// the search driver -- OpenCL bring-up, score-profile build, enqueue path --
+// is replaced by calls into the C ABI of include/oswald_hip.h; this file is
+// the mirror of fpga_search() (reference host/src/FPGAsearch.c:4-374) with
+// GPUs where the reference has FPGAs.  There is no host compute path here.
+#include <argp.h>
+#include <sys/time.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "oswald_hip.h"
+#include "oswald_host.h"
+
+namespace {
+
+struct Options {
+    const char *op = nullptr, *input = nullptr, *output = nullptr, *queries = nullptr, *db = nullptr;
+    std::string submat = "blosum62", submat_name = "BLOSUM62";
+    int open_gap = 10, extend_gap = 2, cpu_threads = 4, execution_mode = 1, cpu_vector_length = 16, cpu_block_size = 256;
+    unsigned num_devices = 1;
+    unsigned long top = 10, max_chunk_size = 134217728;
+    double test_db_percentage = 0.01;
+    int arg_count = 0;
+};
+
+const char *argp_doc =
+    "\nOSWALD (MI355X build) accelerates Smith-Waterman protein database search; this build runs the search on AMD Instinct GPUs "
+    "through HIP instead of the reference's Altera FPGAs";
+
+int parse_opt(int key, char *arg, struct argp_state *state)
+{
+    Options *o = (Options *)state->input;
+    switch (key) {
+    case 'O':
+        if (strcmp(arg, "preprocess") && strcmp(arg, "search") && strcmp(arg, "info"))
+            argp_failure(state, 1, 0, "%s is not a valid option for execution.", arg);
+        o->op = arg;
+        break;
+    case 'i': o->input = arg; break;
+    case 'o': o->output = arg; break;
+    case 'q': o->queries = arg; break;
+    case 'd': o->db = arg; break;
+    case 's': {
+        if (!oswald::submat_by_name(arg)) argp_failure(state, 1, 0, "%s is not a valid option for substitution matrix.", arg);
+        o->submat = arg;
+        o->submat_name = arg;
+        for (char &c : o->submat_name) c = (char)toupper((unsigned char)c);
+        break;
+    }
+    case 'g':
+        o->open_gap = atoi(arg);
+        if (o->open_gap < 0 || o->open_gap > 255) argp_failure(state, 1, 0, "%d is not a valid option for gap open penalty.", o->open_gap);
+        break;
+    case 'e':
+        o->extend_gap = atoi(arg);
+        if (o->extend_gap < 0 || o->extend_gap > 127) argp_failure(state, 1, 0, "%d is not a valid option for gap extend penalty.", o->extend_gap);
+        break;
+    case 'm':
+        o->execution_mode = atoi(arg);
+        if (o->execution_mode != 0 && o->execution_mode != 1) argp_failure(state, 1, 0, "%d is not a valid option for execution mode.", o->execution_mode);
+        break;
+    case 'c':
+        o->cpu_threads = atoi(arg);
+        if (o->cpu_threads < 0) argp_failure(state, 1, 0, "The number of host threads must be greater than 0.");
+        break;
+    case 'b':
+        o->cpu_block_size = atoi(arg);
+        if (o->cpu_block_size < 0) argp_failure(state, 1, 0, "The host block width must be greater than 0.");
+        break;
+    case 'v':
+        o->cpu_vector_length = atoi(arg);
+        if (o->cpu_vector_length != 16 && o->cpu_vector_length != 32) argp_failure(state, 1, 0, "%d is not a valid option for vector length of host.", o->cpu_vector_length);
+        break;
+    case 'f': {
+        const int v = atoi(arg);
+        if (v <= 0) argp_failure(state, 1, 0, "The number of GPUs must be greater than 0.");
+        o->num_devices = (unsigned)v;
+        break;
+    }
+    case 'k': {
+        const long v = atol(arg);
+        if (v <= 0) argp_failure(state, 1, 0, "The chunk size must be greater than 0.");
+        o->max_chunk_size = (unsigned long)v;
+        break;
+    }
+    case 'p':
+        o->test_db_percentage = atof(arg);
+        if (o->test_db_percentage <= 0 || o->test_db_percentage > 1) argp_failure(state, 1, 0, "The database percentage for testing must be between 0 and 1.");
+        break;
+    case 'r': {
+        const long v = atol(arg);
+        if (v < 0) argp_failure(state, 1, 0, "The number of scores to show must be greater than 0.");
+        o->top = (unsigned long)v;
+        break;
+    }
+    case ARGP_KEY_END:
+        if (o->arg_count == 1) argp_failure(state, 1, 0, "Missing options");
+        if (!o->op) argp_failure(state, 1, 0, "OSWALD execution option is required");
+        else if (!strcmp(o->op, "preprocess")) {
+            if (!o->input) argp_failure(state, 1, 0, "Input sequence filename is required");
+            if (!o->output) argp_failure(state, 1, 0, "Output filename is required");
+        } else if (!strcmp(o->op, "search")) {
+            if (!o->db) argp_failure(state, 1, 0, "Database filename is required");
+            if (!o->queries) argp_failure(state, 1, 0, "Query sequences filename is required");
+        }
+        break;
+    default: break;
+    }
+    return 0;
+}
+
+double dwalltime()
+{
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    return tv.tv_sec + tv.tv_usec / 1000000.0;
+}
+
+// the reference's convention: any accelerator error prints and terminates (utils.c:256-262)
+void check(int rc, const char *what)
+{
+    if (rc != 0) {
+        fprintf(stderr, "OSWALD: %s failed: %s\n", what, oswald_hip_last_error());
+        exit(EXIT_FAILURE);
+    }
+}
+
+int do_preprocess(const Options &o)
+{
+    const double tick = dwalltime();
+    const oswald::PreprocessStats st = oswald::preprocess_db(o.input, o.output, o.cpu_threads);
+    printf("\nOSWALD v%s\n\n", oswald::kVersion);
+    printf("Database file:\t\t\t %s\n", o.input);
+    printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)st.sequences, (long)st.residues);
+    printf("Preprocessed database name:\t%s\n", o.output);
+    printf("Preprocessing time:\t\t%lf seconds\n\n", dwalltime() - tick);
+    return 0;
+}
+
+int do_info()
+{
+    int n = 0;
+    check(oswald_hip_device_count(&n), "device discovery");
+    if (n <= 0) { fprintf(stderr, "OSWALD: no GPU found.\n"); return -1; }
+    oswald_hip_ctx *ctx = nullptr;
+    check(oswald_hip_init(n, nullptr, &ctx), "device bring-up");
+    char buf[2048];
+    for (int d = 0; d < n; ++d) {
+        check(oswald_hip_info(ctx, d, buf, sizeof buf), "device info");
+        fputs(buf, stdout);
+    }
+    oswald_hip_finalize(ctx);
+    return 0;
+}
+
+int do_search(Options &o)
+{
+    const time_t current_time = time(nullptr);
+    printf("\nOSWALD v%s \n\n", oswald::kVersion);
+    printf("Database file:\t\t\t%s\n", o.db);
+    if (o.execution_mode == 1)
+        fprintf(stderr, "OSWALD: hybrid mode (-m 1) splits work between host SIMD and the accelerator; this build runs the whole "
+                        "database on the GPU(s) (as -m 0).\n");
+
+    oswald::Queries q = oswald::load_query_sequences(o.queries);
+    oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, o.num_devices);
+    const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength;
+
+    printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)db.sequences_count, (long)db.D);
+    printf("Longest database sequence: \t%d residues\n", db.sequences_db_max_length);
+    printf("Substitution matrix:\t\t%s\n", o.submat_name.c_str());
+    printf("Gap open penalty:\t\t%d\n", o.open_gap);
+    printf("Gap extend penalty:\t\t%d\n", o.extend_gap);
+    printf("Query filename:\t\t\t%s\n", o.queries);
+
+    if (db.sequences_count < o.top) o.top = db.sequences_count;
+    std::vector<int32_t> scores(nq * db.vect_sequences_count * W, 0);
+    std::vector<std::vector<int32_t>> tmp(o.num_devices);
+
+    const double tick = dwalltime();
+    oswald_hip_ctx *ctx = nullptr;
+    check(oswald_hip_init((int)o.num_devices, nullptr, &ctx), "device bring-up");
+    check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 16), "scoring setup");
+    check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
+    // chunk c of a round goes to device c mod ndev (reference FPGAsearch.c:132-138)
+    for (size_t k = 0; k < db.chunks.size(); k += o.num_devices) {
+        const size_t active = std::min<size_t>(o.num_devices, db.chunks.size() - k);
+        for (size_t d = 0; d < active; ++d) {
+            const oswald::Chunk &c = db.chunks[k + d];
+            tmp[d].resize(nq * c.n.size() * W);
+            check(oswald_hip_search_chunk_async(ctx, (int)d, c.b.data(), c.b.size(), c.n.data(), c.disp.data(), (uint32_t)c.n.size(),
+                                                (uint32_t)W, tmp[d].data()), "chunk search");
+        }
+        check(oswald_hip_wait(ctx, -1), "wait");
+        for (size_t d = 0; d < active; ++d) {
+            const oswald::Chunk &c = db.chunks[k + d];
+            const size_t row = c.n.size() * W;
+            for (uint64_t qi = 0; qi < nq; ++qi)
+                memcpy(scores.data() + (qi * db.vect_sequences_count + c.accum) * W, tmp[d].data() + qi * row, row * sizeof(int32_t));
+        }
+    }
+    const double workTime = dwalltime() - tick;
+    oswald_hip_finalize(ctx);
+
+    const std::vector<std::string> headers = oswald::load_database_headers(o.db, db.sequences_count);
+    std::vector<int32_t> ts;
+    std::vector<uint64_t> ti;
+    for (uint64_t i = 0; i < nq; ++i) {
+        oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, ts, ti);
+        printf("\nQuery no.\t\t\t%d\n", (int)i + 1);
+        printf("Query description: \t\t%s\n", q.titles[i].c_str() + 1);
+        printf("Query length:\t\t\t%d residues\n", q.m[i]);
+        printf("\nScore\tSequence description\n");
+        for (size_t j = 0; j < ts.size(); ++j) {
+            const std::string &h = headers[ti[j]];
+            printf("%d\t%s\n", ts[j], h.empty() ? "" : h.c_str() + 1);
+        }
+    }
+    printf("\nSearch date:\t\t\t%s", ctime(&current_time));
+    printf("Search time:\t\t\t%lf seconds\n", workTime);
+    printf("Search speed:\t\t\t%.2lf GCUPS\n", (double)(q.Q * db.D) / (workTime * 1000000000));
+    printf("CPU threads:\t\t\t%d\n", o.cpu_threads);
+    printf("CPU vector length:\t\t%d\n", 16);
+    printf("CPU block width:\t\t%d\n", o.cpu_block_size);
+    printf("Number of FPGAs:\t\t%u\n", o.num_devices);
+    printf("FPGA vector length:\t\t%d\n", oswald::kFpgaVectorLength);
+    printf("FPGA block width:\t\t%d\n", oswald::kFpgaBlockWidth);
+    printf("Max. chunk size in FPGA:\t%ld bytes\n", (long)o.max_chunk_size);
+    printf("Accelerator:\t\t\t%u x AMD Instinct GPU via HIP (the \"FPGA\" lines above describe the input layout)\n", o.num_devices);
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char *argv[])
+{
+    static struct argp_option options[] = {
+        {0, 0, 0, 0, "OSWALD execution", 1},
+        {0, 'O', "<string>", 0, "'preprocess' for database preprocessing, 'search' for database search, 'info' for GPU information [REQUIRED]", 1},
+        {0, 0, 0, 0, "preprocess", 2},
+        {"input", 'i', "<string>", 0, "Input sequence filename (must be in FASTA format). [REQUIRED]", 2},
+        {"output", 'o', "<string>", 0, "Output filename. [REQUIRED]", 2},
+        {0, 0, 0, 0, "search", 3},
+        {"query", 'q', "<string>", 0, "Input query sequence filename (must be in FASTA format). [REQUIRED]", 3},
+        {"db", 'd', "<string>", 0, "Preprocessed database output filename. [REQUIRED]", 3},
+        {"sm", 's', "<string>", 0, "Substitution matrix. Supported values: blosum45, blosum50, blosum62, blosum80, blosum90, pam30, pam70, pam250 (default: blosum62).", 3},
+        {"gap_open", 'g', "<integer>", 0, "Gap open penalty (default: 10).", 3},
+        {"gap_extend", 'e', "<integer>", 0, "Gap extend penalty (default: 2).", 3},
+        {"execution_mode", 'm', "<integer>", 0, "0 for accelerator mode, 1 for hybrid mode (accepted, runs as 0) (default: 1).", 3},
+        {"cpu_threads", 'c', "<integer>", 0, "Number of CPU threads (default: 4).", 3},
+        {"vector_length", 'v', "<integer>", 0, "Vector length in host: 16 or 32 (accepted for compatibility) (default: 16).", 3},
+        {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (accepted for compatibility) (default: 256).", 3},
+        {"num_fpgas", 'f', "<integer>", 0, "Number of GPUs (the reference's number of FPGAs) (default: 1).", 3},
+        {"max_chunk_size", 'k', "<integer>", 0, "Maximum chunk size on the accelerator (bytes, default: 134217728).", 3},
+        {"db_percentage", 'p', "<integer>", 0, "Database percentage for testing computational power (hybrid mode only) (default: 0.01).", 3},
+        {"top", 'r', "<integer>", 0, "Number of scores to show (default: 10).", 3},
+        {0}};
+    Options o;
+    o.arg_count = argc;
+    struct argp argp = {options, parse_opt, 0, argp_doc};
+    argp_parse(&argp, argc, argv, 0, 0, &o);
+    try {
+        if (!strcmp(o.op, "preprocess")) return do_preprocess(o);
+        if (!strcmp(o.op, "info")) return do_info();
+        return do_search(o);
+    } catch (const std::exception &e) {
+        // file errors print and exit(2)/(3) in the reference (sequences.c:18, :133, :1110)
+        printf("%s\n", e.what());
+        return 2;
+    }
+}

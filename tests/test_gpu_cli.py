@@ -1,0 +1,69 @@
+"""End to end through the command line tool on a GPU: `oswald -O preprocess`
+then `oswald -O search -m 0`, report parsed and compared with the oracle's
+top-r (scores, titles, tie order)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oswald_amd import dblayout, submat, synth
+
+import hostlib
+from helpers import pack_queries
+
+pytestmark = pytest.mark.gpu
+
+
+def parse_report(text):
+    blocks = []
+    cur = None
+    for line in text.split("\n"):
+        if line.startswith("Query no."):
+            cur = {"hits": []}
+            blocks.append(cur)
+        elif cur is not None and line.startswith("Query description:"):
+            cur["title"] = line.split("\t")[-1]
+        elif cur is not None and line.startswith("Query length:"):
+            cur["m"] = int(re.search(r"(\d+) residues", line).group(1))
+        elif cur is not None and re.match(r"^\d+\t", line):
+            s, t = line.split("\t", 1)
+            cur["hits"].append((int(s), t))
+        elif line.startswith("Search date"):
+            cur = None
+    return blocks
+
+
+@pytest.mark.parametrize("matrix,go,ge,extra", [("blosum62", 10, 2, []), ("pam250", 14, 2, ["-k", "60000"])])
+def test_cli_search_report(tmp_path, oracle, matrix, go, ge, extra):
+    qs = synth.make_queries([120, 45, 300], seed=3)
+    L, R, O = synth.make_database(600, qs, seed=9, homologs_per_query=4)
+    seqs = [R[O[i]:O[i + 1]] for i in range(600)]
+    titles = [f"syn|{i}|len={len(s)}" for i, s in enumerate(seqs)]
+    synth.write_fasta(str(tmp_path / "db.fasta"), seqs, titles)
+    synth.write_fasta(str(tmp_path / "q.fasta"), qs, titles=["q120 first in file", "q45", "q300"])
+    db = str(tmp_path / "db")
+    subprocess.run([hostlib.CLI, "-O", "preprocess", "-i", str(tmp_path / "db.fasta"), "-o", db], check=True, capture_output=True)
+    p = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-q", str(tmp_path / "q.fasta"), "-d", db, "-s", matrix,
+                        "-g", str(go), "-e", str(ge), "-r", "7"] + extra, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    out = p.stdout
+    assert out.startswith("\nOSWALD v1.0 \n\nDatabase file:\t\t\t" + db + "\n")
+    assert f"Database size:\t\t\t600 sequences ({int(L.sum())} residues) \n" in out
+    assert f"Substitution matrix:\t\t{matrix.upper()}\nGap open penalty:\t\t{go}\nGap extend penalty:\t\t{ge}\n" in out
+    assert re.search(r"Search speed:\t\t\t\d+\.\d\d GCUPS\n", out)
+    blocks = parse_report(out)
+    # queries are reported in ascending length order (reference sequences.c:342)
+    assert [b["m"] for b in blocks] == [45, 120, 300]
+    assert [b["title"] for b in blocks] == ["q45", "q120 first in file", "q300"]
+    # expected: oracle scores on the sorted database, reference tie order
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    b, n, disp = dblayout.interleave(sl, sr, so, 16)
+    sorted_qs = [qs[1], qs[0], qs[2]]
+    a, m, ad = pack_queries(sorted_qs)
+    want = oracle.search_chunk_scalar(a, m, ad, b, n, disp.astype(np.uint32), 16, submat.load(matrix), go, ge)
+    for qi, blk in enumerate(blocks):
+        sc, ix = dblayout.topr_reference_order(want[qi, :600], 7)
+        assert [h[0] for h in blk["hits"]] == sc.tolist()
+        assert [h[1] for h in blk["hits"]] == [titles[order[i]] for i in ix]

@@ -1,0 +1,29 @@
+#!/bin/bash
+# tools/profile_gpu.sh -- rocprofv3 evidence for bench.py's dominant kernel, run
+# on the GPU box through gpurun:  gpurun -- 'bash tools/profile_gpu.sh c2 100000'
+# Pass 1: kernel trace + stats (durations).  Passes 2-4: PMC counters, each in
+# its own run with nothing but --pmc (MI355X_MICROARCH.md: FETCH_SIZE and
+# WRITE_SIZE do not fit one pass; counters are never mixed with trace domains).
+# Raw output goes to gpurun_out/prof_*; tools/summarize_prof.py condenses it.
+set -e -o pipefail
+WL=${1:-c2}
+NSEQ=${2:-100000}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_${WL}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $REPO/bench.py --workload $WL --nseq $NSEQ --cpu-seconds 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 5 --warmup 1 > "$OUT/stats.log" 2>&1
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH --steps 2 --warmup 0 > "$OUT/fetch.log" 2>&1
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH --steps 2 --warmup 0 > "$OUT/write.log" 2>&1
+echo "write pass done"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/sq" -- $BENCH --steps 2 --warmup 0 > "$OUT/sq.log" 2>&1
+echo "sq pass done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -- $REPO/tools/ubench calib > "$OUT/calib_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -- $REPO/tools/ubench calib > "$OUT/calib_write.log" 2>&1
+echo "calibration passes done"
+cd "$REPO"
+python3 tools/summarize_prof.py "$OUT" "$WL" "$NSEQ" > "$OUT/summary.txt" 2>&1 || true
+cat "$OUT/summary.txt"

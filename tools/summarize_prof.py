@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""tools/summarize_prof.py -- condense rocprofv3 CSV output of tools/profile_gpu.sh
+into the small files committed under profiles/ (kernel stats, PMC per-launch
+averages, HBM traffic per launch of the DP kernel)."""
+import csv, glob, json, os, sys
+
+out, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
+KERNELS = ("osw_sw_pk16", "osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
+
+
+def find(sub, pattern):
+    r = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
+    return r[0] if r else None
+
+
+summary = {"workload": wl, "nseq": int(nseq)}
+f = find("stats", "*kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    summary["kernel_stats"] = [{k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
+f = find("stats", "*kernel_trace.csv")
+if f:
+    rows = [r for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "").startswith("osw_sw_pk16")]
+    if rows:
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+        summary["pk16_trace"] = {"launches": len(d), "avg_ms": sum(d) / len(d) / 1e6, "min_ms": min(d) / 1e6, "max_ms": max(d) / 1e6,
+                                 "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"), "lds": rows[0].get("LDS_Block_Size"),
+                                 "grid": rows[0].get("Grid_Size"), "workgroup": rows[0].get("Workgroup_Size")}
+
+
+def pmc(sub):
+    f = find(sub, "*counter_collection.csv")
+    res = {}
+    if not f:
+        return res
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        name = next((x for x in KERNELS if k.startswith(x)), None)
+        if not name:
+            continue
+        c = r["Counter_Name"]
+        v = float(r["Counter_Value"])
+        e = res.setdefault(name, {}).setdefault(c, [0.0, set()])
+        e[0] += v
+        e[1].add(r.get("Dispatch_Id"))
+    return {k: {c: {"sum": v[0], "dispatches": len(v[1]), "per_dispatch": v[0] / max(1, len(v[1]))} for c, v in d.items()} for k, d in res.items()}
+
+
+def calib(sub, counter, kernel):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        return None
+    tot = 0.0
+    for r in csv.DictReader(open(f)):
+        if r.get("Kernel_Name", "").startswith(kernel) and r["Counter_Name"] == counter:
+            tot += float(r["Counter_Value"])
+    return tot or None
+
+
+summary["pmc_fetch"] = pmc("fetch")
+summary["pmc_write"] = pmc("write")
+summary["pmc_sq"] = pmc("sq")
+try:
+    fs = summary["pmc_fetch"]["osw_sw_pk16"]["FETCH_SIZE"]["per_dispatch"]
+    ws = summary["pmc_write"]["osw_sw_pk16"]["WRITE_SIZE"]["per_dispatch"]
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts 64 B per
+    # 128-B request for wide coalesced reads, other widths must be calibrated on a known byte count in the kernel's own
+    # access pattern.  The DP kernel moves 8 B per lane; `ubench calib` reads and writes exactly 1 GiB that way.
+    GIB = float(1 << 30)
+    cf = calib("calib_fetch", "FETCH_SIZE", "stream_read8")
+    cw = calib("calib_write", "WRITE_SIZE", "stream_write8")
+    kf = GIB / (cf * 1024) if cf else 2.0
+    kw = GIB / (cw * 1024) if cw else 1.0
+    summary["traffic"] = {"fetch_kib_raw": fs, "write_kib_raw": ws, "calib_fetch_kib_for_1GiB": cf, "calib_write_kib_for_1GiB": cw,
+                          "fetch_factor": kf, "write_factor": kw,
+                          "hbm_bytes_per_launch": int((kf * fs + kw * ws) * 1024),
+                          "correction": "bytes = KiB * 1024 * factor; factor = 1 GiB / counter value of a 1-GiB 8-B-per-lane stream (same access width as the DP kernel)"}
+except KeyError:
+    pass
+print(json.dumps(summary, indent=1))

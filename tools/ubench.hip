@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -52,6 +53,18 @@ __global__ __launch_bounds__(256) void lds_rate(uint32_t *out, const uint32_t *r
     if (acc == 0x12345678u) out[threadIdx.x] = acc;
 }
 
+// PMC calibration: a known number of bytes moved with the DP kernel's access width (8 B per lane)
+__global__ __launch_bounds__(256) void stream_read8(const uint2 *src, uint32_t *out, size_t n)
+{
+    uint32_t acc = 0;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const uint2 v = src[i]; acc += v.x ^ v.y; }
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void stream_write8(uint2 *dst, size_t n)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = make_uint2((uint32_t)i, 7u);
+}
+
 template <class F>
 static double time_ms(F f, int reps)
 {
@@ -68,8 +81,20 @@ static double time_ms(F f, int reps)
     return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "calib")) {
+        // 1 GiB read + 1 GiB written, 8 B per lane: compare with FETCH_SIZE / WRITE_SIZE of these two kernels
+        const size_t n = (1ull << 30) / 8;
+        uint2 *buf; uint32_t *o;
+        hipMalloc(&buf, n * 8); hipMalloc(&o, 4096);
+        hipMemset(buf, 1, n * 8);
+        hipLaunchKernelGGL(stream_write8, dim3(2048), dim3(256), 0, 0, buf, n);
+        hipLaunchKernelGGL(stream_read8, dim3(2048), dim3(256), 0, 0, (const uint2 *)buf, o, n);
+        hipDeviceSynchronize();
+        printf("calib: wrote %zu bytes (stream_write8), read %zu bytes (stream_read8)\n", n * 8, n * 8);
+        return 0;
+    }
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
