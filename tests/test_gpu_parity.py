@@ -223,3 +223,48 @@ def test_workgroup_items(hip_ctx, oracle, lg, monkeypatch):
     got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
     want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
     np.testing.assert_array_equal(got, want)
+
+
+def test_edge_cases_empty_inputs(hip_ctx, oracle):
+    """Empty query (length 0) scores 0 everywhere; an empty chunk is a no-op;
+    errors are reported, not swallowed."""
+    from oswald_amd import capi
+    sm = submat.load("blosum62")
+    qs = [np.zeros(0, np.uint8), synth.make_queries([20], seed=1)[0]]
+    L, R, O = random_db(40, seed=2, max_len=50)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert (got[0] == 0).all()
+    # empty chunk
+    a, m, ad = pack_queries(qs[1:])
+    hip_ctx.set_queries(a, m, ad)
+    h = hip_ctx.chunk_upload(np.zeros(0, np.uint8), np.zeros(0, np.uint16), np.zeros(0, np.uint32), 16)
+    hip_ctx.chunk_search(h, None)
+    hip_ctx.wait()
+    hip_ctx.chunk_release(h)
+    # a group running past the chunk buffer is rejected before anything is launched
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_upload(np.zeros(100, np.uint8), np.array([28], np.uint16), np.array([0], np.uint32), 16)
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_upload(b, n, disp, 24)
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_topr(9999, 1, 1)
+
+
+def test_max_length_sequence_and_many_queries(hip_ctx, oracle):
+    """One very long database sequence (8 000 residues) among short ones and 40
+    queries: item planning with extreme cost ratios."""
+    rng = np.random.default_rng(8)
+    qs = [rng.integers(0, 23, int(l)).astype(np.uint8) for l in rng.integers(5, 60, 40)]
+    long_seq = synth.random_residues(77, 0, 8000)
+    long_seq[4000:4050] = qs[-1][:50] if len(qs[-1]) >= 50 else long_seq[4000:4050]
+    seqs = [synth.random_residues(100 + i, 0, int(l)) for i, l in enumerate(rng.integers(1, 40, 30))] + [long_seq]
+    from helpers import db_from_sequences
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum80")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 11, 1)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 11, 1)
+    np.testing.assert_array_equal(got, want)
