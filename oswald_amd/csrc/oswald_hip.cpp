@@ -179,20 +179,37 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
         }
         return lg;
     };
-    std::vector<uint32_t> lgmax(nq), lgmax_wg(nq), lg_floor(nq);
+    // Default geometry of a query: as many lane groups as it has 32-row strips, so that the
+    // groups hand their bottom rows to each other in registers and (almost) nothing spills to
+    // HBM.  Up to 128 rows that fits a wave's private LDS slice (wave item, one round); longer
+    // queries run as workgroup items with the 4x larger shared slice (G <= 16, 512 rows per round).
+    struct Mode { bool wg; uint32_t lg; };
+    std::vector<Mode> def(nq);
+    std::vector<uint32_t> lgmax(nq), lgmax_wg(nq);
     double total = 0;
     for (uint32_t q = 0; q < nq; ++q) {
         lgmax[q] = lg_limit(ctx->m[q], ldsr, 8);
-        lg_floor[q] = 0;
-        while (lg_floor[q] < 2 && lg_floor[q] < lgmax[q] && (2u << lg_floor[q]) * rmax <= ((ctx->m[q] + 3u) & ~3u)) ++lg_floor[q];
-        lgmax_wg[q] = lg_limit(ctx->m[q], ldsr_wg, 4);
-        for (uint32_t b = 0; b < c.nblocks; ++b) total += item_cost(ctx->m[q], 0, c.ncols4_alloc[b] * 4, ldsr);
+        lgmax_wg[q] = i32 ? 0 : lg_limit(ctx->m[q], ldsr_wg, 4);
+        const uint32_t m4 = std::max(4u, (ctx->m[q] + 3u) & ~3u);
+        uint32_t lg = 0;
+        while ((rmax << lg) < m4 && lg < 4) ++lg;         // smallest G with G*rmax >= m4, at most 16
+        if ((rmax << lg) <= ldsr || lgmax_wg[q] < 2) {
+            def[q] = {false, std::min(lg, lgmax[q])};
+            while ((rmax << def[q].lg) > ldsr && def[q].lg > 0) --def[q].lg; // int32 / tiny LDS: stay inside the slice
+        } else {
+            def[q] = {true, std::max(2u, std::min(lg, lgmax_wg[q]))};
+        }
+        for (uint32_t b = 0; b < c.nblocks; ++b)
+            total += (double)(1u << def[q].lg) * item_cost(ctx->m[q], def[q].lg, c.ncols4_alloc[b] * 4, def[q].wg ? ldsr_wg : ldsr);
     }
     const double nwaves = (double)d.grid * (OSW_WG_THREADS / 64);
     const double target = std::max(total / nwaves / 3.0, 1.0e6);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
-    // OSWALD_HIP_FORCE_WG=1 runs every item as a workgroup item (G >= 4)
-    int force_lg = -1, force_wg = 0;
+    // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
+    int force_lg = -1, force_wg = -1;
+    uint32_t wg_min_cols = 384, wg_wide_cols = 2048;
+    if (const char *e = getenv("OSWALD_HIP_WG_MINCOLS")) wg_min_cols = (uint32_t)atoi(e);
+    if (const char *e = getenv("OSWALD_HIP_WG_WIDECOLS")) wg_wide_cols = (uint32_t)atoi(e);
     if (const char *e = getenv("OSWALD_HIP_FORCE_LG")) force_lg = atoi(e);
     if (const char *e = getenv("OSWALD_HIP_FORCE_WG")) force_wg = atoi(e);
     if (force_lg > 6) force_lg = 6;
@@ -204,33 +221,41 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     for (uint32_t q = 0; q < nq; ++q)
         for (uint32_t b = 0; b < c.nblocks; ++b) {
             const uint32_t ncols = c.ncols4_alloc[b] * 4, m = ctx->m[q];
-            // even light items run at G = 4 when the query has >= 4 full strips: the groups hand their
-            // bottom rows to each other in registers, so only every 4th strip boundary spills to HBM
-            uint32_t lg = lg_floor[q];
-            bool wg = false;
-            while (lg < lgmax[q] && item_cost(m, lg, ncols, ldsr) > target) ++lg;
-            if (!i32 && item_cost(m, lg, ncols, ldsr) > target && lgmax_wg[q] >= 2) {
-                // too heavy for a lone wave: smallest workgroup geometry that fits, else the cheapest
-                uint32_t best = 2;
-                double best_cost = item_cost(m, 2, ncols, ldsr_wg);
-                for (uint32_t k = 2; k <= lgmax_wg[q]; ++k) {
-                    const double ck = item_cost(m, k, ncols, ldsr_wg);
-                    if (ck < best_cost) { best = k; best_cost = ck; }
-                    if (ck <= target) { best = k; best_cost = ck; break; }
-                }
-                if (best_cost < item_cost(m, lg, ncols, ldsr)) { lg = best; wg = true; }
+            bool wg = def[q].wg;
+            uint32_t lg = def[q].lg;
+            if (wg && ncols < wg_min_cols) {
+                // short block: the pipeline fill of a wide geometry (G columns per round) would cost more
+                // than the spill it saves; run as wave items at G = 4
+                wg = false;
+                lg = std::min(2u, lgmax[q]);
+            } else if (wg && ncols < wg_wide_cols && lg > 3) {
+                lg = 3; // medium block: 8 groups (256 rows per round)
             }
-            if (force_lg >= 0) lg = (uint32_t)force_lg;
-            if (force_wg) { wg = true; if (lg < 2) lg = 2; }
+            double cost = item_cost(m, lg, ncols, wg ? ldsr_wg : ldsr);
+            if (cost > target) {
+                // too long for one wave's share: widen the geometry (shorter critical path, a little less
+                // efficient); among the candidates take the first that fits, else the cheapest
+                double best = cost;
+                bool bwg = wg;
+                uint32_t blg = lg;
+                auto consider = [&](bool w, uint32_t k) {
+                    const double ck = item_cost(m, k, ncols, w ? ldsr_wg : ldsr);
+                    if (ck < best) { best = ck; bwg = w; blg = k; }
+                    return ck <= target;
+                };
+                bool done = false;
+                if (!wg) for (uint32_t k = lg + 1; k <= lgmax[q] && !done; ++k) done = consider(false, k);
+                if (!i32) for (uint32_t k = std::max(2u, wg ? lg + 1 : 2u); k <= lgmax_wg[q] && !done; ++k) done = consider(true, k);
+                wg = bwg; lg = blg; cost = best;
+            }
+            if (force_lg >= 0) { lg = (uint32_t)force_lg; wg = false; }
+            if (force_wg == 1) { wg = true; if (lg < 2) lg = 2; }
+            if (force_wg == 0) wg = false;
+            if (force_lg >= 0 || force_wg >= 0) cost = item_cost(m, lg, ncols, wg ? ldsr_wg : ldsr);
             const uint32_t G = 1u << lg;
             c.max_lg = std::max(c.max_lg, lg);
-            if (wg) {
-                const double cost = item_cost(m, lg, ncols, ldsr_wg);
-                for (uint32_t s = 0; s < G; s += 4) its_wg.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
-            } else {
-                const double cost = item_cost(m, lg, ncols, ldsr);
-                for (uint32_t s = 0; s < G; ++s) its.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
-            }
+            if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
+            else for (uint32_t s = 0; s < G; ++s) its.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
         }
     auto by_cost = [](const It &x, const It &y) { return x.cost > y.cost; };
     std::stable_sort(its.begin(), its.end(), by_cost);
@@ -251,7 +276,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
         double sw = 0, sg = 0;
         for (const It &i : its) sw += i.cost;
         for (const It &i : its_wg) sg += i.cost * 4;
-        fprintf(stderr, "[oswald_hip] plan: total(G=1) %.3g slots, %.0f waves, target %.3g; wave items %zu (sum %.3g, max %.3g), "
+        fprintf(stderr, "[oswald_hip] plan: total %.3g slots, %.0f waves, target %.3g; wave items %zu (sum %.3g, max %.3g), "
                         "workgroup items %zu (sum %.3g, max %.3g), max lg %u\n",
                 total, nwaves, target, its.size(), sw, its.empty() ? 0.0 : its[0].cost, its_wg.size(), sg,
                 its_wg.empty() ? 0.0 : its_wg[0].cost, c.max_lg);

@@ -105,17 +105,62 @@ struct CellPK16 {
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
 
-    // four rows of substitution scores for both sequences of the lane:
-    // two ds_read_b64 + four v_perm_b32 that pair up (seq lo, seq hi)
-    static __device__ __forceinline__ void load_s(lds_u2p lp, uint32_t alo, uint32_t ahi, int rb, T (&s)[4])
+    // Four rows of substitution scores for both sequences of the lane: two
+    // ds_read_b64 (one per sequence) + four v_perm_b32 that pair up (lo, hi).
+    // The loads are inline asm so that they stay single ds_read_b64: the
+    // compiler would fuse neighbouring row-blocks into ds_read2_b64, whose
+    // 32-bank addressing makes residue codes c and c+16 collide (measured:
+    // 2.5 conflict cycles per LDS instruction); ds_read_b64 sees 64 banks and
+    // the 32 codes x 8 B of a row-block are conflict-free.  Loads run two
+    // batches ahead; the compiler does not count inline-asm loads, so the
+    // waits are explicit (all but the newest 2 = the batch issued last).
+    struct Raw { u32x2 lo, hi; };
+    template <int RB>
+    static __device__ __forceinline__ void ld(uint32_t a_lo, uint32_t a_hi, Raw &r)
     {
-        const u32x2 plo = *(lds_u2p)((lds_cp)lp + alo + rb * 256);
-        const u32x2 phi = *(lds_u2p)((lds_cp)lp + ahi + rb * 256);
-        s[0] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x05040100u));
-        s[1] = as_v2s(__builtin_amdgcn_perm(phi.x, plo.x, 0x07060302u));
-        s[2] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x05040100u));
-        s[3] = as_v2s(__builtin_amdgcn_perm(phi.y, plo.y, 0x07060302u));
+        asm volatile("ds_read_b64 %0, %2 offset:%4\n\t"
+                     "ds_read_b64 %1, %3 offset:%4"
+                     : "=&v"(r.lo), "=&v"(r.hi)
+                     : "v"(a_lo), "v"(a_hi), "i"(RB * 256)
+                     : "memory");
     }
+    template <int Newest>
+    static __device__ __forceinline__ void landed(Raw &r)
+    {
+        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.lo), "+v"(r.hi));
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r.lo), "+v"(r.hi));
+    }
+    static __device__ __forceinline__ void pair_up(const Raw &r, T (&s)[4])
+    {
+        s[0] = as_v2s(__builtin_amdgcn_perm(r.hi.x, r.lo.x, 0x05040100u));
+        s[1] = as_v2s(__builtin_amdgcn_perm(r.hi.x, r.lo.x, 0x07060302u));
+        s[2] = as_v2s(__builtin_amdgcn_perm(r.hi.y, r.lo.y, 0x05040100u));
+        s[3] = as_v2s(__builtin_amdgcn_perm(r.hi.y, r.lo.y, 0x07060302u));
+    }
+
+    template <int R, int RB>
+    struct Batch {
+        // s = scores of this row-block (paired), r1 = raw next block (in flight or landed), r2 = free
+        static __device__ __forceinline__ void run(uint32_t a_lo, uint32_t a_hi, T (&D)[R], T (&E)[R], T &x, T &f, T &hl, GapT goe, GapT ge,
+                                                   T &score, T (&s)[4], Raw &r1, Raw &r2)
+        {
+            T sn[4];
+            if constexpr (RB + 2 < R / 4) ld<RB + 2>(a_lo, a_hi, r2);
+            if constexpr (RB + 1 < R / 4) {
+                if constexpr (RB + 2 < R / 4) landed<2>(r1); else landed<0>(r1);
+                pair_up(r1, sn);
+            }
+            OSW_PK16_ROW(x, E[RB * 4 + 0], D[RB * 4 + 1], f, score, s[1], ge, goe);
+            OSW_PK16_ROW(x, E[RB * 4 + 1], D[RB * 4 + 2], f, score, s[2], ge, goe);
+            OSW_PK16_ROW(x, E[RB * 4 + 2], D[RB * 4 + 3], f, score, s[3], ge, goe);
+            if constexpr (RB + 1 < R / 4) {
+                OSW_PK16_ROW(x, E[RB * 4 + 3], D[RB * 4 + 4], f, score, sn[0], ge, goe);
+                Batch<R, RB + 1>::run(a_lo, a_hi, D, E, x, f, hl, goe, ge, score, sn, r2, r1);
+            } else {
+                OSW_PK16_ROW_LAST(x, E[RB * 4 + 3], hl, f, score, ge, goe);
+            }
+        }
+    };
 
     // One database column against the R rows of the strip.
     //   top_prev = H(i0-1, j-1); f in: F(i0, j), out: F(i0+R, j); hl = H(i0+R-1, j)
@@ -123,23 +168,15 @@ struct CellPK16 {
     static __device__ __forceinline__ void column(lds_u2p lp, uint32_t alo, uint32_t ahi, int /*half*/, T (&D)[R], T (&E)[R],
                                                   T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
     {
-        T s[4], sn[4];
-        load_s(lp, alo, ahi, 0, s);
+        const uint32_t base = (uint32_t)(uintptr_t)lp;
+        const uint32_t a_lo = base + alo, a_hi = base + ahi;
+        Raw r0, r1, r2;
+        T s[4];
+        ld<0>(a_lo, a_hi, r0);
+        if constexpr (R / 4 > 1) { ld<1>(a_lo, a_hi, r1); landed<2>(r0); } else { landed<0>(r0); }
+        pair_up(r0, s);
         T x = __builtin_elementwise_add_sat(top_prev, s[0]);
-#pragma unroll
-        for (int rb = 0; rb < R / 4; ++rb) {
-            if (rb + 1 < R / 4) load_s(lp, alo, ahi, rb + 1, sn);
-            OSW_PK16_ROW(x, E[rb * 4 + 0], D[rb * 4 + 1], f, score, s[1], ge, goe);
-            OSW_PK16_ROW(x, E[rb * 4 + 1], D[rb * 4 + 2], f, score, s[2], ge, goe);
-            OSW_PK16_ROW(x, E[rb * 4 + 2], D[rb * 4 + 3], f, score, s[3], ge, goe);
-            if (rb + 1 < R / 4) {
-                OSW_PK16_ROW(x, E[rb * 4 + 3], D[rb * 4 + 4], f, score, sn[0], ge, goe);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) s[k] = sn[k];
-            } else {
-                OSW_PK16_ROW_LAST(x, E[rb * 4 + 3], hl, f, score, ge, goe);
-            }
-        }
+        Batch<R, 0>::run(a_lo, a_hi, D, E, x, f, hl, goe, ge, score, s, r1, r2);
     }
 };
 
