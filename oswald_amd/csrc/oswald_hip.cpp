@@ -524,6 +524,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.items = (const uint2 *)c.items.p;
     a.nitems = c.nitems;
     a.nitems_wg = c.nitems_wg;
+    a.two_ended_waves = getenv("OSWALD_HIP_TWO_ENDED") ? (uint32_t)atoi(getenv("OSWALD_HIP_TWO_ENDED")) : 0u;
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;
@@ -632,7 +633,7 @@ int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, 
     HIP_TRY(hipSetDevice(d.id));
     HIP_TRY(hipStreamSynchronize(d.stream));
     drain_events(d);
-    uint32_t ctr[OSW_CTR_COUNT] = {0};
+    uint32_t ctr[8] = {0};
     HIP_TRY(hipMemcpy(ctr, d.counters.p, sizeof ctr, hipMemcpyDeviceToHost));
     if (dp_kernel_ms) *dp_kernel_ms = d.dp_ms;
     if (dp_launches) *dp_launches = d.dp_launches;

@@ -62,7 +62,13 @@ static __host__ __device__ inline uint32_t osw_plan_maxrows(const OswPlan &p) { 
 #define OSW_CTR_OVF 1        // number of items queued for the int32 re-run
 #define OSW_CTR_WORK32 2     // next item of the int32 queue
 #define OSW_CTR_WORK_WG 3     // next workgroup-cooperative (heavy) item of the pk16 queue
-#define OSW_CTR_COUNT 8
+#define OSW_CTR_FRONT 4       // wave items taken from the heavy end / light end of the queue
+#define OSW_CTR_BACK 5
+#define OSW_CTR_FRONT_WG 6    // same for workgroup items
+#define OSW_CTR_BACK_WG 7
+#define OSW_CTR_CU0 8         // per-CU arrival counters (which workgroup came first on a CU)
+#define OSW_CTR_CUS 4096
+#define OSW_CTR_COUNT (OSW_CTR_CU0 + OSW_CTR_CUS)
 
 // One wave block of the re-tiled chunk: 128 consecutive sequences of the
 // (length-sorted) chunk, stored column-major in groups of 4 columns.
@@ -79,6 +85,7 @@ struct OswSearchArgs {
     const uint2 *items;        // work queue, heaviest first: nitems_wg workgroup items, then nitems wave items
     uint32_t nitems;
     uint32_t nitems_wg;
+    uint32_t two_ended_waves;  // wave items: eat the queue from both ends (see osw_sw_pk16) or heaviest-first only
     uint32_t force_all;        // int32 kernel: run `items` instead of the overflow queue
     const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16
     const uint32_t *prof_off;

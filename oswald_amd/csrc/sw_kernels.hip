@@ -407,9 +407,28 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
 
+    // Which end of the (cost-sorted) queues this workgroup eats from: the first workgroup to
+    // arrive on a CU takes the heavy end, later arrivals the light end, so that a long item
+    // shares its SIMD with short ones (and, with its raised priority, runs at nearly the full
+    // issue rate) instead of with three other long ones.  Placement is read from the hardware
+    // id registers; it only steers speed, never correctness.
+    if (threadIdx.x == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));   // HW_REG_HW_ID[15:8]: cu, sh, se
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); // HW_REG_XCC_ID[3:0]
+        const uint32_t cu = ((xcc & 15u) << 8) | (hw & 255u);
+        wg_item = atomicAdd(&p.counters[OSW_CTR_CU0 + (cu & (OSW_CTR_CUS - 1))], 1u);
+    }
+    __syncthreads();
+    const bool heavy_end = wg_item == 0;
+    __syncthreads();
+
     // phase 1: heavy items, the workgroup's four waves on four sub-blocks of one item
     for (;;) {
-        if (threadIdx.x == 0) wg_item = atomicAdd(&p.counters[OSW_CTR_WORK_WG], 1u);
+        if (threadIdx.x == 0) {
+            uint32_t t = atomicAdd(&p.counters[OSW_CTR_WORK_WG], 1u);
+            if (t < p.nitems_wg) t = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT_WG], 1u) : p.nitems_wg - 1 - atomicAdd(&p.counters[OSW_CTR_BACK_WG], 1u);
+            wg_item = t;
+        }
         __syncthreads();
         const uint32_t it = wg_item;
         __syncthreads();
@@ -427,7 +446,10 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
     const uint2 *items = p.items + p.nitems_wg;
     for (;;) {
         uint32_t it = 0;
-        if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
+        if (lane == 0) {
+            it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
+            if (it < p.nitems && p.two_ended_waves) it = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT], 1u) : p.nitems - 1 - atomicAdd(&p.counters[OSW_CTR_BACK], 1u);
+        }
         it = __builtin_amdgcn_readfirstlane(it);
         if (it >= p.nitems) break;
         const uint2 item = items[it];

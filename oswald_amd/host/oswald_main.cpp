@@ -188,9 +188,10 @@ int do_search(Options &o)
     std::vector<int32_t> scores(nq * db.vect_sequences_count * W, 0);
     std::vector<std::vector<int32_t>> tmp(o.num_devices);
 
-    const double tick = dwalltime();
+    // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80)
     oswald_hip_ctx *ctx = nullptr;
     check(oswald_hip_init((int)o.num_devices, nullptr, &ctx), "device bring-up");
+    const double tick = dwalltime();
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 16), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
     // chunk c of a round goes to device c mod ndev (reference FPGAsearch.c:132-138)

@@ -32,6 +32,29 @@ __global__ __launch_bounds__(256) void pk_rate(uint32_t *out, uint32_t c1, uint3
     if (acc == 0x12345678u) out[threadIdx.x] = acc;
 }
 
+// plain 32-bit integer VALU (v_add_u32 / v_max_i32 / v_max3_i32 / v_sub_u32): issue rate vs packed int16
+template <int ILP>
+__global__ __launch_bounds__(256) void i32_rate(uint32_t *out, int c1, int c2, int iters)
+{
+    int x[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) x[i] = threadIdx.x + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) {
+            int t;
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(x[i]), "v"(c1));
+            asm volatile("v_max_i32 %0, %1, %2" : "=v"(x[i]) : "v"(t), "v"(c2));
+            asm volatile("v_sub_u32 %0, %1, %2" : "=v"(t) : "v"(x[i]), "v"(c1));
+            asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(x[i]) : "v"(t), "v"(c2), "v"(c1));
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc ^= (uint32_t)x[i];
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
 // LDS: ds_read_b64 of 4 profile rows at residue*8 + imm, 16 reads per "column"
 __global__ __launch_bounds__(256) void lds_rate(uint32_t *out, const uint32_t *res, int iters)
 {
@@ -116,6 +139,15 @@ int main(int argc, char **argv)
         run(pk_rate<1>, 1, "ilp1");
         run(pk_rate<2>, 2, "ilp2");
         run(pk_rate<8>, 8, "ilp8");
+    }
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        auto run = [&](auto kern, int ilp, const char *name) {
+            double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(cus * wps), dim3(256), 0, 0, out, 3, 1, iters); }, 3);
+            double ops = (double)cus * wps * 4 * iters * ilp * 4.0;
+            printf("i32_rate %-6s waves/SIMD=%d : %.3f ms = %.2f cycles/instr/SIMD at 2.4GHz\n", name, wps, ms, (double)cus * 4 * 2.4e9 / (ops / (ms * 1e-3)));
+        };
+        run(i32_rate<1>, 1, "ilp1");
+        run(i32_rate<8>, 8, "ilp8");
     }
     for (int wps = 1; wps <= 4; wps *= 2) {
         double ms = time_ms([&] { hipLaunchKernelGGL(lds_rate, dim3(cus * wps), dim3(256), 0, 0, out, res, iters); }, 3);
