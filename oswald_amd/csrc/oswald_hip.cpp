@@ -81,7 +81,7 @@ struct Device {
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, submat, bnd, counters, staging_b, staging_n, staging_disp;
-    DevBuf topr_scores, topr_index;
+    DevBuf topr_scores, topr_index, wg_times;
     uint64_t bnd_stride = 0;         // uint2 per wave slot
     uint64_t queries_version = ~0ull; // what is currently uploaded
     uint64_t scoring_version = ~0ull;
@@ -265,7 +265,8 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     for (const It &i : its) planned += i.cost;
     for (const It &i : its_wg) planned += i.cost * 4;
     const double fair = planned / nwaves;
-    auto prio_of = [&](double cost) { return cost > fair / 2 ? 3u : cost > fair / 4 ? 2u : cost > fair / 8 ? 1u : 0u; };
+    const bool no_prio = getenv("OSWALD_HIP_NO_PRIO") != nullptr;
+    auto prio_of = [&](double cost) { return no_prio ? 0u : cost > fair / 2 ? 3u : cost > fair / 4 ? 2u : cost > fair / 8 ? 1u : 0u; };
     std::vector<uint2> flat;
     flat.reserve(its.size() + its_wg.size());
     for (const It &i : its_wg) flat.push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
@@ -366,7 +367,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.items.release(); c.scores.release(); c.ovf.release(); }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.submat, &d.bnd, &d.counters, &d.staging_b,
-                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index})
+                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.wg_times})
             b->release();
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -541,6 +542,12 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.goe = (int32_t)goe;
     a.ge = (int32_t)ge;
 
+    const bool dbg_times = getenv("OSWALD_HIP_DEBUG_TIMES") != nullptr;
+    if (dbg_times) {
+        HIP_TRY(d.wg_times.reserve((size_t)d.grid * 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d.wg_times.p, 0, (size_t)d.grid * 4 * sizeof(unsigned long long), d.stream));
+        a.wg_times = (unsigned long long *)d.wg_times.p;
+    }
     EventPair ev{};
     if (ctx->profiling) {
         if (d.ev_pool.empty()) {
@@ -555,6 +562,29 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     HIP_TRY(osw_launch_i32(a, grid, d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
+    if (dbg_times) {
+        // diagnostics only: when did the workgroups of the DP launch start / leave phase 1 / finish
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        std::vector<unsigned long long> t((size_t)grid * 4);
+        HIP_TRY(hipMemcpy(t.data(), d.wg_times.p, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (uint32_t g = 0; g < grid; ++g) { if (t[g * 4]) t0 = std::min(t0, t[g * 4]); t1 = std::max(t1, std::max(t[g * 4 + 2], t[g * 4 + 3])); }
+        const double span = (double)(t1 - t0) / 100.0; // us
+        uint32_t hist_p1[10] = {0}, hist_end[10] = {0};
+        double sum_end = 0;
+        for (uint32_t g = 0; g < grid; ++g) {
+            const double p1 = (double)(t[g * 4 + 1] - t0) / 100.0, e = (double)(std::max(t[g * 4 + 2], t[g * 4 + 3]) - t0) / 100.0;
+            hist_p1[std::min(9, (int)(p1 / span * 10))]++;
+            hist_end[std::min(9, (int)(e / span * 10))]++;
+            sum_end += e;
+        }
+        fprintf(stderr, "[oswald_hip] DP launch span %.1f us over %u workgroups; mean finish at %.0f%% of span\n", span, grid, 100.0 * sum_end / grid / span);
+        fprintf(stderr, "[oswald_hip]   phase-1 exits by decile:");
+        for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_p1[k]);
+        fprintf(stderr, "\n[oswald_hip]   finishes by decile:    ");
+        for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_end[k]);
+        fprintf(stderr, "\n");
+    }
     if (scores_out) {
         const size_t row = (size_t)c.ngroups * c.W * sizeof(int32_t);
         HIP_TRY(hipMemcpy2DAsync(scores_out, row, c.scores.p, (size_t)c.score_stride * sizeof(int32_t), row, ctx->nq,

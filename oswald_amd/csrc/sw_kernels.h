@@ -98,6 +98,7 @@ struct OswSearchArgs {
     uint2 *ovf_items;
     uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves
     int32_t goe, ge;
+    unsigned long long *wg_times; // diagnostics (or null): per workgroup {start, end of phase 1, end, end} in 100 MHz ticks
 };
 
 // host-side launchers, defined in sw_kernels.hip

@@ -237,16 +237,19 @@ static __device__ __forceinline__ void sw_round(const uint2 *__restrict__ tb, ui
     const int src = ((lane - (int)gl) & 63) << 2; // ds_bpermute source: the lane one group below
     uint32_t hand_h = 0, hand_f = 0, hand_c = 0x1717u;
     uint2 res = tb[0], res_n = tb[64];
-    uint2 bcur = make_uint2(0, 0);
-    if (!first) bcur = bnd[0];
+    // Boundary values {H, F} of the previous round are fetched two columns ahead into two
+    // alternating register pairs (the loop body is instantiated for even and odd columns): a value
+    // is never copied while its load is in flight, so the loop only ever waits for a load that is
+    // two column steps old.  (A rotating queue of registers would have to move the newest, still
+    // in-flight entry every step and expose the full memory latency to a wave that runs alone.)
+    uint2 bqa = make_uint2(0, 0), bqb = bqa;
+    if (!first) { bqa = bnd[0]; bqb = bnd[64]; } // scratch is padded past the last column
     const uint32_t nsteps = ncols + G - 1;
-#pragma unroll 1
-    for (uint32_t t = 0; t < nsteps; ++t) {
-        uint2 bnxt = make_uint2(0, 0);
-        if (!first) bnxt = bnd[(size_t)(t + 1) * 64]; // scratch is padded past the last column
+    auto column_step = [&](uint32_t t, uint2 &bq) {
         // inputs of group 0: column t of the stream (dummy residues / zeros once it has ended)
         uint32_t codes = (res.x & 0xffu) | ((res.y & 0xffu) << 8);
-        uint32_t topb = bcur.x, fb = bcur.y;
+        uint32_t topb = bq.x, fb = bq.y;
+        if (!first) bq = bnd[(size_t)(t + 2) * 64];
         if (t >= ncols) { codes = 0x1717u; topb = 0; fb = 0; }
         // every other group takes what the group below produced in the previous step
         if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
@@ -266,7 +269,11 @@ static __device__ __forceinline__ void sw_round(const uint2 *__restrict__ tb, ui
             res = res_n;
             res_n = tb[(size_t)((t >> 2) + 2) * 64]; // tiled is padded at its end
         }
-        bcur = bnxt;
+    };
+#pragma unroll 1
+    for (uint32_t t = 0; t < nsteps; t += 2) {
+        column_step(t, bqa);
+        if (t + 1 < nsteps) column_step(t + 1, bqb);
     }
 }
 
@@ -407,6 +414,9 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
 
+    // optional diagnostics: when each workgroup started, left phase 1 and finished (100 MHz ticks)
+    if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+
     // Which end of the (cost-sorted) queues this workgroup eats from: the first workgroup to
     // arrive on a CU takes the heavy end, later arrivals the light end, so that a long item
     // shares its SIMD with short ones (and, with its raised priority, runs at nearly the full
@@ -442,6 +452,8 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
         pk16_finish(p, q, B, blk, sigma, lg, lane, score);
     }
 
+    if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+
     // phase 2: every wave on its own
     const uint2 *items = p.items + p.nitems_wg;
     for (;;) {
@@ -460,6 +472,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
         set_wave_prio(0);
         pk16_finish(p, q, B, blk, sigma, lg, lane, score);
     }
+    if (p.wg_times && lane == 0) p.wg_times[blockIdx.x * 4 + 2 + (wv & 1)] = __builtin_amdgcn_s_memrealtime(); // waves 0/1 (or 2/3) race: any is fine
 }
 
 // ---------------------------------------------------------------------------
