@@ -54,10 +54,10 @@ def parse():
 
 def workload(name):
     if name == "c2":
-        return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="C2: 20 queries len 100-1000 x 100k-seq synthetic DB, BLOSUM62 10/2, int16 cells")
+        return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="C2: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
     if name == "c3":
-        return dict(qlens=None, matrix="pam250", go=14, ge=2, label="C3: 20 queries len 100-1000 x 100k-seq synthetic DB, PAM250 14/2, int16 cells")
-    return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="C5: 1 query len 5000 x 100k-seq synthetic DB, BLOSUM62 10/2")
+        return dict(qlens=None, matrix="pam250", go=14, ge=2, label="C3: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, PAM250 14/2, int16 cells")
+    return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="C5: 1 query len 5000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
 
 
 def main():
@@ -69,14 +69,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path is HIP only (no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU over RCCL ("nccl").  OSWALD_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer
+    # GPUs than ranks: ranks share the visible GPUs and the top-r gather runs over gloo on host tensors.
+    backend = os.environ.get("OSWALD_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    dist = None
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from oswald_amd import capi, dblayout, multigpu, submat, synth
 
@@ -98,7 +106,7 @@ def main():
     d_local = int(sl.astype(np.int64).sum())
     t_gen = time.time() - t0
 
-    ctx = capi.Context(1, [local_rank])
+    ctx = capi.Context(1, [gpu])
     ctx.set_scoring(sm, wl["go"], wl["ge"], 16)
     ctx.set_queries(a, m, a_disp)
     if b.size >= 2**32:
@@ -116,7 +124,7 @@ def main():
         ctx.chunk_search(chunk, None)
         sc, ix = ctx.chunk_topr(chunk, args.nseq, args.top)   # syncs the library's stream
         gix = ix.astype(np.int64) + rank * args.nseq          # global index = shard base + sorted position
-        return multigpu.gather_topr(sc, gix, args.top, dist, dev if dist is not None else None)
+        return multigpu.gather_topr(sc, gix, args.top, dist, coll_dev if dist is not None else None)
 
     for _ in range(args.warmup):
         step()
@@ -132,8 +140,8 @@ def main():
     kern_ms, kern_launches, rerun = ctx.kernel_stats()
     ctx.set_profiling(False)
 
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    d_all = torch.tensor([d_local], dtype=torch.float64, device=dev)
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    d_all = torch.tensor([d_local], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(d_all, op=dist.ReduceOp.SUM)
@@ -156,9 +164,9 @@ def main():
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": wl["label"], "queries": nq, "query_residues": sum_m, "db_sequences_per_gpu": args.nseq,
+            "config": {"workload": wl["label"].format(nseq=args.nseq), "queries": nq, "query_residues": sum_m, "db_sequences_per_gpu": args.nseq,
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
-                       "top": args.top, "sharding": f"db-shard x{world}, RCCL all_gather of top-{args.top}" if world > 1 else "single GPU"},
+                       "top": args.top, "sharding": f"db-shard x{world}, {'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "osw_sw_pk16(+osw_sw_i32)", "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
