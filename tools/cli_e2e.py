@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""tools/cli_e2e.py -- end-to-end wall time of the `oswald` CLI on a synthetic C2-size database."""
+import os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oswald_amd import synth
+nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+tmp = sys.argv[2] if len(sys.argv) > 2 else "/tmp/osw_e2e"
+os.makedirs(tmp, exist_ok=True)
+cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oswald_amd", "oswald")
+qs = synth.make_queries(synth.default_query_lengths())
+L, R, O = synth.make_database(nseq, qs)
+t = time.time(); synth.write_fasta(f"{tmp}/db.fasta", [R[O[i]:O[i+1]] for i in range(nseq)]); synth.write_fasta(f"{tmp}/q.fasta", qs); print("fasta written", round(time.time()-t,1), "s")
+t = time.time(); subprocess.run([cli, "-O", "preprocess", "-i", f"{tmp}/db.fasta", "-o", f"{tmp}/db"], check=True, stdout=subprocess.DEVNULL); print("preprocess", round(time.time()-t,2), "s")
+t = time.time(); p = subprocess.run([cli, "-O", "search", "-m", "0", "-q", f"{tmp}/q.fasta", "-d", f"{tmp}/db"], capture_output=True, text=True); print("search wall", round(time.time()-t,2), "s rc", p.returncode)
+print("\n".join(l for l in p.stdout.split("\n") if l.startswith(("Search time", "Search speed", "Database size"))))
+print(p.stdout.split("Query no.")[1][:400] if "Query no." in p.stdout else p.stderr[-500:])
