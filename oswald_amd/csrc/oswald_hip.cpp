@@ -203,7 +203,8 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             total += (double)(1u << def[q].lg) * item_cost(ctx->m[q], def[q].lg, c.ncols4_alloc[b] * 4, def[q].wg ? ldsr_wg : ldsr);
     }
     const double nwaves = (double)d.grid * (OSW_WG_THREADS / 64);
-    const double target = std::max(total / nwaves / 3.0, 1.0e6);
+    const double target_div = getenv("OSWALD_HIP_TARGET_DIV") ? atof(getenv("OSWALD_HIP_TARGET_DIV")) : 3.0;
+    const double target = std::max(total / nwaves / target_div, 1.0e6);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
     int force_lg = -1, force_wg = -1;
