@@ -87,8 +87,8 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
 
 /* One database chunk made resident on device `dev`: uploads the interleaved
  * groups and re-tiles them for the kernels.  b: vD bytes; n[g]: (padded) group
- * lengths; disp[g]: byte offset of group g in b; lane_width W: 16 or 32
- * (128 % W == 0).  Replaces the four clEnqueueWriteBuffer + clFinish of
+ * lengths; disp[g]: byte offset of group g in b; lane_width W: 16 (the
+ * reference's device layout), 32 (its AVX2 layout), 64 or 128.  Replaces the four clEnqueueWriteBuffer + clFinish of
  * FPGAsearch.c:180-198, minus the 23x score profile.  *chunk receives a handle
  * valid until oswald_hip_chunk_release() or finalize. */
 int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,

@@ -20,15 +20,20 @@
 //     lanes.  Group g runs strip (round*G + g) of the SAME 128/G sequences, one
 //     column behind group g-1, and receives that group's bottom row (H, F) and
 //     residues through ds_bpermute -- a systolic array inside the wave, no
-//     inter-wave synchronisation anywhere.  G = 1 is the plain case; larger G
-//     shortens the critical path of heavy (long query x long sequence) items by
-//     G so that the work queue balances, and G = 64 is the exact int32 re-run
-//     of single lanes.
+//     inter-wave synchronisation.  G = 1 is the plain case; G groups keep G
+//     strips' boundaries in registers (only every G-th strip boundary touches
+//     HBM) and shorten the critical path of heavy (long query x long sequence)
+//     items by G so that the work queue balances; G = 64 is the exact int32
+//     re-run of single lanes.
+//   * workgroup items: the four waves of a workgroup run four sub-blocks of one
+//     heavy item and share ONE 4x larger profile slice (taller rounds at the
+//     same G); two workgroup barriers per round are the only synchronisation.
 //   * between rounds the bottom row of the last group spills to a wave-private
-//     HBM scratch {H, F} per column and lane, read back one column ahead.
-//   * work items (query, block, sub-block, G) are pulled from an atomic queue
-//     sorted by cost, so one launch covers all queries of a chunk; every wave
-//     exits when the queue is drained.
+//     HBM scratch {H, F} per column and lane, read back two columns ahead.
+//   * work items (query, block, sub-block, G) are pulled from atomic queues
+//     sorted by cost (planned on the host, oswald_hip.cpp::build_items), so one
+//     launch covers all queries of a chunk; every wave exits when the queues
+//     are drained: nothing ever waits for another workgroup.
 //   * lanes that hit the int16 ceiling are queued on the device and re-run by
 //     the int32 kernel (the reference's int8->int16->int32 escalation,
 //     host/src/HybridSearch.c:1670-1680,:1774-1784, yields exact scores; so

@@ -67,3 +67,28 @@ def test_cli_search_report(tmp_path, oracle, matrix, go, ge, extra):
         sc, ix = dblayout.topr_reference_order(want[qi, :600], 7)
         assert [h[0] for h in blk["hits"]] == sc.tolist()
         assert [h[1] for h in blk["hits"]] == [titles[order[i]] for i in ix]
+
+
+def test_cli_info_and_footer(tmp_path):
+    """`-O info` lists the device; the search footer keeps the reference's labels
+    (reference FPGAsearch.c:322-331) so that scripts parsing OSWALD reports keep working."""
+    p = subprocess.run([hostlib.CLI, "-O", "info"], capture_output=True, text=True)
+    assert p.returncode == 0 and "Device 0:" in p.stdout and "compute units:" in p.stdout and "gfx950" in p.stdout
+    qs = synth.make_queries([33], seed=1)
+    L, R, O = synth.make_database(64, qs, seed=2, homologs_per_query=1)
+    synth.write_fasta(str(tmp_path / "db.fasta"), [R[O[i]:O[i + 1]] for i in range(64)])
+    synth.write_fasta(str(tmp_path / "q.fasta"), qs, titles=["the query"])
+    db = str(tmp_path / "db")
+    subprocess.run([hostlib.CLI, "-O", "preprocess", "-i", str(tmp_path / "db.fasta"), "-o", db], check=True, capture_output=True)
+    s = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-q", str(tmp_path / "q.fasta"), "-d", db, "-c", "7", "-b", "128", "-r", "100"],
+                       capture_output=True, text=True)
+    assert s.returncode == 0, s.stderr
+    lines = s.stdout.split("\n")
+    i = next(k for k, l in enumerate(lines) if l.startswith("Search date:"))
+    assert lines[i].startswith("Search date:\t\t\t")
+    assert re.fullmatch(r"Search time:\t\t\t\d+\.\d{6} seconds", lines[i + 1])
+    assert re.fullmatch(r"Search speed:\t\t\t\d+\.\d\d GCUPS", lines[i + 2])
+    assert lines[i + 3:i + 10] == ["CPU threads:\t\t\t7", "CPU vector length:\t\t16", "CPU block width:\t\t128", "Number of FPGAs:\t\t1",
+                                   "FPGA vector length:\t\t16", "FPGA block width:\t\t28", "Max. chunk size in FPGA:\t134217728 bytes"]
+    # -r larger than the database is clipped to the database size (reference FPGAsearch.c:68)
+    assert sum(1 for l in lines if re.match(r"^\d+\tsyn\|", l)) == 64
