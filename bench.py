@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nseq", type=int, default=100000, help="database sequences per GPU")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
@@ -57,6 +57,8 @@ def workload(name):
         return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="C2: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
     if name == "c3":
         return dict(qlens=None, matrix="pam250", go=14, ge=2, label="C3: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, PAM250 14/2, int16 cells")
+    if name == "q1":
+        return dict(qlens=[375], matrix="blosum62", go=10, ge=2, label="Q1: 1 query len 375 (the C1 query) x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
     return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="C5: 1 query len 5000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
 
 

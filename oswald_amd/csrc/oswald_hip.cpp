@@ -204,7 +204,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     }
     const double nwaves = (double)d.grid * (OSW_WG_THREADS / 64);
     const double target_div = getenv("OSWALD_HIP_TARGET_DIV") ? atof(getenv("OSWALD_HIP_TARGET_DIV")) : 3.0;
-    const double target = std::max(total / nwaves / target_div, 1.0e6);
+    const double target = std::max(total / nwaves / target_div, 4.0e4);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
     int force_lg = -1, force_wg = -1;
@@ -234,20 +234,21 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             }
             double cost = item_cost(m, lg, ncols, wg ? ldsr_wg : ldsr);
             if (cost > target) {
-                // too long for one wave's share: widen the geometry (shorter critical path, a little less
-                // efficient); among the candidates take the first that fits, else the cheapest
-                double best = cost;
-                bool bwg = wg;
-                uint32_t blg = lg;
+                // too long for one wave's share: widen the geometry (shorter critical path, somewhat less
+                // efficient).  Among the geometries that fit the target take the one with the least total
+                // work; if none fits, the one with the shortest critical path.
+                double best_fit_work = -1, best_cost = cost;
+                bool fwg = wg, cwg = wg;
+                uint32_t flg = lg, clg = lg;
                 auto consider = [&](bool w, uint32_t k) {
-                    const double ck = item_cost(m, k, ncols, w ? ldsr_wg : ldsr);
-                    if (ck < best) { best = ck; bwg = w; blg = k; }
-                    return ck <= target;
+                    const double ck = item_cost(m, k, ncols, w ? ldsr_wg : ldsr), work = ck * (double)(1u << k);
+                    if (ck <= target && (best_fit_work < 0 || work < best_fit_work)) { best_fit_work = work; fwg = w; flg = k; }
+                    if (ck < best_cost) { best_cost = ck; cwg = w; clg = k; }
                 };
-                bool done = false;
-                if (!wg) for (uint32_t k = lg + 1; k <= lgmax[q] && !done; ++k) done = consider(false, k);
-                if (!i32) for (uint32_t k = std::max(2u, wg ? lg + 1 : 2u); k <= lgmax_wg[q] && !done; ++k) done = consider(true, k);
-                wg = bwg; lg = blg; cost = best;
+                if (!wg) for (uint32_t k = lg + 1; k <= lgmax[q]; ++k) consider(false, k);
+                if (!i32) for (uint32_t k = std::max(2u, wg ? lg + 1 : 2u); k <= lgmax_wg[q]; ++k) consider(true, k);
+                if (best_fit_work >= 0) { wg = fwg; lg = flg; } else { wg = cwg; lg = clg; }
+                cost = item_cost(m, lg, ncols, wg ? ldsr_wg : ldsr);
             }
             if (force_lg >= 0) { lg = (uint32_t)force_lg; wg = false; }
             if (force_wg == 1) { wg = true; if (lg < 2) lg = 2; }
