@@ -64,9 +64,10 @@ struct Chunk {
     uint32_t score_stride = 0;   // nblocks*128
     uint32_t max_ncols4 = 0;     // largest stored extent of a block
     uint64_t total_col4 = 0;     // stored 4-column groups incl. the pad group per block
-    DevBuf tiled, blocks, items, scores, ovf;
+    DevBuf tiled, blocks, items, items_q, scores, ovf;
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
+    uint32_t nitems_q = 0, nitems_q_wg = 0; // the same for the query-pair kernel's queue
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
     int items_bits = 0;                 // cell width it was planned for
     uint32_t max_lg = 0;                // widest geometry in the item list
@@ -78,9 +79,11 @@ struct EventPair { hipEvent_t a, b; };
 struct Device {
     int id = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second queue: the single-query launch runs beside the query-pair launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
-    DevBuf queries, qlen, a_disp, prof_off, prof, submat, bnd, counters, staging_b, staging_n, staging_disp;
+    DevBuf queries, qlen, a_disp, prof_off, prof, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index, wg_times;
     uint64_t bnd_stride = 0;         // uint2 per wave slot
     uint64_t queries_version = ~0ull; // what is currently uploaded
@@ -106,6 +109,10 @@ struct oswald_hip_ctx {
     std::vector<uint16_t> m;
     std::vector<uint32_t> a_disp, prof_off;
     uint32_t nq = 0, total_rowblocks = 0, max_rowblocks = 0;
+    // query batching: pairs of queries of similar length share a lane (CellPK16Q); the rest run alone
+    std::vector<uint32_t> pair_q, pair_off, singles;
+    std::vector<uint16_t> pair_len;
+    uint32_t pair_rowblocks = 0, pair_max_rowblocks = 0;
     uint64_t queries_version = 0;
     bool profiling = false;
 };
@@ -140,69 +147,97 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                      (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
                                      (uint2 *)d.prof.p, d.stream));
+    const uint32_t np = (uint32_t)ctx->pair_len.size();
+    if (np > 0) {
+        HIP_TRY(d.pair_q.reserve(2 * np * sizeof(uint32_t)));
+        HIP_TRY(d.pair_off.reserve(np * sizeof(uint32_t)));
+        HIP_TRY(d.pair_len.reserve(np * sizeof(uint16_t) + 16));
+        HIP_TRY(d.prof_pair.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096));
+        HIP_TRY(hipMemcpyAsync(d.pair_q.p, ctx->pair_q.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(d.pair_off.p, ctx->pair_off.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(d.pair_len.p, ctx->pair_len.data(), np * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(osw_launch_build_pair_profile((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
+                                              (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
+                                              ctx->pair_max_rowblocks, (uint4 *)d.prof_pair.p, d.stream));
+    }
     HIP_TRY(hipStreamSynchronize(d.stream)); // host vectors may change after return
     d.queries_version = ctx->queries_version;
     d.scoring_version = ctx->scoring_version;
     return 0;
 }
 
-// Work queue of a chunk for the current query set.  An item is (query, block,
-// sub-block, geometry G): G = 1 is a whole 128-sequence block on one wave; a
-// heavier item (many strips x many columns) is cut into G sub-blocks of 128/G
-// sequences whose G strips run side by side in the wave, so that no item is
-// longer than a fraction of a wave's fair share of the launch.  The heaviest
-// ones become workgroup items: four sub-blocks on the four waves of a workgroup
-// sharing one 4x larger profile slice (taller rounds at high G).
-// Cost model in VALU issue slots: rounds x (columns + pipeline fill) x (10 per
-// row + ~35 per column).  Heaviest first within each class.
+// Work queues of a chunk for the current query set.  An item is (entity, block, sub-block,
+// geometry G); an entity is a single query (osw_sw_pk16 / osw_sw_i32) or a pair of queries
+// sharing a lane (osw_sw_pk16q).  G = 1 is a whole 128-sequence block on one wave; a heavier
+// item (many strips x many columns) is cut into G sub-blocks of 128/G sequences whose G strips
+// run side by side in the wave, so that no item is longer than a fraction of a wave's fair
+// share of the launch.  The heaviest ones become workgroup items: four sub-blocks on the four
+// waves of a workgroup sharing one 4x larger profile slice (taller rounds at high G).
+// Cost model in VALU issue slots: passes x (columns + pipeline fill) x (9|10 per row + ~35 per
+// column step and round).  Heaviest first within each class.
 int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
 {
     if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0;
-    const uint32_t nq = ctx->nq;
     const bool i32 = ctx->cell_bits == 32;
-    const uint32_t rmax = i32 ? OSW_RMAX32 : OSW_RMAX16, ldsr = i32 ? OSW_LDS_ROWS32 : OSW_LDS_ROWS16;
-    const uint32_t ldsr_wg = ldsr * (OSW_WG_THREADS / 64);
-    auto item_cost = [&](uint32_t m, uint32_t lg, uint32_t ncols, uint32_t lds_rows) {
-        const OswPlan pl = osw_plan(m, 1u << lg, lds_rows, rmax);
+    struct Kind { uint32_t rmax, ldsr; double row_cost, passes; };
+    const Kind kinds[2] = {
+        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16, 10.0, 1.0},
+        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, 9.0, 2.0}};
+    struct Entity { uint32_t m, id, kind; };
+    std::vector<Entity> ents;
+    if (i32) {
+        for (uint32_t q = 0; q < ctx->nq; ++q) ents.push_back({ctx->m[q], q, 0});
+    } else {
+        for (uint32_t q : ctx->singles) ents.push_back({ctx->m[q], q, 0});
+        for (uint32_t k = 0; k < ctx->pair_len.size(); ++k) ents.push_back({ctx->pair_len[k], k, 1});
+    }
+    const uint32_t ne = (uint32_t)ents.size();
+    const uint32_t wgx = OSW_WG_THREADS / 64;
+    auto item_cost = [&](const Entity &e, uint32_t lg, uint32_t ncols, bool wg) {
+        const Kind &kd = kinds[e.kind];
+        const OswPlan pl = osw_plan(e.m, 1u << lg, wg ? kd.ldsr * wgx : kd.ldsr, kd.rmax);
         const double rows = 4.0 * (pl.base * pl.rounds + pl.extra); // rows per lane group over all rounds
-        return (double)(ncols + (1u << lg)) * (10.0 * rows + 35.0 * pl.rounds);
+        return kd.passes * (double)(ncols + (1u << lg)) * (kd.row_cost * rows + 35.0 * pl.rounds);
     };
-    // widest useful geometry per query: strips of >= 8 rows for wave items (per-column
-    // overhead), >= 4 for workgroup items, and no lane group entirely past the query
-    auto lg_limit = [&](uint32_t m, uint32_t lds_rows, uint32_t min_rows) {
+    // widest useful geometry per entity: strips of >= min_rows rows and no lane group entirely past the query
+    auto lg_limit = [&](const Entity &e, bool wg, uint32_t min_rows) {
+        const Kind &kd = kinds[e.kind];
+        const uint32_t lds_rows = wg ? kd.ldsr * wgx : kd.ldsr;
         uint32_t lg = 0;
         while (lg < 6) {
             const uint32_t G2 = 2u << lg;
-            const OswPlan pl = osw_plan(m, G2, lds_rows, rmax);
+            const OswPlan pl = osw_plan(e.m, G2, lds_rows, kd.rmax);
             if (G2 * osw_plan_maxrows(pl) > lds_rows || 4 * pl.base < min_rows || G2 * min_rows > pl.m4) break;
             ++lg;
         }
         return lg;
     };
-    // Default geometry of a query: as many lane groups as it has 32-row strips, so that the
-    // groups hand their bottom rows to each other in registers and (almost) nothing spills to
-    // HBM.  Up to 128 rows that fits a wave's private LDS slice (wave item, one round); longer
-    // queries run as workgroup items with the 4x larger shared slice (G <= 16, 512 rows per round).
+    // Default geometry of an entity: as many lane groups as it has full strips, so that the groups hand
+    // their bottom rows to each other in registers and (almost) nothing spills to HBM.  If that fits a
+    // wave's private LDS slice it is a wave item with one round; longer queries run as workgroup items
+    // with the 4x larger shared slice.
     struct Mode { bool wg; uint32_t lg; };
-    std::vector<Mode> def(nq);
-    std::vector<uint32_t> lgmax(nq), lgmax_wg(nq);
+    std::vector<Mode> def(ne);
+    std::vector<uint32_t> lgmax(ne), lgmax_wg(ne), lg_full_wave(ne);
     double total = 0;
-    for (uint32_t q = 0; q < nq; ++q) {
-        lgmax[q] = lg_limit(ctx->m[q], ldsr, 8);
-        lgmax_wg[q] = i32 ? 0 : lg_limit(ctx->m[q], ldsr_wg, 4);
-        const uint32_t m4 = std::max(4u, (ctx->m[q] + 3u) & ~3u);
+    for (uint32_t k = 0; k < ne; ++k) {
+        const Kind &kd = kinds[ents[k].kind];
+        lgmax[k] = lg_limit(ents[k], false, 8);
+        lgmax_wg[k] = i32 ? 0 : lg_limit(ents[k], true, 4);
+        const uint32_t m4 = std::max(4u, (ents[k].m + 3u) & ~3u);
+        // widest geometries that still run full-height strips (G * rmax rows fit the LDS slice)
+        uint32_t full_wave = 0, full_wg = 0;
+        while ((kd.rmax << (full_wave + 1)) <= kd.ldsr) ++full_wave;
+        while ((kd.rmax << (full_wg + 1)) <= kd.ldsr * wgx) ++full_wg;
+        lg_full_wave[k] = std::min(full_wave, lgmax[k]);
         uint32_t lg = 0;
-        while ((rmax << lg) < m4 && lg < 4) ++lg;         // smallest G with G*rmax >= m4, at most 16
-        if ((rmax << lg) <= ldsr || lgmax_wg[q] < 2) {
-            def[q] = {false, std::min(lg, lgmax[q])};
-            while ((rmax << def[q].lg) > ldsr && def[q].lg > 0) --def[q].lg; // int32 / tiny LDS: stay inside the slice
-        } else {
-            def[q] = {true, std::max(2u, std::min(lg, lgmax_wg[q]))};
-        }
+        while ((kd.rmax << lg) < m4 && lg < full_wg) ++lg; // smallest G with G*rmax >= m4
+        if (lg <= full_wave || lgmax_wg[k] < 2) def[k] = {false, std::min(std::min(lg, full_wave), lgmax[k])};
+        else def[k] = {true, std::max(2u, std::min(lg, lgmax_wg[k]))};
         for (uint32_t b = 0; b < c.nblocks; ++b)
-            total += (double)(1u << def[q].lg) * item_cost(ctx->m[q], def[q].lg, c.ncols4_alloc[b] * 4, def[q].wg ? ldsr_wg : ldsr);
+            total += (double)(1u << def[k].lg) * item_cost(ents[k], def[k].lg, c.ncols4_alloc[b] * 4, def[k].wg);
     }
-    const double nwaves = (double)d.grid * (OSW_WG_THREADS / 64);
+    const double nwaves = (double)d.grid * wgx;
     const double target_div = getenv("OSWALD_HIP_TARGET_DIV") ? atof(getenv("OSWALD_HIP_TARGET_DIV")) : 3.0;
     const double target = std::max(total / nwaves / target_div, 4.0e4);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
@@ -216,23 +251,23 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     if (force_lg > 6) force_lg = 6;
     if (i32) force_wg = 0; // the int32 kernel has no workgroup phase
     struct It { double cost; uint32_t x, b; };
-    std::vector<It> its, its_wg;
-    its.reserve((size_t)nq * c.nblocks + 1024);
+    std::vector<It> its[2], its_wg[2];
     c.max_lg = 0;
-    for (uint32_t q = 0; q < nq; ++q)
+    for (uint32_t k = 0; k < ne; ++k)
         for (uint32_t b = 0; b < c.nblocks; ++b) {
-            const uint32_t ncols = c.ncols4_alloc[b] * 4, m = ctx->m[q];
-            bool wg = def[q].wg;
-            uint32_t lg = def[q].lg;
+            const Entity &e = ents[k];
+            const uint32_t ncols = c.ncols4_alloc[b] * 4;
+            bool wg = def[k].wg;
+            uint32_t lg = def[k].lg;
             if (wg && ncols < wg_min_cols) {
                 // short block: the pipeline fill of a wide geometry (G columns per round) would cost more
-                // than the spill it saves; run as wave items at G = 4
+                // than the spill it saves; run as wave items at the widest full-height geometry (G = 4; 2 for pairs)
                 wg = false;
-                lg = std::min(2u, lgmax[q]);
+                lg = lg_full_wave[k];
             } else if (wg && ncols < wg_wide_cols && lg > 3) {
-                lg = 3; // medium block: 8 groups (256 rows per round)
+                lg = 3; // medium block: 8 groups
             }
-            double cost = item_cost(m, lg, ncols, wg ? ldsr_wg : ldsr);
+            double cost = item_cost(e, lg, ncols, wg);
             if (cost > target) {
                 // too long for one wave's share: widen the geometry (shorter critical path, somewhat less
                 // efficient).  Among the geometries that fit the target take the one with the least total
@@ -240,63 +275,70 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
                 double best_fit_work = -1, best_cost = cost;
                 bool fwg = wg, cwg = wg;
                 uint32_t flg = lg, clg = lg;
-                auto consider = [&](bool w, uint32_t k) {
-                    const double ck = item_cost(m, k, ncols, w ? ldsr_wg : ldsr), work = ck * (double)(1u << k);
-                    if (ck <= target && (best_fit_work < 0 || work < best_fit_work)) { best_fit_work = work; fwg = w; flg = k; }
-                    if (ck < best_cost) { best_cost = ck; cwg = w; clg = k; }
+                auto consider = [&](bool w, uint32_t g2) {
+                    const double ck = item_cost(e, g2, ncols, w), work = ck * (double)(1u << g2);
+                    if (ck <= target && (best_fit_work < 0 || work < best_fit_work)) { best_fit_work = work; fwg = w; flg = g2; }
+                    if (ck < best_cost) { best_cost = ck; cwg = w; clg = g2; }
                 };
-                if (!wg) for (uint32_t k = lg + 1; k <= lgmax[q]; ++k) consider(false, k);
-                if (!i32) for (uint32_t k = std::max(2u, wg ? lg + 1 : 2u); k <= lgmax_wg[q]; ++k) consider(true, k);
+                if (!wg) for (uint32_t g2 = lg + 1; g2 <= lgmax[k]; ++g2) consider(false, g2);
+                if (!i32) for (uint32_t g2 = std::max(2u, wg ? lg + 1 : 2u); g2 <= lgmax_wg[k]; ++g2) consider(true, g2);
                 if (best_fit_work >= 0) { wg = fwg; lg = flg; } else { wg = cwg; lg = clg; }
-                cost = item_cost(m, lg, ncols, wg ? ldsr_wg : ldsr);
             }
             if (force_lg >= 0) { lg = (uint32_t)force_lg; wg = false; }
             if (force_wg == 1) { wg = true; if (lg < 2) lg = 2; }
             if (force_wg == 0) wg = false;
-            if (force_lg >= 0 || force_wg >= 0) cost = item_cost(m, lg, ncols, wg ? ldsr_wg : ldsr);
+            cost = item_cost(e, lg, ncols, wg);
             const uint32_t G = 1u << lg;
             c.max_lg = std::max(c.max_lg, lg);
-            if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
-            else for (uint32_t s = 0; s < G; ++s) its.push_back({cost, OSW_ITEM_PACK(q, s, lg, 3u), b});
+            if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg[e.kind].push_back({cost, OSW_ITEM_PACK(e.id, s, lg, 3u), b});
+            else for (uint32_t s = 0; s < G; ++s) its[e.kind].push_back({cost, OSW_ITEM_PACK(e.id, s, lg, 3u), b});
         }
     auto by_cost = [](const It &x, const It &y) { return x.cost > y.cost; };
-    std::stable_sort(its.begin(), its.end(), by_cost);
-    std::stable_sort(its_wg.begin(), its_wg.end(), by_cost);
     // issue priority of the long items (see set_wave_prio in sw_kernels.hip)
     double planned = 0;
-    for (const It &i : its) planned += i.cost;
-    for (const It &i : its_wg) planned += i.cost * 4;
+    for (int kd = 0; kd < 2; ++kd) {
+        std::stable_sort(its[kd].begin(), its[kd].end(), by_cost);
+        std::stable_sort(its_wg[kd].begin(), its_wg[kd].end(), by_cost);
+        for (const It &i : its[kd]) planned += i.cost;
+        for (const It &i : its_wg[kd]) planned += i.cost * 4;
+    }
     const double fair = planned / nwaves;
     const bool no_prio = getenv("OSWALD_HIP_NO_PRIO") != nullptr;
     auto prio_of = [&](double cost) { return no_prio ? 0u : cost > fair / 2 ? 3u : cost > fair / 4 ? 2u : cost > fair / 8 ? 1u : 0u; };
-    std::vector<uint2> flat;
-    flat.reserve(its.size() + its_wg.size());
-    for (const It &i : its_wg) flat.push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
-    for (const It &i : its) flat.push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
-    c.nitems_wg = (uint32_t)its_wg.size();
-    c.nitems = (uint32_t)its.size();
+    std::vector<uint2> flat[2];
+    for (int kd = 0; kd < 2; ++kd) {
+        flat[kd].reserve(its[kd].size() + its_wg[kd].size());
+        for (const It &i : its_wg[kd]) flat[kd].push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
+        for (const It &i : its[kd]) flat[kd].push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
+    }
+    c.nitems_wg = (uint32_t)its_wg[0].size();
+    c.nitems = (uint32_t)its[0].size();
+    c.nitems_q_wg = (uint32_t)its_wg[1].size();
+    c.nitems_q = (uint32_t)its[1].size();
     if (getenv("OSWALD_HIP_DEBUG")) {
-        double sw = 0, sg = 0;
-        for (const It &i : its) sw += i.cost;
-        for (const It &i : its_wg) sg += i.cost * 4;
-        fprintf(stderr, "[oswald_hip] plan: total %.3g slots, %.0f waves, target %.3g; wave items %zu (sum %.3g, max %.3g), "
-                        "workgroup items %zu (sum %.3g, max %.3g), max lg %u\n",
-                total, nwaves, target, its.size(), sw, its.empty() ? 0.0 : its[0].cost, its_wg.size(), sg,
-                its_wg.empty() ? 0.0 : its_wg[0].cost, c.max_lg);
-        uint32_t hist[2][8] = {{0}};
-        for (const It &i : its) hist[0][OSW_ITEM_LG(i.x)]++;
-        for (const It &i : its_wg) hist[1][OSW_ITEM_LG(i.x)]++;
-        for (int w = 0; w < 2; ++w)
-            for (int k = 0; k < 7; ++k)
-                if (hist[w][k]) fprintf(stderr, "[oswald_hip]   %s lg=%d: %u items\n", w ? "workgroup" : "wave", k, hist[w][k]);
+        fprintf(stderr, "[oswald_hip] plan: %zu single queries, %zu query pairs, total %.3g slots, %.0f waves, target %.3g, max lg %u\n",
+                i32 ? (size_t)ctx->nq : ctx->singles.size(), i32 ? (size_t)0 : ctx->pair_len.size(), total, nwaves, target, c.max_lg);
+        for (int kd = 0; kd < 2; ++kd) {
+            double sw = 0, sg = 0;
+            for (const It &i : its[kd]) sw += i.cost;
+            for (const It &i : its_wg[kd]) sg += i.cost * 4;
+            fprintf(stderr, "[oswald_hip]   %s: wave items %zu (sum %.3g, max %.3g), workgroup items %zu (sum %.3g, max %.3g)\n", kd ? "pairs  " : "singles",
+                    its[kd].size(), sw, its[kd].empty() ? 0.0 : its[kd][0].cost, its_wg[kd].size(), sg, its_wg[kd].empty() ? 0.0 : its_wg[kd][0].cost);
+            uint32_t hist[2][8] = {{0}};
+            for (const It &i : its[kd]) hist[0][OSW_ITEM_LG(i.x)]++;
+            for (const It &i : its_wg[kd]) hist[1][OSW_ITEM_LG(i.x)]++;
+            for (int w = 0; w < 2; ++w)
+                for (int g2 = 0; g2 < 7; ++g2)
+                    if (hist[w][g2]) fprintf(stderr, "[oswald_hip]     %s lg=%d: %u items\n", w ? "workgroup" : "wave", g2, hist[w][g2]);
+        }
     }
-    HIP_TRY(c.items.reserve(flat.size() * sizeof(uint2) + 16));
-    HIP_TRY(c.ovf.reserve((size_t)nq * c.nblocks * 64 * sizeof(uint2) + 16));
-    HIP_TRY(c.scores.reserve((size_t)nq * c.score_stride * sizeof(int32_t) + 16));
-    if (!flat.empty()) {
-        HIP_TRY(hipMemcpyAsync(c.items.p, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipStreamSynchronize(d.stream));
-    }
+    HIP_TRY(c.items.reserve(flat[0].size() * sizeof(uint2) + 16));
+    HIP_TRY(c.items_q.reserve(flat[1].size() * sizeof(uint2) + 16));
+    HIP_TRY(c.ovf.reserve((size_t)ctx->nq * c.nblocks * 128 * sizeof(uint2) + 16));
+    HIP_TRY(c.scores.reserve((size_t)ctx->nq * c.score_stride * sizeof(int32_t) + 16));
+    if (!flat[0].empty()) HIP_TRY(hipMemcpyAsync(c.items.p, flat[0].data(), flat[0].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
+    if (!flat[1].empty()) HIP_TRY(hipMemcpyAsync(c.items_q.p, flat[1].data(), flat[1].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
     c.items_version = ctx->queries_version;
     c.items_bits = ctx->cell_bits;
     return 0;
@@ -349,12 +391,15 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         hipError_t r = hipSetDevice(d.id);
         if (r == hipSuccess) r = hipGetDeviceProperties(&d.prop, d.id);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming);
         int per_cu = 0;
         if (r == hipSuccess) r = (hipError_t)osw_occupancy_pk16(&per_cu);
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "bring-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
         if (per_cu < 1) per_cu = 1;
         d.grid = (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu;
-        r = d.counters.reserve(OSW_CTR_COUNT * sizeof(uint32_t));
+        r = d.counters.reserve((2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
     }
     *out = ctx;
@@ -367,12 +412,15 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
     for (Device &d : ctx->dev) {
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.items.release(); c.scores.release(); c.ovf.release(); }
-        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.submat, &d.bnd, &d.counters, &d.staging_b,
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
+        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
                           &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.wg_times})
             b->release();
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
+        if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
+        if (d.ev_join) (void)hipEventDestroy(d.ev_join);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete ctx;
@@ -436,6 +484,39 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
     ctx->total_rowblocks = off;
     ctx->max_rowblocks = mx;
     ctx->nq = nq;
+    // Pair up queries of similar length (sorted by length, neighbours): a pair costs 9 instructions per
+    // row of the LONGER query for one sequence, two singles 10 per row for two sequences, so pairing pays
+    // when the shorter one is longer than ~0.85 of the longer one.  OSWALD_HIP_PAIRS=0 disables it,
+    // =2 pairs every neighbour (test hook).
+    ctx->pair_q.clear(); ctx->pair_off.clear(); ctx->pair_len.clear(); ctx->singles.clear();
+    ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
+    {
+        int mode = 1;
+        if (const char *e = getenv("OSWALD_HIP_PAIRS")) mode = atoi(e);
+        std::vector<uint32_t> order(nq);
+        for (uint32_t q = 0; q < nq; ++q) order[q] = q;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return m[x] < m[y]; });
+        for (uint32_t k = 0; k < nq;) {
+            bool pair = false;
+            if (mode > 0 && k + 1 < nq) {
+                const double ma = m[order[k]], mb = m[order[k + 1]];
+                pair = mode >= 2 ? mb > 0 : (mb >= 64 && 9.0 * 1.03 * mb < 5.0 * (ma + mb));
+            }
+            if (pair) {
+                const uint32_t mb = m[order[k + 1]], rb = std::max(1u, (mb + 3u) / 4u);
+                ctx->pair_q.push_back(order[k]);
+                ctx->pair_q.push_back(order[k + 1]);
+                ctx->pair_len.push_back((uint16_t)mb);
+                ctx->pair_off.push_back(ctx->pair_rowblocks);
+                ctx->pair_rowblocks += rb;
+                ctx->pair_max_rowblocks = std::max(ctx->pair_max_rowblocks, rb);
+                k += 2;
+            } else {
+                ctx->singles.push_back(order[k]);
+                k += 1;
+            }
+        }
+    }
     ctx->have_queries = true;
     ctx->queries_version++;
     return 0;
@@ -498,7 +579,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     if (stride > d.bnd_stride) {
         const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
         HIP_TRY(hipStreamSynchronize(d.stream));
-        HIP_TRY(d.bnd.reserve(slots * stride * sizeof(uint2)));
+        HIP_TRY(d.bnd.reserve(2 * slots * stride * sizeof(uint2))); // two launches may be in flight side by side
         d.bnd_stride = stride;
     }
     HIP_TRY(hipStreamSynchronize(d.stream)); // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
@@ -518,7 +599,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     HIP_TRY(hipSetDevice(d.id));
     if (int r = sync_queries(ctx, d)) return r;
     if (int r = build_items(ctx, d, c)) return r;
-    if (c.nitems + c.nitems_wg == 0) { c.searched = true; return 0; }
+    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return 0; }
 
     OswSearchArgs a;
     memset(&a, 0, sizeof a);
@@ -537,6 +618,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.scores = (int32_t *)c.scores.p;
     a.score_stride = c.score_stride;
     a.counters = (uint32_t *)d.counters.p;
+    a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
     a.ovf_items = (uint2 *)c.ovf.p;
     const uint32_t goe = (uint32_t)(ctx->open_gap + ctx->extend_gap), ge = (uint32_t)ctx->extend_gap;
     a.goe_pk = goe | (goe << 16);
@@ -557,11 +639,40 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             HIP_TRY(hipEventCreate(&ev.b));
         } else { ev = d.ev_pool.back(); d.ev_pool.pop_back(); }
     }
-    HIP_TRY(hipMemsetAsync(d.counters.p, 0, OSW_CTR_COUNT * sizeof(uint32_t), d.stream));
-    const uint32_t grid = std::min<uint32_t>(d.grid, (c.nitems + 3) / 4 + c.nitems_wg);
+    HIP_TRY(hipMemsetAsync(d.counters.p, 0, (2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
+    const uint32_t grid = std::min<uint32_t>(d.grid, std::max<uint32_t>(1, (c.nitems + 3) / 4 + c.nitems_wg));
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
-    if (ctx->cell_bits == 16) HIP_TRY(osw_launch_pk16(a, grid, d.stream));
-    HIP_TRY(osw_launch_i32(a, grid, d.stream));
+    if (ctx->cell_bits == 16 && c.nitems_q + c.nitems_q_wg > 0) {
+        // query pairs first (the bulk of a multi-query search), on their own queue counters
+        OswSearchArgs aq = a;
+        aq.items = (const uint2 *)c.items_q.p;
+        aq.nitems = c.nitems_q;
+        aq.nitems_wg = c.nitems_q_wg;
+        aq.prof = (const uint2 *)d.prof_pair.p;
+        aq.prof_off = (const uint32_t *)d.pair_off.p;
+        aq.qlen = (const uint16_t *)d.pair_len.p;
+        aq.pair_q = (const uint32_t *)d.pair_q.p;
+        aq.counters = (uint32_t *)d.counters.p + OSW_CTR_COUNT;
+        const uint32_t gq = std::min<uint32_t>(d.grid, (c.nitems_q + 3) / 4 + c.nitems_q_wg);
+        if (c.nitems + c.nitems_wg > 0 && !getenv("OSWALD_HIP_ONE_STREAM")) {
+            // the single-query launch goes to a second stream so that its workgroups fill the slots the
+            // pair launch frees while it drains (both are persistent grids pulling from their own queues)
+            HIP_TRY(hipEventRecord(d.ev_fork, d.stream));
+            HIP_TRY(osw_launch_pk16q(aq, gq, d.stream));
+            HIP_TRY(hipStreamWaitEvent(d.stream2, d.ev_fork, 0));
+            OswSearchArgs a2 = a; // its own half of the spill scratch: the two launches overlap
+            a2.bnd = a.bnd + (size_t)d.grid * (OSW_WG_THREADS / 64) * d.bnd_stride;
+            HIP_TRY(osw_launch_pk16(a2, grid, d.stream2));
+            HIP_TRY(hipEventRecord(d.ev_join, d.stream2));
+            HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_join, 0));
+        } else {
+            HIP_TRY(osw_launch_pk16q(aq, gq, d.stream));
+            if (c.nitems + c.nitems_wg > 0) HIP_TRY(osw_launch_pk16(a, grid, d.stream));
+        }
+    } else if (ctx->cell_bits == 16 && c.nitems + c.nitems_wg > 0) {
+        HIP_TRY(osw_launch_pk16(a, grid, d.stream));
+    }
+    HIP_TRY(osw_launch_i32(a, std::min<uint32_t>(d.grid, 1024u), d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
     if (dbg_times) {
@@ -666,10 +777,10 @@ int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, 
     HIP_TRY(hipStreamSynchronize(d.stream));
     drain_events(d);
     uint32_t ctr[8] = {0};
-    HIP_TRY(hipMemcpy(ctr, d.counters.p, sizeof ctr, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
     if (dp_kernel_ms) *dp_kernel_ms = d.dp_ms;
     if (dp_launches) *dp_launches = d.dp_launches;
-    if (rerun_items) *rerun_items = ctr[OSW_CTR_OVF]; // of the most recent search
+    if (rerun_items) *rerun_items = ctr[0]; // of the most recent search
     if (reset) { d.dp_ms = 0; d.dp_launches = 0; }
     return 0;
 }
@@ -691,7 +802,7 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
     out6[1] = alloc;
     out6[2] = live;
     out6[3] = live * 64 * sizeof(uint2);
-    out6[4] = c.nitems + c.nitems_wg;
+    out6[4] = c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg;
     out6[5] = c.max_lg;
     return 0;
 }

@@ -94,7 +94,9 @@ struct OswSearchArgs {
     uint64_t bnd_stride;       // uint2 per region
     int32_t *scores;           // [nq][score_stride]
     uint32_t score_stride;
-    uint32_t *counters;
+    uint32_t *counters;        // this launch's queue counters (OSW_CTR_*)
+    uint32_t *counters_ovf;    // shared by all launches of a search: [0] = items queued for the int32 kernel
+    const uint32_t *pair_q;    // query-pair kernel: the two queries of pair i (rows of the score table)
     uint2 *ovf_items;
     uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves
     int32_t goe, ge;
@@ -104,6 +106,10 @@ struct OswSearchArgs {
 // host-side launchers, defined in sw_kernels.hip
 hipError_t osw_launch_pk16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
+                                         const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
+                                         uint4 *prof_pair, hipStream_t s);
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint2 *tiled, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,

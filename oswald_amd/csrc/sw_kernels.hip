@@ -105,6 +105,7 @@ struct CellPK16 {
     typedef uint32_t GapT; // (value, value) packed, wave-uniform
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16;
+    static constexpr int kRowBytes = 64; // profile bytes per query row: 32 codes x int16
     static __device__ __forceinline__ T zero() { return (T)(0); }
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
@@ -185,12 +186,82 @@ struct CellPK16 {
     }
 };
 
+// ---------------------------------------------------------------------------
+// Query-pair cell (query batching): the two halves of a register
+// hold two QUERIES of similar length against ONE database sequence per lane
+// (the `half` of the lane's sequence pair; the item runs both halves one after
+// the other).  The pair profile stores (S_A, S_B) already packed, 4 rows x
+// 2 queries = 16 B per residue code, so one ds_read_b128 feeds four rows and
+// the v_perm_b32 disappears: 9 VALU instructions per wave per 128 cells.
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct CellPK16Q {
+    typedef v2s T;
+    typedef uint32_t GapT;
+    static constexpr int kRows = OSW_RMAX16;
+    static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
+    static constexpr int kRowBytes = 128; // 32 codes x 2 queries x int16
+    static __device__ __forceinline__ T zero() { return (T)(0); }
+    static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
+    static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
+    static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
+
+    template <int RB>
+    static __device__ __forceinline__ void ld(uint32_t a, u32x4 &r)
+    {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(a), "i"(RB * 512) : "memory");
+    }
+    template <int Newest>
+    static __device__ __forceinline__ void landed(u32x4 &r)
+    {
+        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
+        else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r));
+    }
+
+    template <int R, int RB>
+    struct Batch {
+        static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &f, T &hl, GapT goe, GapT ge, T &score,
+                                                   u32x4 &r0, u32x4 &r1, u32x4 &r2)
+        {
+            // r0 = this row-block (landed), r1 = next (in flight), r2 = free
+            if constexpr (RB + 2 < R / 4) ld<RB + 2>(a, r2);
+            if constexpr (RB + 1 < R / 4) {
+                if constexpr (RB + 2 < R / 4) landed<1>(r1); else landed<0>(r1);
+            }
+            T s1 = as_v2s(r0.y), s2 = as_v2s(r0.z), s3 = as_v2s(r0.w);
+            OSW_PK16_ROW(x, E[RB * 4 + 0], D[RB * 4 + 1], f, score, s1, ge, goe);
+            OSW_PK16_ROW(x, E[RB * 4 + 1], D[RB * 4 + 2], f, score, s2, ge, goe);
+            OSW_PK16_ROW(x, E[RB * 4 + 2], D[RB * 4 + 3], f, score, s3, ge, goe);
+            if constexpr (RB + 1 < R / 4) {
+                T sn = as_v2s(r1.x);
+                OSW_PK16_ROW(x, E[RB * 4 + 3], D[RB * 4 + 4], f, score, sn, ge, goe);
+                Batch<R, RB + 1>::run(a, D, E, x, f, hl, goe, ge, score, r1, r2, r0);
+            } else {
+                OSW_PK16_ROW_LAST(x, E[RB * 4 + 3], hl, f, score, ge, goe);
+            }
+        }
+    };
+
+    template <int R>
+    static __device__ __forceinline__ void column(lds_u2p lp, uint32_t clo, uint32_t chi, int half, T (&D)[R], T (&E)[R],
+                                                  T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
+    {
+        const uint32_t a = (uint32_t)(uintptr_t)lp + (half ? chi : clo) * 2u; // codes arrive pre-multiplied by 8
+        u32x4 r0, r1, r2;
+        ld<0>(a, r0);
+        if constexpr (R / 4 > 1) { ld<1>(a, r1); landed<1>(r0); } else { landed<0>(r0); }
+        T x = __builtin_elementwise_add_sat(top_prev, as_v2s(r0.x));
+        Batch<R, 0>::run(a, D, E, x, f, hl, goe, ge, score, r0, r1, r2);
+    }
+};
+
 // Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.
 struct CellI32 {
     typedef int T;
     typedef int GapT;
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
+    static constexpr int kRowBytes = 64;
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
@@ -311,14 +382,14 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint2
 // into the wave's LDS region.  Only this wave touches the region; LDS
 // operations of one wave execute in order, the wave barriers only pin the
 // compiler's order.
-static __device__ __forceinline__ void load_profile_round(const uint2 *prof_q, uint32_t rb0, uint32_t nrb, uint32_t rb_end,
-                                                          uint2 *lds_wave, int lane)
+static __device__ __forceinline__ void load_profile_round(const uint4 *prof_q, uint32_t rb0, uint32_t nrb, uint32_t rb_end,
+                                                          uint32_t rb16 /* uint4 per row-block */, uint2 *lds_wave, int lane)
 {
     __builtin_amdgcn_wave_barrier();
-    const uint4 *src = (const uint4 *)(prof_q + (size_t)rb0 * 32);
+    const uint4 *src = prof_q + (size_t)rb0 * rb16;
     uint4 *dst = (uint4 *)lds_wave;
-    const uint32_t n16 = nrb * 16;
-    const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * 16 : 0;
+    const uint32_t n16 = nrb * rb16;
+    const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * rb16 : 0;
     for (uint32_t i = lane; i < n16; i += 64) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -347,23 +418,24 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + sigma * gl + u;
     uint2 *bnd = bnd_wave + u;
     const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
-    const uint2 *prof_q = p.prof + (size_t)p.prof_off[q] * 32;
+    constexpr uint32_t rb16 = C::kRowBytes * 4 / 16; // uint4 per row-block of 4 rows
+    const uint4 *prof_q = (const uint4 *)p.prof + (size_t)p.prof_off[q] * rb16;
     T score = C::zero();
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, nrb = G * R / 4, rb_end = plan.m4 / 4;
         if constexpr (WG) {
             __syncthreads(); // every wave is done with the previous slice
-            const uint4 *src = (const uint4 *)(prof_q + (size_t)rb0 * 32);
+            const uint4 *src = prof_q + (size_t)rb0 * rb16;
             uint4 *dst = (uint4 *)lds_region;
-            const uint32_t n16 = nrb * 16;
-            const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * 16 : 0;
+            const uint32_t n16 = nrb * rb16;
+            const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * rb16 : 0;
             for (uint32_t i = threadIdx.x; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
             __syncthreads();
         } else {
-            load_profile_round(prof_q, rb0, nrb, rb_end, lds_region, lane);
+            load_profile_round(prof_q, rb0, nrb, rb_end, rb16, lds_region, lane);
         }
-        const lds_u2p lp = (lds_u2p)((lds_cp)lds_region + g * R * 64);
+        const lds_u2p lp = (lds_u2p)((lds_cp)lds_region + g * R * C::kRowBytes);
         sw_round_dispatch<C>(R, tb, ncols, lp, bnd, rho == 0, rho + 1 == plan.rounds, G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups
@@ -401,8 +473,31 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
         *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lam) = out;
         const uint32_t hm = (score.x == 32767 ? 1u : 0u) | (score.y == 32767 ? 2u : 0u);
         if (hm) {
-            const uint32_t k = atomicAdd(&p.counters[OSW_CTR_OVF], 1u);
+            const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
+        }
+    }
+}
+
+// Scores of one query-pair item and one sequence half: lane's low half = query A,
+// high half = query B, both against sequence 2*lam + half of the block.
+static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint32_t pair, uint32_t B, const OswBlock &blk, uint32_t sigma,
+                                                    uint32_t lg, int lane, int half, v2s score)
+{
+    const uint32_t gl = 64u >> lg;
+    if ((uint32_t)lane < gl) {
+        const uint32_t lam = sigma * gl + lane;
+        const uint32_t qa = p.pair_q[2 * pair], qb = p.pair_q[2 * pair + 1];
+        const size_t seq = (size_t)blk.seq0 + 2 * lam + half;
+        p.scores[(size_t)qa * p.score_stride + seq] = score.x;
+        p.scores[(size_t)qb * p.score_stride + seq] = score.y;
+        if (score.x == 32767) {
+            const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
+            p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam, 6u, 1u << half), B);
+        }
+        if (score.y == 32767) {
+            const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
+            p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(qb, lam, 6u, 1u << half), B);
         }
     }
 }
@@ -410,7 +505,8 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
 // ---------------------------------------------------------------------------
 // Main kernel: packed int16.
 // ---------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p)
+template <class C, bool PAIR>
+static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8];
     __shared__ uint32_t wg_item;
@@ -452,9 +548,17 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x) + wv, lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        const v2s score = run_item<CellPK16, true>(p, q, blk, sigma, lg, lane, 0, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
-        set_wave_prio(0);
-        pk16_finish(p, q, B, blk, sigma, lg, lane, score);
+        if constexpr (PAIR) {
+            for (int half = 0; half < 2; ++half) {
+                const v2s score = run_item<C, true>(p, q, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
+                pk16q_finish(p, q, B, blk, sigma, lg, lane, half, score);
+            }
+            set_wave_prio(0);
+        } else {
+            const v2s score = run_item<C, true>(p, q, blk, sigma, lg, lane, 0, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
+            set_wave_prio(0);
+            pk16_finish(p, q, B, blk, sigma, lg, lane, score);
+        }
     }
 
     if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -473,12 +577,26 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        const v2s score = run_item<CellPK16, false>(p, q, blk, sigma, lg, lane, 0, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
-        set_wave_prio(0);
-        pk16_finish(p, q, B, blk, sigma, lg, lane, score);
+        if constexpr (PAIR) {
+            for (int half = 0; half < 2; ++half) {
+                const v2s score = run_item<C, false>(p, q, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
+                pk16q_finish(p, q, B, blk, sigma, lg, lane, half, score);
+            }
+            set_wave_prio(0);
+        } else {
+            const v2s score = run_item<C, false>(p, q, blk, sigma, lg, lane, 0, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
+            set_wave_prio(0);
+            pk16_finish(p, q, B, blk, sigma, lg, lane, score);
+        }
     }
     if (p.wg_times && lane == 0) p.wg_times[blockIdx.x * 4 + 2 + (wv & 1)] = __builtin_amdgcn_s_memrealtime(); // waves 0/1 (or 2/3) race: any is fine
 }
+
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16, false>(p); }
+
+// Query pairs: `items` / `qlen` / `prof` / `prof_off` describe pairs (length = the longer query,
+// profile = packed (A, B) scores); pair_q maps a pair to its two query rows of the score table.
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16Q, true>(p); }
 
 // ---------------------------------------------------------------------------
 // Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at
@@ -494,7 +612,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
     uint2 *lds_wave = lds_prof[wv];
     // the queue length was produced by the previous kernel on this stream
-    const uint32_t nitems = p.force_all ? p.nitems : p.counters[OSW_CTR_OVF];
+    const uint32_t nitems = p.force_all ? p.nitems : p.counters_ovf[0];
     const uint2 *items = p.force_all ? p.items + p.nitems_wg : p.ovf_items;
 
     for (;;) {
@@ -607,6 +725,32 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_
     }
 }
 
+// Pair profile: prof_pair[(pair_off[p] + i/4)*32 + code] = 16 B = 4 rows x (S_A, S_B) int16 pairs.
+// Built from the single-query profiles (rows past a query's end are already zero there, and
+// a row-block past its last one reads as zero).
+extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile(const uint2 *__restrict__ prof, const uint32_t *__restrict__ prof_off,
+                                                                          const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ pair_q,
+                                                                          const uint32_t *__restrict__ pair_off, const uint16_t *__restrict__ pair_len,
+                                                                          uint32_t npairs, uint4 *__restrict__ prof_pair)
+{
+    const uint32_t pr = blockIdx.y;
+    if (pr >= npairs) return;
+    const uint32_t qa = pair_q[2 * pr], qb = pair_q[2 * pr + 1];
+    const uint32_t nrb = (pair_len[pr] + 3u) / 4u > 0 ? (pair_len[pr] + 3u) / 4u : 1u;
+    const uint32_t na = (qlen[qa] + 3u) / 4u, nb = (qlen[qb] + 3u) / 4u;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < nrb * 32; e += gridDim.x * blockDim.x) {
+        const uint32_t rb = e >> 5, code = e & 31;
+        const uint2 A = rb < na ? prof[(size_t)(prof_off[qa] + rb) * 32 + code] : make_uint2(0, 0);
+        const uint2 Bv = rb < nb ? prof[(size_t)(prof_off[qb] + rb) * 32 + code] : make_uint2(0, 0);
+        uint4 o;
+        o.x = (A.x & 0xffffu) | (Bv.x << 16);
+        o.y = (A.x >> 16) | (Bv.x & 0xffff0000u);
+        o.z = (A.y & 0xffffu) | (Bv.y << 16);
+        o.w = (A.y >> 16) | (Bv.y & 0xffff0000u);
+        prof_pair[(size_t)(pair_off[pr] + rb) * 32 + code] = o;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Top-r selection with the reference's tie rule (reference host/src/utils.c:
 // 3-86 sorts descending and, on equal scores, puts the LATER database index
@@ -671,6 +815,25 @@ extern "C" __global__ __launch_bounds__(1024) void osw_topr(const int32_t *__res
 hipError_t osw_launch_pk16(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 {
     hipLaunchKernelGGL(osw_sw_pk16, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_pk16q, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
+                                         const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
+                                         uint4 *prof_pair, hipStream_t s)
+{
+    if (npairs == 0) return hipSuccess;
+    uint32_t gx = (max_rowblocks * 32 + 255) / 256;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(osw_build_pair_profile, dim3(gx, npairs), dim3(256), 0, s, prof, prof_off, qlen, pair_q, pair_off, pair_len, npairs, prof_pair);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

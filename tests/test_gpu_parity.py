@@ -268,3 +268,51 @@ def test_max_length_sequence_and_many_queries(hip_ctx, oracle):
     got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 11, 1)
     want = expect(oracle, qs, b, n, disp, 16, sm, 11, 1)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("lg,wg", [(-1, -1), (0, 0), (2, 0), (4, 0), (2, 1), (4, 1), (6, 1)])
+def test_query_pairs(hip_ctx, oracle, lg, wg, monkeypatch):
+    """Query batching: two queries share a lane (osw_sw_pk16q).  OSWALD_HIP_PAIRS=2 pairs every
+    neighbour in length order, however different the lengths, at every geometry."""
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
+    if lg >= 0:
+        monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
+    if wg >= 0:
+        monkeypatch.setenv("OSWALD_HIP_FORCE_WG", str(wg))
+    qs = synth.make_queries([1, 7, 64, 65, 130, 131, 300, 1200, 40], seed=300 + lg)   # 4 pairs + one single
+    L, R, O = random_db(270, seed=310 + lg, max_len=110, queries=qs[4:8], homologs=2)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_query_pairs_overflow_rerun(hip_ctx, oracle, monkeypatch):
+    """Either query of a pair can hit the int16 ceiling on its own."""
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
+    w = synth.ALPHABET.index("W")
+    qa, qb = np.full(3100, w, np.uint8), np.full(2900, w, np.uint8)
+    seqs = [np.full(k, w, np.uint8) for k in (5, 2978, 2979, 3100)] + [synth.random_residues(3, 0, 300)]
+    from helpers import db_from_sequences
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, [qa, qb], b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, [qa, qb], b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want[0].max() == 34100 and want[1].max() == 31900
+
+
+def test_pairing_is_invisible(hip_ctx, oracle, monkeypatch):
+    """Default pairing rule vs. no pairing: identical score tables."""
+    qs = synth.make_queries([90, 100, 310, 330, 500], seed=77)
+    L, R, O = random_db(400, seed=78, max_len=300, queries=qs, homologs=1)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("pam70")
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "0")
+    off = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 12, 3)
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "1")
+    on = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 12, 3)
+    np.testing.assert_array_equal(on, off)
+    np.testing.assert_array_equal(on, expect(oracle, qs, b, n, disp, 16, sm, 12, 3))
