@@ -5,7 +5,7 @@ averages, HBM traffic per launch of the DP kernel)."""
 import csv, glob, json, os, sys
 
 out, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNELS = ("osw_sw_pk16", "osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
+KERNELS = ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
 
 
 def find(sub, pattern):
@@ -20,12 +20,26 @@ if f:
     summary["kernel_stats"] = [{k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
 f = find("stats", "*kernel_trace.csv")
 if f:
-    rows = [r for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "").startswith("osw_sw_pk16")]
-    if rows:
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-        summary["pk16_trace"] = {"launches": len(d), "avg_ms": sum(d) / len(d) / 1e6, "min_ms": min(d) / 1e6, "max_ms": max(d) / 1e6,
-                                 "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"), "lds": rows[0].get("LDS_Block_Size"),
-                                 "grid": rows[0].get("Grid_Size"), "workgroup": rows[0].get("Workgroup_Size")}
+    allrows = list(csv.DictReader(open(f)))
+    def kname(r):
+        return r.get("Kernel_Name", "").split("(")[0].strip()
+    for kn in ("osw_sw_pk16q", "osw_sw_pk16"):
+        rows = [r for r in allrows if kname(r) == kn]
+        if rows:
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+            summary[kn + "_trace"] = {"launches": len(d), "avg_ms": sum(d) / len(d) / 1e6, "min_ms": min(d) / 1e6, "max_ms": max(d) / 1e6,
+                                      "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"), "lds": rows[0].get("LDS_Block_Size")}
+    # one search step = the pair launch and the single-query launch side by side (two streams) + the int32 re-run:
+    # span from the first start to the last end of the k-th dispatches
+    dp = {kn: sorted([r for r in allrows if kname(r) == kn], key=lambda r: int(r["Start_Timestamp"])) for kn in ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32")}
+    nstep = len(dp["osw_sw_i32"])
+    spans = []
+    for k in range(nstep):
+        rs = [dp[kn][k] for kn in dp if len(dp[kn]) == nstep]
+        spans.append(max(int(r["End_Timestamp"]) for r in rs) - min(int(r["Start_Timestamp"]) for r in rs))
+    if spans:
+        summary["dp_step_span"] = {"steps": len(spans), "avg_ms": sum(spans) / len(spans) / 1e6, "min_ms": min(spans) / 1e6, "max_ms": max(spans) / 1e6,
+                                   "what": "osw_sw_pk16q + osw_sw_pk16 (concurrent) + osw_sw_i32 of one search; compare with bench.py roofline.kernel_ms"}
 
 
 def pmc(sub):
@@ -35,7 +49,7 @@ def pmc(sub):
         return res
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        name = next((x for x in KERNELS if k.startswith(x)), None)
+        name = next((x for x in KERNELS if k.split("(")[0].strip() == x), None)
         if not name:
             continue
         c = r["Counter_Name"]
@@ -61,8 +75,10 @@ summary["pmc_fetch"] = pmc("fetch")
 summary["pmc_write"] = pmc("write")
 summary["pmc_sq"] = pmc("sq")
 try:
-    fs = summary["pmc_fetch"]["osw_sw_pk16"]["FETCH_SIZE"]["per_dispatch"]
-    ws = summary["pmc_write"]["osw_sw_pk16"]["WRITE_SIZE"]["per_dispatch"]
+    fs = sum(summary["pmc_fetch"].get(k, {}).get("FETCH_SIZE", {}).get("per_dispatch", 0.0) for k in ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32"))
+    ws = sum(summary["pmc_write"].get(k, {}).get("WRITE_SIZE", {}).get("per_dispatch", 0.0) for k in ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32"))
+    if fs == 0 and ws == 0:
+        raise KeyError("no DP kernel counters")
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts 64 B per
     # 128-B request for wide coalesced reads, other widths must be calibrated on a known byte count in the kernel's own
     # access pattern.  The DP kernel moves 8 B per lane; `ubench calib` reads and writes exactly 1 GiB that way.
