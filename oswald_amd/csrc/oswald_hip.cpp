@@ -259,6 +259,9 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             const uint32_t ncols = c.ncols4_alloc[b] * 4;
             bool wg = def[k].wg;
             uint32_t lg = def[k].lg;
+            // the block's boundary row must fit the wave's spill region: (columns + pad) x lanes per group
+            uint32_t lg_scratch = 0;
+            while (lg_scratch < 6 && ((uint64_t)ncols + OSW_SCRATCH_PAD_COLS) * (64u >> lg_scratch) > d.bnd_stride) ++lg_scratch;
             if (wg && ncols < wg_min_cols) {
                 // short block: the pipeline fill of a wide geometry (G columns per round) would cost more
                 // than the spill it saves; run as wave items at the widest full-height geometry (G = 4; 2 for pairs)
@@ -287,6 +290,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             if (force_lg >= 0) { lg = (uint32_t)force_lg; wg = false; }
             if (force_wg == 1) { wg = true; if (lg < 2) lg = 2; }
             if (force_wg == 0) wg = false;
+            if (lg < lg_scratch) lg = lg_scratch; // any G up to 64 is a valid plan for any query length
             cost = item_cost(e, lg, ncols, wg);
             const uint32_t G = 1u << lg;
             c.max_lg = std::max(c.max_lg, lg);
@@ -334,7 +338,10 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     }
     HIP_TRY(c.items.reserve(flat[0].size() * sizeof(uint2) + 16));
     HIP_TRY(c.items_q.reserve(flat[1].size() * sizeof(uint2) + 16));
-    HIP_TRY(c.ovf.reserve((size_t)ctx->nq * c.nblocks * 128 * sizeof(uint2) + 16));
+    // worst case of the overflow queue: every sequence of every query at the int16 ceiling
+    const size_t ovf_bytes = (size_t)ctx->nq * c.nblocks * 128 * sizeof(uint2) + 16;
+    if (ovf_bytes > (64ull << 30)) return fail(OSWALD_HIP_EINVAL, "%u queries x %u sequence blocks in one chunk need a %zu-byte overflow queue; search in smaller chunks or query sets", ctx->nq, c.nblocks, ovf_bytes);
+    HIP_TRY(c.ovf.reserve(ovf_bytes));
     HIP_TRY(c.scores.reserve((size_t)ctx->nq * c.score_stride * sizeof(int32_t) + 16));
     if (!flat[0].empty()) HIP_TRY(hipMemcpyAsync(c.items.p, flat[0].data(), flat[0].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
     if (!flat[1].empty()) HIP_TRY(hipMemcpyAsync(c.items_q.p, flat[1].data(), flat[1].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
@@ -575,7 +582,8 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint2 *)c.tiled.p, d.stream));
     }
     // strip-boundary scratch: one region per resident wave, sized for the longest block
-    const uint64_t stride = ((uint64_t)c.max_ncols4 * 4 + OSW_SCRATCH_PAD_COLS) * 64; // uint2 per wave slot
+    // {H,F} entries per wave slot: the longest block at G = 1, capped (longer blocks get a wider geometry, build_items)
+    const uint64_t stride = std::min<uint64_t>(((uint64_t)c.max_ncols4 * 4 + OSW_SCRATCH_PAD_COLS) * 64, OSW_SCRATCH_MAX_ENTRIES);
     if (stride > d.bnd_stride) {
         const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
         HIP_TRY(hipStreamSynchronize(d.stream));

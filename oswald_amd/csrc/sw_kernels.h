@@ -13,6 +13,8 @@
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
 #define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
 #define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64)
+#define OSW_SCRATCH_MAX_ENTRIES ((4096u + OSW_SCRATCH_PAD_COLS) * 64u) // cap of a wave's spill region ({H,F} entries, 2.1 MB):
+                                                                      // longer blocks must run at a geometry with fewer lanes per group
 #define OSW_TILED_TAIL_GROUPS 24 // readable 4-column groups past the last block (drain of G <= 64)
 
 // Work item: x = query | sub-block << 16 | log2(G) << 24 | halves << 28 | priority << 30, y = block.

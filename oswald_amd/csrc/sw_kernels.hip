@@ -296,7 +296,7 @@ struct CellI32 {
 // column behind group g-1.
 //   tb   : tiled residues of the lane's sequences (lane-offset applied), [c4*64]
 //   lp   : this lane's profile slice in LDS (wave region + g*R rows)
-//   bnd  : wave scratch, lane-offset u = lane % gl applied, [col*64] = {H, F}
+//   bnd  : wave scratch, lane-offset u = lane % gl applied, [col*gl] = {H, F}
 // ---------------------------------------------------------------------------
 template <class C, int R>
 static __device__ __forceinline__ void sw_round(const uint2 *__restrict__ tb, uint32_t ncols, lds_u2p lp, uint2 *bnd,
@@ -319,13 +319,15 @@ static __device__ __forceinline__ void sw_round(const uint2 *__restrict__ tb, ui
     // two column steps old.  (A rotating queue of registers would have to move the newest, still
     // in-flight entry every step and expose the full memory latency to a wave that runs alone.)
     uint2 bqa = make_uint2(0, 0), bqb = bqa;
-    if (!first) { bqa = bnd[0]; bqb = bnd[64]; } // scratch is padded past the last column
+    // scratch layout [column][gl lanes of a group]: a region of S entries holds S/gl columns, so the
+    // wider the geometry the longer the block it can take (the planner guarantees the fit)
+    if (!first) { bqa = bnd[0]; bqb = bnd[gl]; } // scratch is padded past the last column
     const uint32_t nsteps = ncols + G - 1;
     auto column_step = [&](uint32_t t, uint2 &bq) {
         // inputs of group 0: column t of the stream (dummy residues / zeros once it has ended)
         uint32_t codes = (res.x & 0xffu) | ((res.y & 0xffu) << 8);
         uint32_t topb = bq.x, fb = bq.y;
-        if (!first) bq = bnd[(size_t)(t + 2) * 64];
+        if (!first) bq = bnd[(size_t)(t + 2) * gl];
         if (t >= ncols) { codes = 0x1717u; topb = 0; fb = 0; }
         // every other group takes what the group below produced in the previous step
         if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
@@ -333,7 +335,7 @@ static __device__ __forceinline__ void sw_round(const uint2 *__restrict__ tb, ui
         T f = C::from_bits(fb), hl;
         C::template column<R>(lp, alo, ahi, half, D, E, top_prev, f, hl, goe, ge, score);
         top_prev = C::from_bits(topb);
-        if (!last && t + 1 >= G && glast) bnd[(size_t)(t + 1 - G) * 64] = make_uint2(C::to_bits(hl), C::to_bits(f));
+        if (!last && t + 1 >= G && glast) bnd[(size_t)(t + 1 - G) * gl] = make_uint2(C::to_bits(hl), C::to_bits(f));
         if (G > 1) {
             hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(hl));
             hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(f));
