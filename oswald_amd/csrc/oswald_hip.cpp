@@ -290,7 +290,14 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             if (force_lg >= 0) { lg = (uint32_t)force_lg; wg = false; }
             if (force_wg == 1) { wg = true; if (lg < 2) lg = 2; }
             if (force_wg == 0) wg = false;
-            if (lg < lg_scratch) lg = lg_scratch; // any G up to 64 is a valid plan for any query length
+            if (lg < lg_scratch) lg = lg_scratch;
+            // hard limit of a geometry: G strips of (at least) 4 rows must fit the profile slice in LDS
+            {
+                const Kind &kd = kinds[e.kind];
+                if (!wg && (4u << lg) > kd.ldsr && !i32 && force_wg != 0 && (4u << lg) <= kd.ldsr * wgx && lg >= 2) wg = true;
+                while ((4u << lg) > (wg ? kd.ldsr * wgx : kd.ldsr) && lg > 0) --lg;
+                if (lg < lg_scratch) return fail(OSWALD_HIP_EINVAL, "a sequence block of %u columns does not fit the spill scratch at any geometry", ncols);
+            }
             cost = item_cost(e, lg, ncols, wg);
             const uint32_t G = 1u << lg;
             c.max_lg = std::max(c.max_lg, lg);

@@ -1,0 +1,65 @@
+"""Randomised GPU parity (hypothesis): query sets, database shapes, matrices,
+gap penalties, lane widths and forced wave geometries drawn at random; every
+score must equal the CPU oracle's.  Derandomised so that a failure reproduces."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oswald_amd import submat, synth
+
+from helpers import db_from_sequences, layout, pack_queries
+
+pytestmark = pytest.mark.gpu
+
+
+@st.composite
+def cases(draw):
+    seed = draw(st.integers(0, 2**31 - 1))
+    rng = np.random.default_rng(seed)
+    nq = draw(st.integers(1, 7))
+    qlens = [int(x) for x in rng.integers(1, draw(st.sampled_from([8, 40, 140, 420])) + 1, nq)]
+    nseq = draw(st.integers(1, 280))
+    max_len = draw(st.sampled_from([3, 30, 120, 500]))
+    return dict(seed=seed, qlens=qlens, nseq=nseq, max_len=max_len,
+                matrix=draw(st.sampled_from(submat.NAMES)), go=draw(st.integers(0, 40)), ge=draw(st.integers(0, 12)),
+                W=draw(st.sampled_from([16, 32, 64, 128])), lg=draw(st.sampled_from([-1, -1, 0, 1, 2, 3, 4, 5, 6])),
+                wg=draw(st.sampled_from([-1, -1, 0, 1])), pairs=draw(st.sampled_from([0, 1, 2])), bits=draw(st.sampled_from([16, 16, 16, 32])),
+                homolog=draw(st.booleans()))
+
+
+@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(cases())
+def test_random_cases(hip_ctx, oracle, case):
+    rng = np.random.default_rng(case["seed"])
+    queries = [synth.random_residues(case["seed"] + 11 * i, 0, m) for i, m in enumerate(case["qlens"])]
+    seqs = [rng.integers(0, 24, int(l)).astype(np.uint8) for l in rng.integers(1, case["max_len"] + 1, case["nseq"])]
+    if case["homolog"]:
+        seqs[int(rng.integers(0, len(seqs)))] = queries[-1].copy()
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, case["W"], round_to=int(rng.choice([1, 4, 28])))
+    sm = submat.load(case["matrix"])
+    env = {"OSWALD_HIP_PAIRS": str(case["pairs"])}
+    if case["lg"] >= 0:
+        env["OSWALD_HIP_FORCE_LG"] = str(case["lg"])
+    if case["wg"] >= 0:
+        env["OSWALD_HIP_FORCE_WG"] = str(case["wg"])
+    old = {k: os.environ.get(k) for k in ("OSWALD_HIP_PAIRS", "OSWALD_HIP_FORCE_LG", "OSWALD_HIP_FORCE_WG")}
+    try:
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        a, m, ad = pack_queries(queries)
+        hip_ctx.set_scoring(sm, case["go"], case["ge"], case["bits"])
+        hip_ctx.set_queries(a, m, ad)
+        got = np.full((len(queries), len(n) * case["W"]), -9, np.int32)
+        hip_ctx.search_chunk_async(b, n, disp, got, case["W"])
+        hip_ctx.wait()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    want = oracle.search_chunk_scalar(a, m, ad, b, n, disp, case["W"], sm, case["go"], case["ge"])
+    np.testing.assert_array_equal(got, want, err_msg=str(case))
