@@ -85,7 +85,7 @@ struct Device {
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index, wg_times;
-    uint64_t bnd_stride = 0;         // uint2 per wave slot
+    uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
     uint64_t scoring_version = ~0ull;
     std::vector<Chunk> chunks;
@@ -559,7 +559,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     c.score_stride = c.nblocks * OSW_BLOCK_SEQS;
     c.ncols4_alloc.assign(c.nblocks, 0);
     std::vector<OswBlock> blocks(c.nblocks);
-    uint64_t off = 0;
+    uint64_t off = OSW_TILED_PAD_GROUPS; // all-dummy columns in front of the first block
     c.max_ncols4 = 0;
     for (uint32_t B = 0; B < c.nblocks; ++B) {
         uint32_t mx = 0;
@@ -572,7 +572,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         blocks[B].seq0 = B * OSW_BLOCK_SEQS;
         c.ncols4_alloc[B] = nc4;
         c.max_ncols4 = std::max(c.max_ncols4, nc4);
-        off += (uint64_t)nc4 + 2; // + the two prefetch pad groups
+        off += (uint64_t)nc4 + OSW_TILED_PAD_GROUPS; // + the all-dummy groups the kernels prefetch / drain through
     }
     c.total_col4 = off;
     HIP_TRY(c.tiled.reserve((off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2)));
@@ -585,8 +585,9 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         HIP_TRY(hipMemcpyAsync(d.staging_n.p, n, ngroups * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemcpyAsync(d.staging_disp.p, disp, ngroups * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemcpyAsync(c.blocks.p, blocks.data(), c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemsetAsync(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), d.stream)); // pads = dummy residue
         HIP_TRY(osw_launch_retile((const uint8_t *)d.staging_b.p, (const uint16_t *)d.staging_n.p, (const uint32_t *)d.staging_disp.p,
-                                  ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint2 *)c.tiled.p, d.stream));
+                                  ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, d.stream));
     }
     // strip-boundary scratch: one region per resident wave, sized for the longest block
     // {H,F} entries per wave slot: the longest block at G = 1, capped (longer blocks get a wider geometry, build_items)
@@ -594,7 +595,10 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     if (stride > d.bnd_stride) {
         const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
         HIP_TRY(hipStreamSynchronize(d.stream));
-        HIP_TRY(d.bnd.reserve(2 * slots * stride * sizeof(uint2))); // two launches may be in flight side by side
+        // two launches may be in flight side by side; every region starts with its zero and trash pages
+        const size_t bytes = 2 * slots * (stride + OSW_SCRATCH_DATA) * sizeof(uint2);
+        HIP_TRY(d.bnd.reserve(bytes));
+        HIP_TRY(hipMemsetAsync(d.bnd.p, 0, bytes, d.stream)); // the zero pages are never written again
         d.bnd_stride = stride;
     }
     HIP_TRY(hipStreamSynchronize(d.stream)); // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
@@ -618,7 +622,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
 
     OswSearchArgs a;
     memset(&a, 0, sizeof a);
-    a.tiled = (const uint2 *)c.tiled.p;
+    a.tiled = (const uint16_t *)c.tiled.p;
     a.blocks = (const OswBlock *)c.blocks.p;
     a.items = (const uint2 *)c.items.p;
     a.nitems = c.nitems;
@@ -629,7 +633,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.prof_off = (const uint32_t *)d.prof_off.p;
     a.qlen = (const uint16_t *)d.qlen.p;
     a.bnd = (uint2 *)d.bnd.p;
-    a.bnd_stride = d.bnd_stride;
+    a.bnd_stride = d.bnd_stride + OSW_SCRATCH_DATA;
     a.scores = (int32_t *)c.scores.p;
     a.score_stride = c.score_stride;
     a.counters = (uint32_t *)d.counters.p;
@@ -676,7 +680,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             HIP_TRY(osw_launch_pk16q(aq, gq, d.stream));
             HIP_TRY(hipStreamWaitEvent(d.stream2, d.ev_fork, 0));
             OswSearchArgs a2 = a; // its own half of the spill scratch: the two launches overlap
-            a2.bnd = a.bnd + (size_t)d.grid * (OSW_WG_THREADS / 64) * d.bnd_stride;
+            a2.bnd = a.bnd + (size_t)d.grid * (OSW_WG_THREADS / 64) * a.bnd_stride;
             HIP_TRY(osw_launch_pk16(a2, grid, d.stream2));
             HIP_TRY(hipEventRecord(d.ev_join, d.stream2));
             HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_join, 0));

@@ -12,10 +12,17 @@
 #define OSW_LDS_ROWS16 128   // profile rows a wave keeps in LDS per round (8 KB), packed int16 kernel
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
 #define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
-#define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64)
-#define OSW_SCRATCH_MAX_ENTRIES ((4096u + OSW_SCRATCH_PAD_COLS) * 64u) // cap of a wave's spill region ({H,F} entries, 2.1 MB):
+#define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64), kept zero
+#define OSW_SCRATCH_MAX_ENTRIES ((4096u + OSW_SCRATCH_PAD_COLS) * 64u) // cap of a wave's spill columns ({H,F} entries, 2.1 MB):
                                                                       // longer blocks must run at a geometry with fewer lanes per group
-#define OSW_TILED_TAIL_GROUPS 24 // readable 4-column groups past the last block (drain of G <= 64)
+// A wave's spill region: 64 entries that stay zero (the "row above" of a first round), 64 entries
+// that absorb the stores of steps / rounds that have nothing to spill, then the columns.
+#define OSW_SCRATCH_ZERO 0
+#define OSW_SCRATCH_TRASH 64
+#define OSW_SCRATCH_DATA 128
+#define OSW_TILED_PAD_GROUPS 18  // all-dummy 4-column groups stored after every block (prefetch + drain of G <= 64: 66 columns)
+#define OSW_TILED_TAIL_GROUPS 2  // readable groups past the last block
+#define OSW_DUMMY_CODE8 0xB8u    // residue code 23 (dummy), pre-multiplied by 8 as stored in `tiled`
 
 // Work item: x = query | sub-block << 16 | log2(G) << 24 | halves << 28 | priority << 30, y = block.
 // G = lane groups of the wave geometry; sub-block = which 64/G lanes (sequence
@@ -73,7 +80,9 @@ static __host__ __device__ inline uint32_t osw_plan_maxrows(const OswPlan &p) { 
 #define OSW_CTR_COUNT (OSW_CTR_CU0 + OSW_CTR_CUS)
 
 // One wave block of the re-tiled chunk: 128 consecutive sequences of the
-// (length-sorted) chunk, stored column-major in groups of 4 columns.
+// (length-sorted) chunk, stored column-major: tiled[col*64 + lane] = uint16 {8*residue of
+// sequence 2*lane, 8*residue of sequence 2*lane+1} (8*code = the byte offset of the code's
+// profile entry); allocation is counted in groups of 4 columns (512 B).
 struct OswBlock {
     uint32_t col4_off;      // first 4-column group of the block in `tiled`
     uint32_t ncols4_alloc;  // groups stored (from the caller's padded lengths)
@@ -82,7 +91,7 @@ struct OswBlock {
 };
 
 struct OswSearchArgs {
-    const uint2 *tiled;        // [col4][64 lanes] {4 residues seq 2l, 4 residues seq 2l+1}
+    const uint16_t *tiled;     // [col][64 lanes] {8*residue of seq 2l, 8*residue of seq 2l+1}
     const OswBlock *blocks;
     const uint2 *items;        // work queue, heaviest first: nitems_wg workgroup items, then nitems wave items
     uint32_t nitems;
@@ -93,7 +102,7 @@ struct OswSearchArgs {
     const uint32_t *prof_off;
     const uint16_t *qlen;
     uint2 *bnd;                // strip-boundary spill {H,F} per column and lane, one region per resident wave
-    uint64_t bnd_stride;       // uint2 per region
+    uint64_t bnd_stride;       // uint2 per region (OSW_SCRATCH_DATA + columns x lanes per group)
     int32_t *scores;           // [nq][score_stride]
     uint32_t score_stride;
     uint32_t *counters;        // this launch's queue counters (OSW_CTR_*)
@@ -113,7 +122,7 @@ hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          uint4 *prof_pair, hipStream_t s);
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
-                             OswBlock *blocks, uint32_t nblocks, uint2 *tiled, hipStream_t s);
+                             OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
                                     const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint2 *prof, hipStream_t s);
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,

@@ -57,6 +57,38 @@ static __device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_
 static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
 
 // ---------------------------------------------------------------------------
+// Input registers of a column step.  H and F of the row above and the residues
+// of the column live in two alternating register sets (even / odd column):
+//   H, F : written for ALL lanes by the ds_bpermute hand-off at the end of the
+//          previous step (lane groups 1.. take the bottom row of the group
+//          below; the lanes of group 0 receive junk),
+//   LH,LF: for the lanes of group 0, the boundary row of the previous round,
+//          LOADED from the spill scratch two columns ahead; merged into H / F
+//          with one EXEC-masked v_mov each,
+//   C    : the residues, loaded two columns ahead by every lane itself (group g
+//          is g columns behind, so its lanes read g columns further back).
+// A register with a load in flight must not be touched by anything else, and
+// the compiler cannot know about loads issued from inline asm: it would be
+// free to copy such a register (reading it too early) or to park a temporary
+// in it.  The sets are therefore FIXED physical registers that never appear as
+// asm operands; every asm statement of the packed-int16 kernels names them as
+// clobbers, so the compiler keeps no value in them, and they are read and
+// written by name inside the asm text only.  tests/test_isa_inflight.py checks
+// the generated ISA: no compiler-scheduled instruction touches them.
+// ---------------------------------------------------------------------------
+#define OSW_VH0 "v118"
+#define OSW_VF0 "v119"
+#define OSW_VC0 "v120"
+#define OSW_VLH0 "v121"
+#define OSW_VLF0 "v122"
+#define OSW_VH1 "v123"
+#define OSW_VF1 "v124"
+#define OSW_VC1 "v125"
+#define OSW_VLH1 "v126"
+#define OSW_VLF1 "v127"
+#define OSW_INFLIGHT "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
+// ---------------------------------------------------------------------------
 // Packed-int16 cell, hand-scheduled.  State per row r: E[r] and D[r] =
 // H(i0+r-1, j-1), the diagonal input of row r (D[0] is only a name: the top
 // input comes from the strip above).  The cell of row r is 9 VOP3P
@@ -64,45 +96,63 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // overwrites D[r+1] with its own H, so every state register is updated in
 // place (no copies), and every result is consumed at a distance of >= 2 issue
 // slots, which is what gfx950 needs between a packed-math write and a dependent
-// VALU read (no s_nop inside the cell).
+// VALU read (no s_nop inside the cell).  F runs down the column in the F
+// register of the step's input set (FREG), where the next strip picks it up.
 //   x   in: D[r] + S[r]          out: D[r+1] + S[r+1]
 //   Dn  in: D[r+1] (old column)  out: H(i0+r, j)  (= D[r+1] of the next column)
 // ---------------------------------------------------------------------------
-#define OSW_PK16_ROW(x, Er, Dn, f, sc, s_next, ge, goe)                                      \
+#define OSW_PK16_ROW(FREG, x, Er, Dn, sc, s_next, ge, goe)                                   \
     do {                                                                                     \
         v2s tmp_;                                                                            \
         asm volatile("v_pk_max_i16 %[tmp], %[x_], %[E_]\n\t"                                 \
                      "v_pk_add_i16 %[x_], %[Dn_], %[sn_] clamp\n\t"                          \
                      "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
-                     "v_pk_max_i16 %[Dn_], %[tmp], %[f_]\n\t"                                \
-                     "v_pk_sub_u16 %[f_], %[f_], %[ge_] clamp\n\t"                           \
+                     "v_pk_max_i16 %[Dn_], %[tmp], " FREG "\n\t"                             \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
                      "v_pk_sub_u16 %[tmp], %[Dn_], %[goe_] clamp\n\t"                        \
                      "v_pk_max_i16 %[sc_], %[sc_], %[Dn_]\n\t"                               \
                      "v_pk_max_i16 %[E_], %[E_], %[tmp]\n\t"                                 \
-                     "v_pk_max_i16 %[f_], %[f_], %[tmp]"                                     \
-                     : [tmp] "=&v"(tmp_), [x_] "+v"(x), [E_] "+v"(Er), [Dn_] "+v"(Dn), [f_] "+v"(f), [sc_] "+v"(sc) \
-                     : [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe));                   \
+                     "v_pk_max_i16 " FREG ", " FREG ", %[tmp]"                               \
+                     : [tmp] "=&v"(tmp_), [x_] "+v"(x), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
+                     : [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe)                     \
+                     : OSW_INFLIGHT);                                                        \
     } while (0)
 
 // last row of the strip: its H goes to `hl` (handed to the next strip)
-#define OSW_PK16_ROW_LAST(x, Er, hl, f, sc, ge, goe)                                         \
+#define OSW_PK16_ROW_LAST(FREG, x, Er, hl, sc, ge, goe)                                      \
     do {                                                                                     \
         v2s tmp_;                                                                            \
         asm volatile("v_pk_max_i16 %[tmp], %[x_], %[E_]\n\t"                                 \
                      "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
-                     "v_pk_max_i16 %[hl_], %[tmp], %[f_]\n\t"                                \
-                     "v_pk_sub_u16 %[f_], %[f_], %[ge_] clamp\n\t"                           \
+                     "v_pk_max_i16 %[hl_], %[tmp], " FREG "\n\t"                             \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
                      "v_pk_sub_u16 %[tmp], %[hl_], %[goe_] clamp\n\t"                        \
                      "v_pk_max_i16 %[sc_], %[sc_], %[hl_]\n\t"                               \
                      "v_pk_max_i16 %[E_], %[E_], %[tmp]\n\t"                                 \
-                     "v_pk_max_i16 %[f_], %[f_], %[tmp]"                                     \
-                     : [tmp] "=&v"(tmp_), [hl_] "=&v"(hl), [E_] "+v"(Er), [f_] "+v"(f), [sc_] "+v"(sc) \
-                     : [x_] "v"(x), [ge_] "s"(ge), [goe_] "s"(goe));                         \
+                     "v_pk_max_i16 " FREG ", " FREG ", %[tmp]"                               \
+                     : [tmp] "=&v"(tmp_), [hl_] "=&v"(hl), [E_] "+v"(Er), [sc_] "+v"(sc)     \
+                     : [x_] "v"(x), [ge_] "s"(ge), [goe_] "s"(goe)                           \
+                     : OSW_INFLIGHT);                                                        \
     } while (0)
+
+// the two row forms on input set P (0: even column, 1: odd column)
+template <int P>
+static __device__ __forceinline__ void pk16_row(v2s &x, v2s &Er, v2s &Dn, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe)
+{
+    if constexpr (P == 0) OSW_PK16_ROW(OSW_VF0, x, Er, Dn, sc, s_next, ge, goe);
+    else OSW_PK16_ROW(OSW_VF1, x, Er, Dn, sc, s_next, ge, goe);
+}
+template <int P>
+static __device__ __forceinline__ void pk16_row_last(v2s x, v2s &Er, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe)
+{
+    if constexpr (P == 0) OSW_PK16_ROW_LAST(OSW_VF0, x, Er, hl, sc, ge, goe);
+    else OSW_PK16_ROW_LAST(OSW_VF1, x, Er, hl, sc, ge, goe);
+}
 
 struct CellPK16 {
     typedef v2s T;
     typedef uint32_t GapT; // (value, value) packed, wave-uniform
+    static constexpr bool kFast = true;
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16;
     static constexpr int kRowBytes = 64; // profile bytes per query row: 32 codes x int16
@@ -128,13 +178,13 @@ struct CellPK16 {
                      "ds_read_b64 %1, %3 offset:%4"
                      : "=&v"(r.lo), "=&v"(r.hi)
                      : "v"(a_lo), "v"(a_hi), "i"(RB * 256)
-                     : "memory");
+                     : "memory", OSW_INFLIGHT);
     }
     template <int Newest>
     static __device__ __forceinline__ void landed(Raw &r)
     {
-        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.lo), "+v"(r.hi));
-        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r.lo), "+v"(r.hi));
+        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.lo), "+v"(r.hi)::OSW_INFLIGHT);
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r.lo), "+v"(r.hi)::OSW_INFLIGHT);
     }
     static __device__ __forceinline__ void pair_up(const Raw &r, T (&s)[4])
     {
@@ -144,10 +194,10 @@ struct CellPK16 {
         s[3] = as_v2s(__builtin_amdgcn_perm(r.hi.y, r.lo.y, 0x07060302u));
     }
 
-    template <int R, int RB>
+    template <int R, int RB, int P>
     struct Batch {
         // s = scores of this row-block (paired), r1 = raw next block (in flight or landed), r2 = free
-        static __device__ __forceinline__ void run(uint32_t a_lo, uint32_t a_hi, T (&D)[R], T (&E)[R], T &x, T &f, T &hl, GapT goe, GapT ge,
+        static __device__ __forceinline__ void run(uint32_t a_lo, uint32_t a_hi, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge,
                                                    T &score, T (&s)[4], Raw &r1, Raw &r2)
         {
             T sn[4];
@@ -156,33 +206,43 @@ struct CellPK16 {
                 if constexpr (RB + 2 < R / 4) landed<2>(r1); else landed<0>(r1);
                 pair_up(r1, sn);
             }
-            OSW_PK16_ROW(x, E[RB * 4 + 0], D[RB * 4 + 1], f, score, s[1], ge, goe);
-            OSW_PK16_ROW(x, E[RB * 4 + 1], D[RB * 4 + 2], f, score, s[2], ge, goe);
-            OSW_PK16_ROW(x, E[RB * 4 + 2], D[RB * 4 + 3], f, score, s[3], ge, goe);
+            pk16_row<P>(x, E[RB * 4 + 0], D[RB * 4 + 1], score, s[1], ge, goe);
+            pk16_row<P>(x, E[RB * 4 + 1], D[RB * 4 + 2], score, s[2], ge, goe);
+            pk16_row<P>(x, E[RB * 4 + 2], D[RB * 4 + 3], score, s[3], ge, goe);
             if constexpr (RB + 1 < R / 4) {
-                OSW_PK16_ROW(x, E[RB * 4 + 3], D[RB * 4 + 4], f, score, sn[0], ge, goe);
-                Batch<R, RB + 1>::run(a_lo, a_hi, D, E, x, f, hl, goe, ge, score, sn, r2, r1);
+                pk16_row<P>(x, E[RB * 4 + 3], D[RB * 4 + 4], score, sn[0], ge, goe);
+                Batch<R, RB + 1, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, sn, r2, r1);
             } else {
-                OSW_PK16_ROW_LAST(x, E[RB * 4 + 3], hl, f, score, ge, goe);
+                pk16_row_last<P>(x, E[RB * 4 + 3], hl, score, ge, goe);
             }
         }
     };
 
-    // One database column against the R rows of the strip.
-    //   top_prev = H(i0-1, j-1); f in: F(i0, j), out: F(i0+R, j); hl = H(i0+R-1, j)
-    template <int R>
-    static __device__ __forceinline__ void column(lds_u2p lp, uint32_t alo, uint32_t ahi, int /*half*/, T (&D)[R], T (&E)[R],
-                                                  T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
+    // One database column against the R rows of the strip, inputs in register set P:
+    //   residues {8*code of the lane's first sequence, 8*code of the second} in bytes 0 / 1 of
+    //   the set's C register (8*code = byte offset of the code's profile entry), F(i0, j) in its
+    //   F register (out: F(i0+R, j)).  base = LDS byte address of the lane's profile slice;
+    //   top_prev = H(i0-1, j-1); hl = H(i0+R-1, j).
+    template <int R, int P>
+    static __device__ __forceinline__ void column(uint32_t base, int /*half*/, T (&D)[R], T (&E)[R], T top_prev, T &hl, GapT goe, GapT ge,
+                                                  T &score)
     {
-        const uint32_t base = (uint32_t)(uintptr_t)lp;
-        const uint32_t a_lo = base + alo, a_hi = base + ahi;
+        uint32_t a_lo, a_hi;
+        if constexpr (P == 0)
+            asm volatile("v_add_u32_sdwa %0, %2, " OSW_VC0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                         "v_add_u32_sdwa %1, %2, " OSW_VC0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+                         : "=&v"(a_lo), "=&v"(a_hi) : "v"(base) : OSW_INFLIGHT);
+        else
+            asm volatile("v_add_u32_sdwa %0, %2, " OSW_VC1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                         "v_add_u32_sdwa %1, %2, " OSW_VC1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+                         : "=&v"(a_lo), "=&v"(a_hi) : "v"(base) : OSW_INFLIGHT);
         Raw r0, r1, r2;
         T s[4];
         ld<0>(a_lo, a_hi, r0);
         if constexpr (R / 4 > 1) { ld<1>(a_lo, a_hi, r1); landed<2>(r0); } else { landed<0>(r0); }
         pair_up(r0, s);
         T x = __builtin_elementwise_add_sat(top_prev, s[0]);
-        Batch<R, 0>::run(a_lo, a_hi, D, E, x, f, hl, goe, ge, score, s, r1, r2);
+        Batch<R, 0, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, s, r1, r2);
     }
 };
 
@@ -198,6 +258,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct CellPK16Q {
     typedef v2s T;
     typedef uint32_t GapT;
+    static constexpr bool kFast = true;
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
     static constexpr int kRowBytes = 128; // 32 codes x 2 queries x int16
@@ -209,18 +270,18 @@ struct CellPK16Q {
     template <int RB>
     static __device__ __forceinline__ void ld(uint32_t a, u32x4 &r)
     {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(a), "i"(RB * 512) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(a), "i"(RB * 512) : "memory", OSW_INFLIGHT);
     }
     template <int Newest>
     static __device__ __forceinline__ void landed(u32x4 &r)
     {
-        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
-        else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r));
+        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)::OSW_INFLIGHT);
+        else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r)::OSW_INFLIGHT);
     }
 
-    template <int R, int RB>
+    template <int R, int RB, int P>
     struct Batch {
-        static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &f, T &hl, GapT goe, GapT ge, T &score,
+        static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge, T &score,
                                                    u32x4 &r0, u32x4 &r1, u32x4 &r2)
         {
             // r0 = this row-block (landed), r1 = next (in flight), r2 = free
@@ -229,36 +290,48 @@ struct CellPK16Q {
                 if constexpr (RB + 2 < R / 4) landed<1>(r1); else landed<0>(r1);
             }
             T s1 = as_v2s(r0.y), s2 = as_v2s(r0.z), s3 = as_v2s(r0.w);
-            OSW_PK16_ROW(x, E[RB * 4 + 0], D[RB * 4 + 1], f, score, s1, ge, goe);
-            OSW_PK16_ROW(x, E[RB * 4 + 1], D[RB * 4 + 2], f, score, s2, ge, goe);
-            OSW_PK16_ROW(x, E[RB * 4 + 2], D[RB * 4 + 3], f, score, s3, ge, goe);
+            pk16_row<P>(x, E[RB * 4 + 0], D[RB * 4 + 1], score, s1, ge, goe);
+            pk16_row<P>(x, E[RB * 4 + 1], D[RB * 4 + 2], score, s2, ge, goe);
+            pk16_row<P>(x, E[RB * 4 + 2], D[RB * 4 + 3], score, s3, ge, goe);
             if constexpr (RB + 1 < R / 4) {
                 T sn = as_v2s(r1.x);
-                OSW_PK16_ROW(x, E[RB * 4 + 3], D[RB * 4 + 4], f, score, sn, ge, goe);
-                Batch<R, RB + 1>::run(a, D, E, x, f, hl, goe, ge, score, r1, r2, r0);
+                pk16_row<P>(x, E[RB * 4 + 3], D[RB * 4 + 4], score, sn, ge, goe);
+                Batch<R, RB + 1, P>::run(a, D, E, x, hl, goe, ge, score, r1, r2, r0);
             } else {
-                OSW_PK16_ROW_LAST(x, E[RB * 4 + 3], hl, f, score, ge, goe);
+                pk16_row_last<P>(x, E[RB * 4 + 3], hl, score, ge, goe);
             }
         }
     };
 
-    template <int R>
-    static __device__ __forceinline__ void column(lds_u2p lp, uint32_t clo, uint32_t chi, int half, T (&D)[R], T (&E)[R],
-                                                  T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
+    template <int R, int P>
+    static __device__ __forceinline__ void column(uint32_t base, int half, T (&D)[R], T (&E)[R], T top_prev, T &hl, GapT goe, GapT ge,
+                                                  T &score)
     {
-        const uint32_t a = (uint32_t)(uintptr_t)lp + (half ? chi : clo) * 2u; // codes arrive pre-multiplied by 8
+        // profile entry of the lane's residue: 16 B per code = 2 x (8*code)
+        uint32_t a;
+        const uint32_t sh = (uint32_t)half * 8u;
+        if constexpr (P == 0)
+            asm volatile("v_bfe_u32 %0, " OSW_VC0 ", %2, 8\n\t"
+                         "v_lshl_add_u32 %0, %0, 1, %1"
+                         : "=&v"(a) : "v"(base), "s"(sh) : OSW_INFLIGHT);
+        else
+            asm volatile("v_bfe_u32 %0, " OSW_VC1 ", %2, 8\n\t"
+                         "v_lshl_add_u32 %0, %0, 1, %1"
+                         : "=&v"(a) : "v"(base), "s"(sh) : OSW_INFLIGHT);
         u32x4 r0, r1, r2;
         ld<0>(a, r0);
         if constexpr (R / 4 > 1) { ld<1>(a, r1); landed<1>(r0); } else { landed<0>(r0); }
         T x = __builtin_elementwise_add_sat(top_prev, as_v2s(r0.x));
-        Batch<R, 0>::run(a, D, E, x, f, hl, goe, ge, score, r0, r1, r2);
+        Batch<R, 0, P>::run(a, D, E, x, hl, goe, ge, score, r0, r1, r2);
     }
 };
 
 // Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.
+// Compiler-scheduled throughout (rare path: re-run of saturated lanes).
 struct CellI32 {
     typedef int T;
     typedef int GapT;
+    static constexpr bool kFast = false;
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
     static constexpr int kRowBytes = 64;
@@ -268,14 +341,14 @@ struct CellI32 {
     static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
 
     template <int R>
-    static __device__ __forceinline__ void column(lds_u2p lp, uint32_t alo, uint32_t ahi, int half, T (&D)[R], T (&E)[R],
+    static __device__ __forceinline__ void column(uint32_t base, uint32_t codes, int half, T (&D)[R], T (&E)[R],
                                                   T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
     {
-        const uint32_t a = half ? ahi : alo;
+        const lds_cp lp = (lds_cp)(uintptr_t)(base + ((codes >> (half * 8)) & 0xffu));
         T diag = top_prev;
 #pragma unroll
         for (int rb = 0; rb < R / 4; ++rb) {
-            const u32x2 p = *(lds_u2p)((lds_cp)lp + a + rb * 256);
+            const u32x2 p = *(lds_u2p)(lp + rb * 256);
             const int s[4] = {(int)(short)(p.x & 0xffffu), (int)p.x >> 16, (int)(short)(p.y & 0xffffu), (int)p.y >> 16};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -291,92 +364,212 @@ struct CellI32 {
     }
 };
 
+static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ---------------------------------------------------------------------------
 // One round: G lane groups, group g runs R rows of strip (round*G + g), one
 // column behind group g-1.
-//   tb   : tiled residues of the lane's sequences (lane-offset applied), [c4*64]
-//   lp   : this lane's profile slice in LDS (wave region + g*R rows)
-//   bnd  : wave scratch, lane-offset u = lane % gl applied, [col*gl] = {H, F}
+//   tcol : the block's residues at this sub-block, column 0 (wave-uniform)
+//   u    : lane's index inside its group (its sequence pair of the sub-block)
+//   base : LDS byte address of this lane's profile slice (wave region + g*R rows)
+//   bnd  : wave's scratch region (wave-uniform), layout [column][gl lanes of a
+//          group] behind the zero and trash pages (OSW_SCRATCH_*)
+//
+// Packed-int16 version.  All vector-memory instructions of the loop are inline
+// asm and their waits are counted by hand.  A step issues, in this order:
+// 2 stores (bottom row {H, F} of the last group; into the trash page while
+// there is nothing to spill, so that the count never changes) and 3 loads for
+// the next-but-one column (LH, LF: lanes of group 0; C: all lanes).  A step
+// therefore starts with vmcnt <= 5: everything older than the 5 operations of
+// the previous step has landed.  No memory instruction is ever issued with an
+// empty EXEC mask.  A first round reads its (all-zero) row above from the zero
+// page with a zero stride; the columns read past the block's end (prefetch,
+// drain steps of the lane groups) are zero in the scratch, and `tiled` holds
+// dummy residues before and after every block (warm-up / drain of the groups).
+// Per column on top of the cells: 2 VALU (LDS addresses) + 1 (first diagonal
+// add) + 1 (top_prev) + 2 (group 0 merges); the rest is SALU, LDS and VMEM.
 // ---------------------------------------------------------------------------
+#define OSW_STEP_BEGIN_ASM(FP, LFP)                                                                          \
+    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\t"                                                         \
+                 "s_mov_b64 %[sv], exec\n\t"                                                                 \
+                 "s_mov_b64 exec, %[mg0]\n\t"                                                                \
+                 "v_mov_b32 " FP ", " LFP "\n\t"                                                             \
+                 "s_mov_b64 exec, %[sv]"                                                                     \
+                 : [sv] "=&s"(sv)                                                                            \
+                 : [mg0] "s"(m_g0)                                                                           \
+                 : "memory", OSW_INFLIGHT)
+
+#define OSW_STEP_END_ASM(HP, FP, CP, LHP, LFP, HQ, FQ)                                                       \
+    asm volatile("v_mov_b32 %[tp], " HP "\n\t"                                                               \
+                 "s_mov_b64 %[sv], exec\n\t"                                                                 \
+                 "s_mov_b64 exec, %[mg0]\n\t"                                                                \
+                 "v_mov_b32 %[tp], " LHP "\n\t"                                                              \
+                 "s_mov_b64 exec, %[mbp]\n\t"                                                                \
+                 "s_cbranch_execz 1f\n\t"                                                                    \
+                 "s_mov_b64 exec, %[sv]\n\t"                                                                 \
+                 "ds_bpermute_b32 " HQ ", %[src], %[ho]\n\t"                                                 \
+                 "ds_bpermute_b32 " FQ ", %[src], " FP "\n"                                                  \
+                 "1:\n\t"                                                                                    \
+                 "s_mov_b64 exec, %[mst]\n\t"                                                                \
+                 "global_store_dword %[voff], %[ho], %[sptr]\n\t"                                            \
+                 "global_store_dword %[voff], " FP ", %[sptr] offset:4\n\t"                                  \
+                 "s_mov_b64 exec, %[mg0]\n\t"                                                                \
+                 "global_load_dword " LHP ", %[voff], %[lptr]\n\t"                                           \
+                 "global_load_dword " LFP ", %[voff], %[lptr] offset:4\n\t"                                  \
+                 "s_mov_b64 exec, %[sv]\n\t"                                                                 \
+                 "global_load_ushort " CP ", %[voffc], %[tptr]"                                              \
+                 : [tp] "=&v"(tp), [sv] "=&s"(sv)                                                            \
+                 : [src] "v"(src), [ho] "v"(ho), [voff] "v"(voff), [voffc] "v"(voffc), [mbp] "s"(m_bp), [mst] "s"(m_st), \
+                   [mg0] "s"(m_g0), [sptr] "s"(sptr), [lptr] "s"(lptr), [tptr] "s"(tptr)                      \
+                 : "memory", OSW_INFLIGHT)
+
 template <class C, int R>
-static __device__ __forceinline__ void sw_round(const uint2 *__restrict__ tb, uint32_t ncols, lds_u2p lp, uint2 *bnd,
-                                                bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
-                                                typename C::GapT goe, typename C::GapT ge, typename C::T &score)
+static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
+                                                     bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
+                                                     typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
     typedef typename C::T T;
     T D[R], E[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { D[r] = C::zero(); E[r] = C::zero(); }
     T top_prev = C::zero(); // H(i0-1, j-1)
+    const uint64_t m_g0 = gl >= 64 ? ~0ull : (1ull << gl) - 1ull; // lanes of group 0
+    const uint64_t m_bp = ~m_g0;                                   // lanes that are handed their inputs (empty: no hand-off)
+    const uint64_t m_st = ~0ull << (64u - gl);                     // lanes of the last group
+    const uint32_t src = (uint32_t)((lane - (int)gl) & 63) << 2;   // ds_bpermute source: the lane one group below
+    const uint32_t g = (uint32_t)lane / gl;
+    // group g reads its residues g columns behind group 0: the pointer runs G-1 columns behind,
+    // the lanes' offsets make up for it (columns before the block are the dummy pad in front of it)
+    const uint32_t voff = u * 8u, voffc = u * 2u + (G - 1u - g) * 128u;
+    // a last round stores into the trash page; so do the G-1 warm-up steps in which the last group is
+    // still before column 0 (the store pointer starts G-1 columns before the data: inside the trash page)
+    const uint64_t data = (uint64_t)(bnd + OSW_SCRATCH_DATA);
+    const uint32_t lstep = first ? 0u : gl * 8u, sstep = last ? 0u : gl * 8u;
+    uint64_t lptr = first ? (uint64_t)(bnd + OSW_SCRATCH_ZERO) : data;
+    uint64_t sptr = last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u;
+    uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * 128u;
+    uint64_t sv;
+    // nothing has been handed over yet: zeros; columns 0 and 1 of the stream
+    asm volatile("v_mov_b32 " OSW_VH0 ", 0\n\t"
+                 "v_mov_b32 " OSW_VF0 ", 0\n\t"
+                 "v_mov_b32 " OSW_VH1 ", 0\n\t"
+                 "v_mov_b32 " OSW_VF1 ", 0\n\t"
+                 "global_load_ushort " OSW_VC0 ", %[voffc], %[tptr]\n\t"
+                 "global_load_ushort " OSW_VC1 ", %[voffc], %[tptr] offset:128\n\t"
+                 "s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[mg0]\n\t"
+                 "global_load_dword " OSW_VLH0 ", %[voff], %[lptr]\n\t"
+                 "global_load_dword " OSW_VLF0 ", %[voff], %[lptr] offset:4\n\t"
+                 "global_load_dword " OSW_VLH1 ", %[voff], %[lptr2]\n\t"
+                 "global_load_dword " OSW_VLF1 ", %[voff], %[lptr2] offset:4\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : [sv] "=&s"(sv)
+                 : [voff] "v"(voff), [voffc] "v"(voffc), [mg0] "s"(m_g0), [lptr] "s"(lptr), [lptr2] "s"(lptr + lstep), [tptr] "s"(tptr)
+                 : "memory", OSW_INFLIGHT);
+    lptr += 2 * lstep;
+    tptr += 256;
+    const uint32_t nsteps = ncols + G - 1;
+#pragma unroll 1
+    for (uint32_t t = 0; t < nsteps; t += 2) {
+        {
+            OSW_STEP_BEGIN_ASM(OSW_VF0, OSW_VLF0);
+            T hl, tp;
+            C::template column<R, 0>(base, half, D, E, top_prev, hl, goe, ge, score);
+            const uint32_t ho = C::to_bits(hl);
+            OSW_STEP_END_ASM(OSW_VH0, OSW_VF0, OSW_VC0, OSW_VLH0, OSW_VLF0, OSW_VH1, OSW_VF1);
+            top_prev = tp;
+            sptr += sstep;
+            lptr += lstep;
+            tptr += 128;
+        }
+        if (t + 1 < nsteps) {
+            OSW_STEP_BEGIN_ASM(OSW_VF1, OSW_VLF1);
+            T hl, tp;
+            C::template column<R, 1>(base, half, D, E, top_prev, hl, goe, ge, score);
+            const uint32_t ho = C::to_bits(hl);
+            OSW_STEP_END_ASM(OSW_VH1, OSW_VF1, OSW_VC1, OSW_VLH1, OSW_VLF1, OSW_VH0, OSW_VF0);
+            top_prev = tp;
+            sptr += sstep;
+            lptr += lstep;
+            tptr += 128;
+        }
+    }
+    // the prefetches of the two columns past the end are still in flight
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", OSW_INFLIGHT);
+}
+
+// Compiler-scheduled version of the same round (int32 cell).
+template <class C, int R>
+static __device__ __forceinline__ void sw_round_plain(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
+                                                      bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
+                                                      typename C::GapT goe, typename C::GapT ge, typename C::T &score)
+{
+    typedef typename C::T T;
+    T D[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { D[r] = C::zero(); E[r] = C::zero(); }
+    T top_prev = C::zero();
     const bool g0 = (uint32_t)lane < gl;
     const bool glast = (uint32_t)lane >= 64u - gl;
-    const int src = ((lane - (int)gl) & 63) << 2; // ds_bpermute source: the lane one group below
-    uint32_t hand_h = 0, hand_f = 0, hand_c = 0x1717u;
-    uint2 res = tb[0], res_n = tb[64];
-    // Boundary values {H, F} of the previous round are fetched two columns ahead into two
-    // alternating register pairs (the loop body is instantiated for even and odd columns): a value
-    // is never copied while its load is in flight, so the loop only ever waits for a load that is
-    // two column steps old.  (A rotating queue of registers would have to move the newest, still
-    // in-flight entry every step and expose the full memory latency to a wave that runs alone.)
-    uint2 bqa = make_uint2(0, 0), bqb = bqa;
-    // scratch layout [column][gl lanes of a group]: a region of S entries holds S/gl columns, so the
-    // wider the geometry the longer the block it can take (the planner guarantees the fit)
-    if (!first) { bqa = bnd[0]; bqb = bnd[gl]; } // scratch is padded past the last column
+    const int src = ((lane - (int)gl) & 63) << 2;
+    const uint16_t *tb = tcol + u;
+    uint2 *col = bnd + OSW_SCRATCH_DATA + u;
+    const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
+    uint32_t hand_h = 0, hand_f = 0, hand_c = dummy;
     const uint32_t nsteps = ncols + G - 1;
-    auto column_step = [&](uint32_t t, uint2 &bq) {
-        // inputs of group 0: column t of the stream (dummy residues / zeros once it has ended)
-        uint32_t codes = (res.x & 0xffu) | ((res.y & 0xffu) << 8);
-        uint32_t topb = bq.x, fb = bq.y;
-        if (!first) bq = bnd[(size_t)(t + 2) * gl];
-        if (t >= ncols) { codes = 0x1717u; topb = 0; fb = 0; }
-        // every other group takes what the group below produced in the previous step
+#pragma unroll 1
+    for (uint32_t t = 0; t < nsteps; ++t) {
+        uint32_t codes = dummy, topb = 0, fb = 0;
+        if (t < ncols) {
+            codes = tb[(size_t)t * 64];
+            if (!first) { const uint2 b = col[(size_t)t * gl]; topb = b.x; fb = b.y; }
+        }
         if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
-        const uint32_t alo = (codes & 31u) * 8u, ahi = ((codes >> 8) & 31u) * 8u;
         T f = C::from_bits(fb), hl;
-        C::template column<R>(lp, alo, ahi, half, D, E, top_prev, f, hl, goe, ge, score);
+        C::template column<R>(base, codes, half, D, E, top_prev, f, hl, goe, ge, score);
         top_prev = C::from_bits(topb);
-        if (!last && t + 1 >= G && glast) bnd[(size_t)(t + 1 - G) * gl] = make_uint2(C::to_bits(hl), C::to_bits(f));
+        if (!last && t + 1 >= G && glast) col[(size_t)(t + 1 - G) * gl] = make_uint2(C::to_bits(hl), C::to_bits(f));
         if (G > 1) {
             hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(hl));
             hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(f));
             hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
         }
-        res.x >>= 8;
-        res.y >>= 8;
-        if ((t & 3u) == 3u) {
-            res = res_n;
-            res_n = tb[(size_t)((t >> 2) + 2) * 64]; // tiled is padded at its end
-        }
-    };
-#pragma unroll 1
-    for (uint32_t t = 0; t < nsteps; t += 2) {
-        column_step(t, bqa);
-        if (t + 1 < nsteps) column_step(t + 1, bqb);
     }
 }
 
 template <class C>
-static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint2 *tb, uint32_t ncols, lds_u2p lp, uint2 *bnd,
+static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
                                                          bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
                                                          typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
+#define OSW_ROUND_CASE(RR)                                                                                                      \
+    case RR:                                                                                                                    \
+        if constexpr (C::kFast) sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, first, last, G, gl, lane, half, goe, ge, score); \
+        else sw_round_plain<C, RR>(tcol, u, ncols, base, bnd, first, last, G, gl, lane, half, goe, ge, score);                  \
+        break
     switch (R) {
-    case 4: sw_round<C, 4>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
-    case 8: sw_round<C, 8>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
-    case 12: sw_round<C, 12>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
-    case 16: sw_round<C, 16>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+        OSW_ROUND_CASE(4);
+        OSW_ROUND_CASE(8);
+        OSW_ROUND_CASE(12);
+        OSW_ROUND_CASE(16);
     default:
         if constexpr (C::kRows > 16) {
             switch (R) {
-            case 20: sw_round<C, 20>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
-            case 24: sw_round<C, 24>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
-            case 28: sw_round<C, 28>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
-            case 32: sw_round<C, 32>(tb, ncols, lp, bnd, first, last, G, gl, lane, half, goe, ge, score); break;
+                OSW_ROUND_CASE(20);
+                OSW_ROUND_CASE(24);
+                OSW_ROUND_CASE(28);
+                OSW_ROUND_CASE(32);
             default: break;
             }
         }
         break;
     }
+#undef OSW_ROUND_CASE
 }
 
 // Copy the round's profile slice (nrb row-blocks of 256 B from row-block rb0;
@@ -417,11 +610,17 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     const uint32_t G = 1u << lg, gl = 64u >> lg;
     const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
     const uint32_t ncols = __builtin_amdgcn_readfirstlane(blk.ncols4) * 4;
-    const uint2 *tb = p.tiled + (size_t)blk.col4_off * 64 + sigma * gl + u;
-    uint2 *bnd = bnd_wave + u;
+    const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
+    uint2 *bnd = (uint2 *)osw_uniform64((uint64_t)bnd_wave);
     const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
     constexpr uint32_t rb16 = C::kRowBytes * 4 / 16; // uint4 per row-block of 4 rows
     const uint4 *prof_q = (const uint4 *)p.prof + (size_t)p.prof_off[q] * rb16;
+    if (plan.rounds > 1) {
+        // the scratch columns the prefetch and the drain steps read past the block's last one are the
+        // row above of dummy columns: zero (other items, at other geometries, have written here)
+        uint2 *pad = bnd + OSW_SCRATCH_DATA + (size_t)ncols * gl;
+        for (uint32_t k = lane; k < (G + 2u) * gl; k += 64) pad[k] = make_uint2(0, 0);
+    }
     T score = C::zero();
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
@@ -437,8 +636,8 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         } else {
             load_profile_round(prof_q, rb0, nrb, rb_end, rb16, lds_region, lane);
         }
-        const lds_u2p lp = (lds_u2p)((lds_cp)lds_region + g * R * C::kRowBytes);
-        sw_round_dispatch<C>(R, tb, ncols, lp, bnd, rho == 0, rho + 1 == plan.rounds, G, gl, lane, half, goe, ge, score);
+        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * R * C::kRowBytes);
+        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, rho == 0, rho + 1 == plan.rounds, G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups
     for (uint32_t off = gl; off < 64; off <<= 1)
@@ -642,12 +841,15 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
 
 // Re-tile the reference's W-lane interleaved groups (a4: b[disp_g + j*W + l],
 // reference host/src/sequences.c:479-498) into 128-sequence wave blocks:
-// tiled[(col4_off + c4)*64 + lane] = { 4 residues of seq 2*lane, 4 residues of
-// seq 2*lane+1 }.  Missing groups / columns past a group's length read as the
-// dummy residue 23, exactly the reference's padding value.
+// tiled[(col4_off*4 + j)*64 + lane] = uint16 {8*residue j of seq 2*lane, 8*residue j of
+// seq 2*lane+1}.  Missing groups / columns past a group's length read as the
+// dummy residue 23, exactly the reference's padding value.  The buffer is
+// pre-filled with the dummy residue: OSW_TILED_PAD_GROUPS all-dummy groups lie
+// in front of the first block and behind every block (the columns the lane
+// groups of the search kernels warm up, prefetch and drain through).
 extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
                                                               const uint32_t *__restrict__ disp, uint32_t ngroups, uint32_t W,
-                                                              const OswBlock *__restrict__ blocks, uint2 *__restrict__ tiled)
+                                                              const OswBlock *__restrict__ blocks, uint16_t *__restrict__ tiled)
 {
     const uint32_t B = blockIdx.x;
     const OswBlock blk = blocks[B];
@@ -658,36 +860,32 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__re
     const bool have = g < ngroups;
     const uint32_t ng = have ? n[g] : 0;
     const uint8_t *src = b + (have ? disp[g] : 0) + l;
-    // two extra (all-dummy) groups past the end: the search kernels prefetch them
-    for (uint32_t c4 = wv; c4 < blk.ncols4_alloc + 2; c4 += 4) {
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t j = c4 * 4 + k;
-            uint32_t r0 = 23, r1 = 23;
-            if (j < ng && c4 < blk.ncols4_alloc) {
-                r0 = src[(size_t)j * W];
-                r1 = src[(size_t)j * W + 1];
-            }
-            lo |= r0 << (8 * k);
-            hi |= r1 << (8 * k);
+    const uint32_t ncols = blk.ncols4_alloc * 4;
+    for (uint32_t j = wv; j < ncols; j += 4) {
+        uint32_t r0 = 23, r1 = 23;
+        if (j < ng) {
+            r0 = src[(size_t)j * W];
+            r1 = src[(size_t)j * W + 1];
         }
-        tiled[(size_t)(blk.col4_off + c4) * 64 + lane] = make_uint2(lo, hi);
+        // codes >= 32 cannot come from the reference's preprocessing (0..23); keep the offset inside the entry row
+        tiled[((size_t)blk.col4_off * 4 + j) * 64 + lane] = (uint16_t)(((r0 & 31u) * 8u) | (((r1 & 31u) * 8u) << 8));
     }
 }
 
 // Trailing columns in which every sequence of the block holds the dummy
 // residue score 0 against everything (reference submat.c: column 23 is zero)
 // and therefore cannot raise any maximum: drop them from the block's extent.
-extern "C" __global__ __launch_bounds__(64) void osw_block_extent(OswBlock *blocks, const uint2 *__restrict__ tiled)
+extern "C" __global__ __launch_bounds__(64) void osw_block_extent(OswBlock *blocks, const uint16_t *__restrict__ tiled)
 {
     const uint32_t B = blockIdx.x;
     const int lane = threadIdx.x;
     const OswBlock blk = blocks[B];
+    const uint16_t dummy = (uint16_t)(OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8));
     uint32_t c4 = blk.ncols4_alloc;
     while (c4 > 0) {
-        const uint2 v = tiled[(size_t)(blk.col4_off + c4 - 1) * 64 + lane];
-        const bool live = (v.x != 0x17171717u) | (v.y != 0x17171717u);
+        bool live = false;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) live |= tiled[((size_t)(blk.col4_off + c4 - 1) * 4 + k) * 64 + lane] != dummy;
         if (__any(live)) break;
         --c4;
     }
@@ -848,12 +1046,12 @@ hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 }
 
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
-                             OswBlock *blocks, uint32_t nblocks, uint2 *tiled, hipStream_t s)
+                             OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL(osw_retile, dim3(nblocks), dim3(256), 0, s, b, n, disp, ngroups, W, (const OswBlock *)blocks, tiled);
     OSW_LAUNCH_CHECK();
-    hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(64), 0, s, blocks, (const uint2 *)tiled);
+    hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(64), 0, s, blocks, (const uint16_t *)tiled);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }
