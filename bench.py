@@ -11,7 +11,9 @@ query profile) are resident in HBM before the timed region starts.
 
 Workload at N = 1: BASELINE.json configs[1] -- 20 queries of length 100..1000
 (sum 11 000) against a 100k-sequence synthetic length-binned database
-(~36.5 M residues), BLOSUM62, gap 10/2, packed-int16 cells.  For N > 1 every
+(~36.5 M residues), BLOSUM62, gap 10/2; first pass in packed fp16 (exact below
+2048), sequences that reach it re-run in int32 (--cell-bits 16: packed int16
+first pass).  For N > 1 every
 rank holds its own 100k-sequence shard (weak scaling; shards are chunk-sharded
 parts of an N x 100k-sequence database, no data-path collective).
 
@@ -35,8 +37,12 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9                 # max clock (MI355X_MICROARCH.md)
 N_CU = 256
 SIMD_PER_CU = 4
-PK_ISSUE_CYCLES = 4.0            # packed-int16 VOP3P: one wave instruction per 4 cycles per SIMD (tools/ubench.hip, measured 4.2-4.4)
-PK_OPS_PER_128CELLS = 10         # VALU instructions per wave per column row: 9 VOP3P + 1 v_perm_b32 for 64 lanes x 2 cells
+PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (tools/ubench.hip, measured 4.2-4.5)
+# VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
+# lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
+PK_OPS_PER_ROW = {11: (8.5, 7.5), 16: (10.0, 9.0), 32: (24.0, 24.0)}
+DTYPE = {11: "f16", 16: "int16", 32: "int32"}
+CELL_LABEL = {11: "packed fp16 first pass (exact < 2048) + int32 re-run", 16: "packed int16 first pass + int32 re-run", 32: "int32 cells"}
 
 
 def parse():
@@ -47,6 +53,8 @@ def parse():
     ap.add_argument("--nseq", type=int, default=100000, help="database sequences per GPU")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
+    ap.add_argument("--cell-bits", type=int, default=0, choices=[0, 11, 16, 32],
+                    help="first-pass arithmetic of the library: 11 = packed fp16 (default), 16 = packed int16, 32 = int32 only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
     return ap.parse_args()
@@ -54,12 +62,12 @@ def parse():
 
 def workload(name):
     if name == "c2":
-        return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="C2: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
+        return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="C2: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2")
     if name == "c3":
-        return dict(qlens=None, matrix="pam250", go=14, ge=2, label="C3: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, PAM250 14/2, int16 cells")
+        return dict(qlens=None, matrix="pam250", go=14, ge=2, label="C3: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, PAM250 14/2")
     if name == "q1":
-        return dict(qlens=[375], matrix="blosum62", go=10, ge=2, label="Q1: 1 query len 375 (the C1 query) x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
-    return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="C5: 1 query len 5000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2, int16 cells")
+        return dict(qlens=[375], matrix="blosum62", go=10, ge=2, label="Q1: 1 query len 375 (the C1 query) x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2")
+    return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="C5: 1 query len 5000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2")
 
 
 def main():
@@ -109,7 +117,8 @@ def main():
     t_gen = time.time() - t0
 
     ctx = capi.Context(1, [gpu])
-    ctx.set_scoring(sm, wl["go"], wl["ge"], 16)
+    cell_bits = args.cell_bits or int(os.environ.get("OSWALD_HIP_CELL_BITS", "11"))
+    ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
     ctx.set_queries(a, m, a_disp)
     if b.size >= 2**32:
         raise SystemExit("shard too large for one chunk")
@@ -160,21 +169,24 @@ def main():
         kern_s = kern_ms / max(1, kern_launches) / 1e3
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         kern_gcups = sum_m * d_local / kern_s / 1e9 if kern_s > 0 else 0.0
-        valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / PK_OPS_PER_128CELLS / 1e9
+        ops_row = PK_OPS_PER_ROW[cell_bits][1 if nq > 1 else 0]  # a multi-query search runs (mostly) as query pairs
+        valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / ops_row / 1e9
+        kname = {11: "osw_sw_f16q+osw_sw_f16(+osw_sw_i32)", 16: "osw_sw_pk16q+osw_sw_pk16(+osw_sw_i32)", 32: "osw_sw_i32"}[cell_bits]
         traffic = measured_traffic(args.workload, args.nseq)
         result = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16", "data": "synthetic",
-            "config": {"workload": wl["label"].format(nseq=args.nseq), "queries": nq, "query_residues": sum_m, "db_sequences_per_gpu": args.nseq,
+            "dtype": DTYPE[cell_bits], "data": "synthetic",
+            "config": {"workload": wl["label"].format(nseq=args.nseq) + ", " + CELL_LABEL[cell_bits], "queries": nq, "query_residues": sum_m, "db_sequences_per_gpu": args.nseq,
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
                        "top": args.top, "sharding": f"db-shard x{world}, {'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "osw_sw_pk16(+osw_sw_i32)", "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
+                         "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
-                                  "note": "integer DP is VALU-issue bound: 10 VALU instructions per wave per 128 cells, packed-int16 issues every 4 cycles per SIMD"}},
+                                  "instr_per_128_cells": ops_row,
+                                  "note": "the DP is VALU-issue bound: instr_per_128_cells VALU instructions per wave per query row (query-pair cell for a multi-query search), one packed 16-bit instruction per 4 cycles per SIMD"}},
             "rerun_items_int32": int(rerun), "work_items": int(ctx.chunk_geometry(chunk)["work_items"]), "max_log2_geometry": int(ctx.chunk_geometry(chunk)["max_log2_geometry"]), "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
             "setup_s": round(t_gen, 1),
         }

@@ -111,7 +111,7 @@ class Context:
         _chk(self.lib.oswald_hip_info(self.h, dev, buf, len(buf)))
         return buf.value.decode()
 
-    def set_scoring(self, submat: np.ndarray, open_gap: int, extend_gap: int, cell_bits: int = 16):
+    def set_scoring(self, submat: np.ndarray, open_gap: int, extend_gap: int, cell_bits: int = 0):
         sm = np.ascontiguousarray(submat, dtype=np.int8).reshape(-1)
         assert sm.size == 24 * 32
         _chk(self.lib.oswald_hip_set_scoring(self.h, _ptr(sm), open_gap, extend_gap, cell_bits))

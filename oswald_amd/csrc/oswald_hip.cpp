@@ -83,7 +83,7 @@ struct Device {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
-    DevBuf queries, qlen, a_disp, prof_off, prof, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
+    DevBuf queries, qlen, a_disp, prof_off, prof, prof_f16, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index, wg_times;
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
@@ -144,9 +144,17 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     HIP_TRY(hipMemcpyAsync(d.a_disp.p, ctx->a_disp.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.prof_off.p, ctx->prof_off.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.submat.p, ctx->submat, 24 * 32, hipMemcpyHostToDevice, d.stream));
+    // integer profile: the int16 first pass and the exact int32 kernel
     HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                      (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                     (uint2 *)d.prof.p, d.stream));
+                                     0u, (uint2 *)d.prof.p, d.stream));
+    const bool f16 = ctx->cell_bits == 11;
+    if (f16) { // the same scores as fp16 for the packed-fp16 first pass
+        HIP_TRY(d.prof_f16.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
+        HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
+                                         (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
+                                         1u, (uint2 *)d.prof_f16.p, d.stream));
+    }
     const uint32_t np = (uint32_t)ctx->pair_len.size();
     if (np > 0) {
         HIP_TRY(d.pair_q.reserve(2 * np * sizeof(uint32_t)));
@@ -156,9 +164,15 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
         HIP_TRY(hipMemcpyAsync(d.pair_q.p, ctx->pair_q.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemcpyAsync(d.pair_off.p, ctx->pair_off.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemcpyAsync(d.pair_len.p, ctx->pair_len.data(), np * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(osw_launch_build_pair_profile((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
+        HIP_TRY(osw_launch_build_pair_profile((const uint2 *)(f16 ? d.prof_f16.p : d.prof.p), (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                               (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
                                               ctx->pair_max_rowblocks, (uint4 *)d.prof_pair.p, d.stream));
+        if (f16) { // int16 pair profile for the items the fp16 kernel redoes
+            HIP_TRY(d.prof_pair_i16.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096));
+            HIP_TRY(osw_launch_build_pair_profile((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
+                                                  (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
+                                                  ctx->pair_max_rowblocks, (uint4 *)d.prof_pair_i16.p, d.stream));
+        }
     }
     HIP_TRY(hipStreamSynchronize(d.stream)); // host vectors may change after return
     d.queries_version = ctx->queries_version;
@@ -173,16 +187,17 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
 // run side by side in the wave, so that no item is longer than a fraction of a wave's fair
 // share of the launch.  The heaviest ones become workgroup items: four sub-blocks on the four
 // waves of a workgroup sharing one 4x larger profile slice (taller rounds at high G).
-// Cost model in VALU issue slots: passes x (columns + pipeline fill) x (9|10 per row + ~35 per
+// Cost model in VALU issue slots: passes x (columns + pipeline fill) x (9|10 per row + ~10 per
 // column step and round).  Heaviest first within each class.
 int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
 {
     if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0;
     const bool i32 = ctx->cell_bits == 32;
     struct Kind { uint32_t rmax, ldsr; double row_cost, passes; };
+    const bool f16 = ctx->cell_bits == 11; // 7.5 instead of 9 instructions per row (+1 for the sequence-pair cell)
     const Kind kinds[2] = {
-        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16, 10.0, 1.0},
-        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, 9.0, 2.0}};
+        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16, f16 ? 8.5 : 10.0, 1.0},
+        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, f16 ? 7.5 : 9.0, 2.0}};
     struct Entity { uint32_t m, id, kind; };
     std::vector<Entity> ents;
     if (i32) {
@@ -193,11 +208,12 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     }
     const uint32_t ne = (uint32_t)ents.size();
     const uint32_t wgx = OSW_WG_THREADS / 64;
+    const double col_cost = getenv("OSWALD_HIP_COL_COST") ? atof(getenv("OSWALD_HIP_COL_COST")) : 10.0; // issue slots per column step besides the cells
     auto item_cost = [&](const Entity &e, uint32_t lg, uint32_t ncols, bool wg) {
         const Kind &kd = kinds[e.kind];
         const OswPlan pl = osw_plan(e.m, 1u << lg, wg ? kd.ldsr * wgx : kd.ldsr, kd.rmax);
         const double rows = 4.0 * (pl.base * pl.rounds + pl.extra); // rows per lane group over all rounds
-        return kd.passes * (double)(ncols + (1u << lg)) * (kd.row_cost * rows + 35.0 * pl.rounds);
+        return kd.passes * (double)(ncols + (1u << lg)) * (kd.row_cost * rows + col_cost * pl.rounds);
     };
     // widest useful geometry per entity: strips of >= min_rows rows and no lane group entirely past the query
     auto lg_limit = [&](const Entity &e, bool wg, uint32_t min_rows) {
@@ -238,7 +254,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             total += (double)(1u << def[k].lg) * item_cost(ents[k], def[k].lg, c.ncols4_alloc[b] * 4, def[k].wg);
     }
     const double nwaves = (double)d.grid * wgx;
-    const double target_div = getenv("OSWALD_HIP_TARGET_DIV") ? atof(getenv("OSWALD_HIP_TARGET_DIV")) : 3.0;
+    const double target_div = getenv("OSWALD_HIP_TARGET_DIV") ? atof(getenv("OSWALD_HIP_TARGET_DIV")) : 1.25;
     const double target = std::max(total / nwaves / target_div, 4.0e4);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
@@ -427,7 +443,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
-        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
+        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_f16, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
                           &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.wg_times})
             b->release();
         drain_events(d);
@@ -466,8 +482,8 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     if (!ctx || !submat) return fail(OSWALD_HIP_EINVAL, "null argument");
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
     if (open_gap + extend_gap > 32767) return fail(OSWALD_HIP_EINVAL, "open+extend must fit int16");
-    if (cell_bits == 0) cell_bits = 16;
-    if (cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 16 or 32");
+    if (cell_bits == 0) cell_bits = getenv("OSWALD_HIP_CELL_BITS") ? atoi(getenv("OSWALD_HIP_CELL_BITS")) : 11;
+    if (cell_bits != 11 && cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 11, 16 or 32");
     memcpy(ctx->submat, submat, 24 * 32);
     ctx->open_gap = open_gap;
     ctx->extend_gap = extend_gap;
@@ -640,8 +656,18 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
     a.ovf_items = (uint2 *)c.ovf.p;
     const uint32_t goe = (uint32_t)(ctx->open_gap + ctx->extend_gap), ge = (uint32_t)ctx->extend_gap;
-    a.goe_pk = goe | (goe << 16);
-    a.ge_pk = ge | (ge << 16);
+    if (ctx->cell_bits == 11) {
+        // packed-fp16 kernels: the negated penalties as fp16 (values beyond 2048 need not be exact: every
+        // H of a lane that stays in the fp16 tier is below 2048, so H - goe is negative either way)
+        const uint32_t ngoe = __builtin_bit_cast(uint16_t, (_Float16)(-(float)goe)), nge = __builtin_bit_cast(uint16_t, (_Float16)(-(float)ge));
+        a.goe_pk = ngoe | (ngoe << 16);
+        a.ge_pk = nge | (nge << 16);
+        a.goe_fb = goe | (goe << 16);
+        a.ge_fb = ge | (ge << 16);
+    } else {
+        a.goe_pk = goe | (goe << 16);
+        a.ge_pk = ge | (ge << 16);
+    }
     a.goe = (int32_t)goe;
     a.ge = (int32_t)ge;
 
@@ -661,13 +687,19 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, (2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
     const uint32_t grid = std::min<uint32_t>(d.grid, std::max<uint32_t>(1, (c.nitems + 3) / 4 + c.nitems_wg));
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
-    if (ctx->cell_bits == 16 && c.nitems_q + c.nitems_q_wg > 0) {
+    const bool f16 = ctx->cell_bits == 11;
+    const auto launch_single = f16 ? osw_launch_f16 : osw_launch_pk16;
+    const auto launch_pair = f16 ? osw_launch_f16q : osw_launch_pk16q;
+    OswSearchArgs as = a; // single queries, first pass (`a` itself stays on the integer profile for the int32 kernel)
+    if (f16) { as.prof = (const uint2 *)d.prof_f16.p; as.prof_fb = (const uint2 *)d.prof.p; }
+    if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
         // query pairs first (the bulk of a multi-query search), on their own queue counters
         OswSearchArgs aq = a;
         aq.items = (const uint2 *)c.items_q.p;
         aq.nitems = c.nitems_q;
         aq.nitems_wg = c.nitems_q_wg;
         aq.prof = (const uint2 *)d.prof_pair.p;
+        aq.prof_fb = (const uint2 *)d.prof_pair_i16.p;
         aq.prof_off = (const uint32_t *)d.pair_off.p;
         aq.qlen = (const uint16_t *)d.pair_len.p;
         aq.pair_q = (const uint32_t *)d.pair_q.p;
@@ -677,19 +709,19 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             // the single-query launch goes to a second stream so that its workgroups fill the slots the
             // pair launch frees while it drains (both are persistent grids pulling from their own queues)
             HIP_TRY(hipEventRecord(d.ev_fork, d.stream));
-            HIP_TRY(osw_launch_pk16q(aq, gq, d.stream));
+            HIP_TRY(launch_pair(aq, gq, d.stream));
             HIP_TRY(hipStreamWaitEvent(d.stream2, d.ev_fork, 0));
-            OswSearchArgs a2 = a; // its own half of the spill scratch: the two launches overlap
+            OswSearchArgs a2 = as; // its own half of the spill scratch: the two launches overlap
             a2.bnd = a.bnd + (size_t)d.grid * (OSW_WG_THREADS / 64) * a.bnd_stride;
-            HIP_TRY(osw_launch_pk16(a2, grid, d.stream2));
+            HIP_TRY(launch_single(a2, grid, d.stream2));
             HIP_TRY(hipEventRecord(d.ev_join, d.stream2));
             HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_join, 0));
         } else {
-            HIP_TRY(osw_launch_pk16q(aq, gq, d.stream));
-            if (c.nitems + c.nitems_wg > 0) HIP_TRY(osw_launch_pk16(a, grid, d.stream));
+            HIP_TRY(launch_pair(aq, gq, d.stream));
+            if (c.nitems + c.nitems_wg > 0) HIP_TRY(launch_single(as, grid, d.stream));
         }
-    } else if (ctx->cell_bits == 16 && c.nitems + c.nitems_wg > 0) {
-        HIP_TRY(osw_launch_pk16(a, grid, d.stream));
+    } else if (ctx->cell_bits != 32 && c.nitems + c.nitems_wg > 0) {
+        HIP_TRY(launch_single(as, grid, d.stream));
     }
     HIP_TRY(osw_launch_i32(a, std::min<uint32_t>(d.grid, 1024u), d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }

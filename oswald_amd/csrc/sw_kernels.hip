@@ -135,24 +135,131 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
                      : OSW_INFLIGHT);                                                        \
     } while (0)
 
-// the two row forms on input set P (0: even column, 1: odd column)
-template <int P>
-static __device__ __forceinline__ void pk16_row(v2s &x, v2s &Er, v2s &Dn, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe)
-{
-    if constexpr (P == 0) OSW_PK16_ROW(OSW_VF0, x, Er, Dn, sc, s_next, ge, goe);
-    else OSW_PK16_ROW(OSW_VF1, x, Er, Dn, sc, s_next, ge, goe);
-}
-template <int P>
-static __device__ __forceinline__ void pk16_row_last(v2s x, v2s &Er, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe)
-{
-    if constexpr (P == 0) OSW_PK16_ROW_LAST(OSW_VF0, x, Er, hl, sc, ge, goe);
-    else OSW_PK16_ROW_LAST(OSW_VF1, x, Er, hl, sc, ge, goe);
-}
+// ---------------------------------------------------------------------------
+// Packed-fp16 cell for a first pass with a 2047 ceiling (the reference's first
+// tier is int8 with a 127 ceiling, host/src/HybridSearch.c:1573-1680).  fp16
+// represents every integer up to 2048 exactly, so as long as a lane's best score
+// stays below 2048 all its values are exact; a lane that reaches 2048 is queued
+// for the exact int32 kernel like a saturated int16 lane.  (x = D + S may round
+// above 2048, but then H >= x >= 2048 and the lane is re-run anyway.)
+// gfx950 has a packed three-operand maximum, v_pk_maximum3_f16: H = max3(x, E,
+// F) and E' = max3(E - ge, H - goe, 0) are one instruction each, and the running
+// maximum takes one instruction per TWO rows: 7.5 VOP3P instructions per row
+// against 9 for packed int16 (measured issue rate is the same, tools/ubench.hip).
+// Gap penalties arrive negated, as fp16 pairs.  Results are consumed at a
+// distance of >= 2 issue slots as in the int16 cell.
+//   x  in: D[r] + S[r];  xn out: D[r+1] + S[r+1];  Dn in: D[r+1], out: H(i0+r, j)
+//   odd rows also fold H of the row above (Dp) and their own H into the maximum
+// ---------------------------------------------------------------------------
+#define OSW_F16_ROW_EVEN(FREG, x, xn, Er, Dn, s_next, nge, ngoe)                             \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_add_f16 %[xn_], %[Dn_], %[sn_]\n\t"                               \
+                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_add_f16 %[E_], %[E_], %[ge_]\n\t"                                 \
+                     "v_pk_add_f16 %[t], %[Dn_], %[goe_]\n\t"                                \
+                     "v_pk_add_f16 " FREG ", " FREG ", %[ge_]\n\t"                           \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], 0\n\t"                           \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], 0"                         \
+                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn)         \
+                     : [x_] "v"(x), [sn_] "v"(s_next), [ge_] "s"(nge), [goe_] "s"(ngoe)      \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
 
-struct CellPK16 {
+#define OSW_F16_ROW_ODD(FREG, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe)                      \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_add_f16 %[xn_], %[Dn_], %[sn_]\n\t"                               \
+                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_add_f16 %[E_], %[E_], %[ge_]\n\t"                                 \
+                     "v_pk_add_f16 %[t], %[Dn_], %[goe_]\n\t"                                \
+                     "v_pk_add_f16 " FREG ", " FREG ", %[ge_]\n\t"                           \
+                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[Dn_]\n\t"                  \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], 0\n\t"                           \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], 0"                         \
+                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
+                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(nge), [goe_] "s"(ngoe) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
+#define OSW_F16_ROW_LAST(FREG, x, Er, hl, Dp, sc, nge, ngoe)                                 \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_maximum3_f16 %[hl_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_add_f16 %[E_], %[E_], %[ge_]\n\t"                                 \
+                     "v_pk_add_f16 %[t], %[hl_], %[goe_]\n\t"                                \
+                     "v_pk_add_f16 " FREG ", " FREG ", %[ge_]\n\t"                           \
+                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[hl_]\n\t"                  \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], 0\n\t"                           \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], 0"                         \
+                     : [hl_] "=&v"(hl), [t] "=&v"(t_), [E_] "+v"(Er), [sc_] "+v"(sc)         \
+                     : [x_] "v"(x), [Dp_] "v"(Dp), [ge_] "s"(nge), [goe_] "s"(ngoe)          \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
+// Cell arithmetic policies: the row forms on input set P (0: even column, 1: odd
+// column) and what a finished score means.
+//   row<P, ODD>: x in/out, Dp = H of the row above (= D[r], fp16 only)
+struct ArithI16 {
+    static constexpr int kCeiling = 32767; // a lane that reaches it is re-run in int32
+    static constexpr bool kEarlyExit = false;
+    static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
+    template <int P, bool ODD>
+    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s /*Dp*/, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe)
+    {
+        if constexpr (P == 0) OSW_PK16_ROW(OSW_VF0, x, Er, Dn, sc, s_next, ge, goe);
+        else OSW_PK16_ROW(OSW_VF1, x, Er, Dn, sc, s_next, ge, goe);
+    }
+    template <int P>
+    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s /*Dp*/, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe)
+    {
+        if constexpr (P == 0) OSW_PK16_ROW_LAST(OSW_VF0, x, Er, hl, sc, ge, goe);
+        else OSW_PK16_ROW_LAST(OSW_VF1, x, Er, hl, sc, ge, goe);
+    }
+    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0) { return __builtin_elementwise_add_sat(top_prev, s0); }
+    static __device__ __forceinline__ int to_int(short bits) { return bits; }
+};
+
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+struct ArithF16 {
+    static constexpr int kCeiling = 2048; // scores at or above it are not exact in fp16
+    static constexpr bool kEarlyExit = true; // checked after every round: the item is redone in packed int16 at once
+    // non-negative fp16 values order like their bit patterns; 2048.0 = 0x6800
+    static __device__ __forceinline__ bool at_ceiling(v2s s) { return (uint16_t)s.x >= 0x6800u || (uint16_t)s.y >= 0x6800u; }
+    template <int P, bool ODD>
+    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t nge, uint32_t ngoe)
+    {
+        v2s xn;
+        if constexpr (ODD) {
+            if constexpr (P == 0) OSW_F16_ROW_ODD(OSW_VF0, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe);
+            else OSW_F16_ROW_ODD(OSW_VF1, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe);
+        } else {
+            if constexpr (P == 0) OSW_F16_ROW_EVEN(OSW_VF0, x, xn, Er, Dn, s_next, nge, ngoe);
+            else OSW_F16_ROW_EVEN(OSW_VF1, x, xn, Er, Dn, s_next, nge, ngoe);
+        }
+        x = xn;
+    }
+    template <int P>
+    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t nge, uint32_t ngoe)
+    {
+        if constexpr (P == 0) OSW_F16_ROW_LAST(OSW_VF0, x, Er, hl, Dp, sc, nge, ngoe);
+        else OSW_F16_ROW_LAST(OSW_VF1, x, Er, hl, Dp, sc, nge, ngoe);
+    }
+    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0)
+    {
+        return __builtin_bit_cast(v2s, __builtin_bit_cast(v2h, top_prev) + __builtin_bit_cast(v2h, s0));
+    }
+    static __device__ __forceinline__ int to_int(short bits) { return (int)(float)__builtin_bit_cast(_Float16, bits); }
+};
+
+template <class A>
+struct CellSeqPair {
+    typedef A Arith;
     typedef v2s T;
     typedef uint32_t GapT; // (value, value) packed, wave-uniform
     static constexpr bool kFast = true;
+    static constexpr bool kEarlyExit = A::kEarlyExit;
+    static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16;
     static constexpr int kRowBytes = 64; // profile bytes per query row: 32 codes x int16
@@ -206,14 +313,14 @@ struct CellPK16 {
                 if constexpr (RB + 2 < R / 4) landed<2>(r1); else landed<0>(r1);
                 pair_up(r1, sn);
             }
-            pk16_row<P>(x, E[RB * 4 + 0], D[RB * 4 + 1], score, s[1], ge, goe);
-            pk16_row<P>(x, E[RB * 4 + 1], D[RB * 4 + 2], score, s[2], ge, goe);
-            pk16_row<P>(x, E[RB * 4 + 2], D[RB * 4 + 3], score, s[3], ge, goe);
+            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s[1], ge, goe);
+            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s[2], ge, goe);
+            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s[3], ge, goe);
             if constexpr (RB + 1 < R / 4) {
-                pk16_row<P>(x, E[RB * 4 + 3], D[RB * 4 + 4], score, sn[0], ge, goe);
+                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn[0], ge, goe);
                 Batch<R, RB + 1, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, sn, r2, r1);
             } else {
-                pk16_row_last<P>(x, E[RB * 4 + 3], hl, score, ge, goe);
+                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe);
             }
         }
     };
@@ -241,7 +348,7 @@ struct CellPK16 {
         ld<0>(a_lo, a_hi, r0);
         if constexpr (R / 4 > 1) { ld<1>(a_lo, a_hi, r1); landed<2>(r0); } else { landed<0>(r0); }
         pair_up(r0, s);
-        T x = __builtin_elementwise_add_sat(top_prev, s[0]);
+        T x = A::first_diag(top_prev, s[0]);
         Batch<R, 0, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, s, r1, r2);
     }
 };
@@ -255,10 +362,14 @@ struct CellPK16 {
 // the v_perm_b32 disappears: 9 VALU instructions per wave per 128 cells.
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct CellPK16Q {
+template <class A>
+struct CellQueryPair {
+    typedef A Arith;
     typedef v2s T;
     typedef uint32_t GapT;
     static constexpr bool kFast = true;
+    static constexpr bool kEarlyExit = A::kEarlyExit;
+    static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
     static constexpr int kRowBytes = 128; // 32 codes x 2 queries x int16
@@ -290,15 +401,15 @@ struct CellPK16Q {
                 if constexpr (RB + 2 < R / 4) landed<1>(r1); else landed<0>(r1);
             }
             T s1 = as_v2s(r0.y), s2 = as_v2s(r0.z), s3 = as_v2s(r0.w);
-            pk16_row<P>(x, E[RB * 4 + 0], D[RB * 4 + 1], score, s1, ge, goe);
-            pk16_row<P>(x, E[RB * 4 + 1], D[RB * 4 + 2], score, s2, ge, goe);
-            pk16_row<P>(x, E[RB * 4 + 2], D[RB * 4 + 3], score, s3, ge, goe);
+            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s1, ge, goe);
+            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s2, ge, goe);
+            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s3, ge, goe);
             if constexpr (RB + 1 < R / 4) {
                 T sn = as_v2s(r1.x);
-                pk16_row<P>(x, E[RB * 4 + 3], D[RB * 4 + 4], score, sn, ge, goe);
+                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn, ge, goe);
                 Batch<R, RB + 1, P>::run(a, D, E, x, hl, goe, ge, score, r1, r2, r0);
             } else {
-                pk16_row_last<P>(x, E[RB * 4 + 3], hl, score, ge, goe);
+                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe);
             }
         }
     };
@@ -321,10 +432,15 @@ struct CellPK16Q {
         u32x4 r0, r1, r2;
         ld<0>(a, r0);
         if constexpr (R / 4 > 1) { ld<1>(a, r1); landed<1>(r0); } else { landed<0>(r0); }
-        T x = __builtin_elementwise_add_sat(top_prev, as_v2s(r0.x));
+        T x = A::first_diag(top_prev, as_v2s(r0.x));
         Batch<R, 0, P>::run(a, D, E, x, hl, goe, ge, score, r0, r1, r2);
     }
 };
+
+typedef CellSeqPair<ArithI16> CellPK16;
+typedef CellQueryPair<ArithI16> CellPK16Q;
+typedef CellSeqPair<ArithF16> CellPKF16;
+typedef CellQueryPair<ArithF16> CellPKF16Q;
 
 // Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.
 // Compiler-scheduled throughout (rare path: re-run of saturated lanes).
@@ -332,6 +448,8 @@ struct CellI32 {
     typedef int T;
     typedef int GapT;
     static constexpr bool kFast = false;
+    static constexpr bool kEarlyExit = false;
+    static __device__ __forceinline__ bool at_ceiling(T) { return false; }
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
     static constexpr int kRowBytes = 64;
@@ -600,10 +718,13 @@ static __device__ __forceinline__ void load_profile_round(const uint4 *prof_q, u
 //               the workgroup's whole LDS (4 x kLdsRows rows), which allows
 //               4x taller rounds for heavy items.  The only synchronisation
 //               is a pair of workgroup barriers around the slice reload.
+// A cell arithmetic with a low ceiling (packed fp16: 2047) is checked after
+// every round: as soon as any lane of the wave (workgroup) has reached it the
+// item is abandoned (`hit`) and the caller redoes it in packed int16.
 template <class C, bool WG>
-static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, uint32_t q, const OswBlock &blk, uint32_t sigma,
+static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, const uint2 *prof, uint32_t q, const OswBlock &blk, uint32_t sigma,
                                                          uint32_t lg, int lane, int half, uint2 *lds_region, uint2 *bnd_wave,
-                                                         typename C::GapT goe, typename C::GapT ge)
+                                                         typename C::GapT goe, typename C::GapT ge, bool &hit)
 {
     typedef typename C::T T;
     constexpr uint32_t kLds = WG ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
@@ -614,7 +735,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     uint2 *bnd = (uint2 *)osw_uniform64((uint64_t)bnd_wave);
     const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
     constexpr uint32_t rb16 = C::kRowBytes * 4 / 16; // uint4 per row-block of 4 rows
-    const uint4 *prof_q = (const uint4 *)p.prof + (size_t)p.prof_off[q] * rb16;
+    const uint4 *prof_q = (const uint4 *)prof + (size_t)p.prof_off[q] * rb16;
     if (plan.rounds > 1) {
         // the scratch columns the prefetch and the drain steps read past the block's last one are the
         // row above of dummy columns: zero (other items, at other geometries, have written here)
@@ -622,11 +743,18 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         for (uint32_t k = lane; k < (G + 2u) * gl; k += 64) pad[k] = make_uint2(0, 0);
     }
     T score = C::zero();
+    bool lane_hit = false;
+    hit = false;
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, nrb = G * R / 4, rb_end = plan.m4 / 4;
         if constexpr (WG) {
-            __syncthreads(); // every wave is done with the previous slice
+            // every wave is done with the previous slice (and says whether it has hit the ceiling)
+            if constexpr (C::kEarlyExit) {
+                if (__syncthreads_or(lane_hit ? 1 : 0)) { hit = true; break; }
+            } else {
+                __syncthreads();
+            }
             const uint4 *src = prof_q + (size_t)rb0 * rb16;
             uint4 *dst = (uint4 *)lds_region;
             const uint32_t n16 = nrb * rb16;
@@ -634,10 +762,20 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             for (uint32_t i = threadIdx.x; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
             __syncthreads();
         } else {
+            if constexpr (C::kEarlyExit) {
+                if (__any(lane_hit ? 1 : 0)) { hit = true; break; }
+            }
             load_profile_round(prof_q, rb0, nrb, rb_end, rb16, lds_region, lane);
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * R * C::kRowBytes);
         sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, rho == 0, rho + 1 == plan.rounds, G, gl, lane, half, goe, ge, score);
+        if constexpr (C::kEarlyExit) lane_hit = C::at_ceiling(score);
+    }
+    if constexpr (C::kEarlyExit) {
+        if (!hit) {
+            if constexpr (WG) hit = __syncthreads_or(lane_hit ? 1 : 0) != 0;
+            else hit = __any(lane_hit ? 1 : 0) != 0;
+        }
     }
     // best over the strips = best over the lane groups
     for (uint32_t off = gl; off < 64; off <<= 1)
@@ -660,8 +798,9 @@ static __device__ __forceinline__ void set_wave_prio(uint32_t prio)
     }
 }
 
-// Scores of one packed-int16 item: written for the lanes of group 0; lanes at
-// the int16 ceiling are queued for the exact int32 kernel.
+// Scores of one packed 16-bit item: written for the lanes of group 0; lanes at
+// the ceiling of the cell arithmetic are queued for the exact int32 kernel.
+template <class A>
 static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
                                                    uint32_t lg, int lane, v2s score)
 {
@@ -669,10 +808,10 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
     if ((uint32_t)lane < gl) {
         const uint32_t lam = sigma * gl + lane; // lane of the block = sequence pair
         int2 out;
-        out.x = score.x;
-        out.y = score.y;
+        out.x = A::to_int(score.x);
+        out.y = A::to_int(score.y);
         *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lam) = out;
-        const uint32_t hm = (score.x == 32767 ? 1u : 0u) | (score.y == 32767 ? 2u : 0u);
+        const uint32_t hm = (out.x >= A::kCeiling ? 1u : 0u) | (out.y >= A::kCeiling ? 2u : 0u);
         if (hm) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
@@ -682,6 +821,7 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
 
 // Scores of one query-pair item and one sequence half: lane's low half = query A,
 // high half = query B, both against sequence 2*lam + half of the block.
+template <class A>
 static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint32_t pair, uint32_t B, const OswBlock &blk, uint32_t sigma,
                                                     uint32_t lg, int lane, int half, v2s score)
 {
@@ -690,13 +830,14 @@ static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint
         const uint32_t lam = sigma * gl + lane;
         const uint32_t qa = p.pair_q[2 * pair], qb = p.pair_q[2 * pair + 1];
         const size_t seq = (size_t)blk.seq0 + 2 * lam + half;
-        p.scores[(size_t)qa * p.score_stride + seq] = score.x;
-        p.scores[(size_t)qb * p.score_stride + seq] = score.y;
-        if (score.x == 32767) {
+        const int sa = A::to_int(score.x), sb = A::to_int(score.y);
+        p.scores[(size_t)qa * p.score_stride + seq] = sa;
+        p.scores[(size_t)qb * p.score_stride + seq] = sb;
+        if (sa >= A::kCeiling) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam, 6u, 1u << half), B);
         }
-        if (score.y == 32767) {
+        if (sb >= A::kCeiling) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(qb, lam, 6u, 1u << half), B);
         }
@@ -706,7 +847,8 @@ static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint
 // ---------------------------------------------------------------------------
 // Main kernel: packed int16.
 // ---------------------------------------------------------------------------
-template <class C, bool PAIR>
+// C = first-pass cell; CF = the cell an item is redone with when C reports its ceiling (CF = C: none)
+template <class C, class CF, bool PAIR>
 static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8];
@@ -749,17 +891,19 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x) + wv, lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        if constexpr (PAIR) {
-            for (int half = 0; half < 2; ++half) {
-                const v2s score = run_item<C, true>(p, q, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
-                pk16q_finish(p, q, B, blk, sigma, lg, lane, half, score);
+        for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
+            bool hit;
+            v2s score = run_item<C, true>(p, p.prof, q, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk, hit);
+            if (C::kEarlyExit && hit) {
+                score = run_item<CF, true>(p, p.prof_fb, q, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_fb, p.ge_fb, hit);
+                if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
+                else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
+            } else {
+                if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
+                else pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
             }
-            set_wave_prio(0);
-        } else {
-            const v2s score = run_item<C, true>(p, q, blk, sigma, lg, lane, 0, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
-            set_wave_prio(0);
-            pk16_finish(p, q, B, blk, sigma, lg, lane, score);
         }
+        set_wave_prio(0);
     }
 
     if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -778,26 +922,36 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        if constexpr (PAIR) {
-            for (int half = 0; half < 2; ++half) {
-                const v2s score = run_item<C, false>(p, q, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
-                pk16q_finish(p, q, B, blk, sigma, lg, lane, half, score);
+        for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
+            bool hit;
+            v2s score = run_item<C, false>(p, p.prof, q, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk, hit);
+            if (C::kEarlyExit && hit) {
+                score = run_item<CF, false>(p, p.prof_fb, q, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_fb, p.ge_fb, hit);
+                if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
+                else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
+            } else {
+                if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
+                else pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
             }
-            set_wave_prio(0);
-        } else {
-            const v2s score = run_item<C, false>(p, q, blk, sigma, lg, lane, 0, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
-            set_wave_prio(0);
-            pk16_finish(p, q, B, blk, sigma, lg, lane, score);
         }
+        set_wave_prio(0);
     }
     if (p.wg_times && lane == 0) p.wg_times[blockIdx.x * 4 + 2 + (wv & 1)] = __builtin_amdgcn_s_memrealtime(); // waves 0/1 (or 2/3) race: any is fine
 }
 
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16, false>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16, CellPK16, false>(p); }
 
 // Query pairs: `items` / `qlen` / `prof` / `prof_off` describe pairs (length = the longer query,
 // profile = packed (A, B) scores); pair_q maps a pair to its two query rows of the score table.
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16Q, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16Q, CellPK16Q, true>(p); }
+
+// The same two kernels with a packed-fp16 first pass (ceiling 2047, see ArithF16): goe_pk / ge_pk carry
+// the NEGATED penalties as fp16 pairs and `prof` holds fp16 scores.  An item in which any sequence
+// reaches the ceiling is redone on the spot in packed int16 (prof_fb, goe_fb, ge_fb), by the wave or
+// workgroup that found out, after the round in which it happened; from there on it is an int16 item
+// (a score at the int16 ceiling goes to the int32 kernel).
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16(OswSearchArgs p) { pk16_body<CellPKF16, CellPK16, false>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16q(OswSearchArgs p) { pk16_body<CellPKF16Q, CellPK16Q, true>(p); }
 
 // ---------------------------------------------------------------------------
 // Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at
@@ -828,7 +982,8 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
         const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
-            const int score = run_item<CellI32, false>(p, q, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge);
+            bool hit;
+            const int score = run_item<CellI32, false>(p, p.prof, q, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge, hit);
             if ((uint32_t)lane < gl)
                 p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }
@@ -895,10 +1050,12 @@ extern "C" __global__ __launch_bounds__(64) void osw_block_extent(OswBlock *bloc
 // Query profile in the layout the search kernels read:
 // prof[(prof_off[q] + i/4)*32 + code] = 4 x int16 = S(a[i..i+3], code);
 // rows past the query end and query codes >= 24 score 0 (the reference's
-// 24th matrix row is all zero, submat.c).
+// 24th matrix row is all zero, submat.c).  fp16 != 0: the scores as fp16 bit
+// patterns (for the packed-fp16 kernels).
 extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_t *__restrict__ a, const uint32_t *__restrict__ a_disp,
                                                                      const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ prof_off,
-                                                                     const int8_t *__restrict__ submat, uint32_t nq, uint2 *__restrict__ prof)
+                                                                     const int8_t *__restrict__ submat, uint32_t nq, uint32_t fp16,
+                                                                     uint2 *__restrict__ prof)
 {
     const uint32_t q = blockIdx.y;
     if (q >= nq) return;
@@ -916,7 +1073,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_
                 const uint32_t ai = aq[i];
                 if (ai < 24) v = submat[ai * 32 + code];
             }
-            s[k] = (short)v;
+            s[k] = fp16 ? __builtin_bit_cast(short, (_Float16)v) : (short)v; // |v| <= 128: exact in fp16
         }
         uint2 o;
         o.x = (uint32_t)(uint16_t)s[0] | ((uint32_t)(uint16_t)s[1] << 16);
@@ -1026,6 +1183,20 @@ hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s
     return hipSuccess;
 }
 
+hipError_t osw_launch_f16(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_f16, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_f16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_f16q, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          uint4 *prof_pair, hipStream_t s)
@@ -1057,12 +1228,12 @@ hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t
 }
 
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
-                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint2 *prof, hipStream_t s)
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, uint2 *prof, hipStream_t s)
 {
     if (nq == 0) return hipSuccess;
     uint32_t gx = (max_rowblocks * 32 + 255) / 256;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, prof);
+    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, fp16, prof);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

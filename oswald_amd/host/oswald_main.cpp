@@ -192,7 +192,7 @@ int do_search(Options &o)
     oswald_hip_ctx *ctx = nullptr;
     check(oswald_hip_init((int)o.num_devices, nullptr, &ctx), "device bring-up");
     const double tick = dwalltime();
-    check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 16), "scoring setup");
+    check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
     // chunk c of a round goes to device c mod ndev (reference FPGAsearch.c:132-138)
     for (size_t k = 0; k < db.chunks.size(); k += o.num_devices) {

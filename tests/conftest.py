@@ -18,6 +18,21 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+def pytest_generate_tests(metafunc):
+    # every GPU test runs once per first-pass arithmetic of the library (packed fp16 = the default,
+    # packed int16); a test that passes cell_bits explicitly is unaffected by the setting
+    if metafunc.definition.get_closest_marker("gpu") and "first_pass" in metafunc.fixturenames:
+        metafunc.parametrize("first_pass", ["f16", "i16"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def first_pass(request, monkeypatch):
+    mode = getattr(request, "param", None)
+    if mode is not None:
+        monkeypatch.setenv("OSWALD_HIP_CELL_BITS", {"f16": "11", "i16": "16"}[mode])
+    return mode
+
+
 @pytest.fixture(scope="session")
 def oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

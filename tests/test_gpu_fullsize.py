@@ -26,7 +26,7 @@ def test_c2_full_size_properties(hip_ctx, oracle, c2):
     b, n, disp = dblayout.interleave(sl, sr, so, 16)
     a, m, ad = pack_queries(qs)
     sm = submat.load("blosum62")
-    hip_ctx.set_scoring(sm, 10, 2, 16)
+    hip_ctx.set_scoring(sm, 10, 2)
     hip_ctx.set_queries(a, m, ad)
     h = hip_ctx.chunk_upload(b, n, disp.astype(np.uint32), 16)
     t1 = np.zeros((len(qs), len(n) * 16), np.int32)
@@ -90,7 +90,7 @@ def test_c5_long_query_full_size_sample(hip_ctx, oracle, c2):
     b, n, disp = dblayout.interleave(lens.astype(np.uint16), allres, off, 16)
     a, m, ad = pack_queries([q])
     sm = submat.load("blosum62")
-    hip_ctx.set_scoring(sm, 10, 2, 16)
+    hip_ctx.set_scoring(sm, 10, 2)
     hip_ctx.set_queries(a, m, ad)
     out = np.zeros((1, len(n) * 16), np.int32)
     hip_ctx.search_chunk_async(b, n, disp.astype(np.uint32), out, 16)

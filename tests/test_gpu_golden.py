@@ -18,7 +18,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def search(ctx, queries, b, n, disp, sm, go, ge):
     a, m, ad = pack_queries(queries)
-    ctx.set_scoring(sm, go, ge, 16)
+    ctx.set_scoring(sm, go, ge)
     ctx.set_queries(a, m, ad)
     out = np.zeros((len(queries), len(n) * 16), np.int32)
     ctx.search_chunk_async(b, n, np.asarray(disp, np.uint32), out, 16)

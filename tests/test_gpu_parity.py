@@ -14,7 +14,7 @@ from helpers import db_from_sequences, layout, pack_queries, random_db
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(ctx, queries, b, n, disp, W, sm, go, ge, cell_bits=16, resident=False):
+def run_gpu(ctx, queries, b, n, disp, W, sm, go, ge, cell_bits=0, resident=False):
     a, m, ad = pack_queries(queries)
     ctx.set_scoring(sm, go, ge, cell_bits)
     ctx.set_queries(a, m, ad)
@@ -111,9 +111,43 @@ def test_int32_mode_equals_int16_mode(hip_ctx, oracle):
     sm = submat.load("pam250")
     got32 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=32)
     got16 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=16)
+    got11 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=11)
     want = expect(oracle, qs, b, n, disp, 16, sm, 14, 2)
     np.testing.assert_array_equal(got32, want)
     np.testing.assert_array_equal(got16, want)
+    np.testing.assert_array_equal(got11, want)
+
+
+def _self_scoring(target, seed):
+    """A sequence whose BLOSUM62 self-alignment scores exactly `target`: W (11), A (4) and E (5) in a seeded order."""
+    rng = np.random.default_rng(seed)
+    w = (target - 40) // 11
+    rest = target - 11 * w           # 40..50: always 4a + 5b
+    b5 = next(k for k in range(11) if (rest - 5 * k) % 4 == 0 and rest - 5 * k >= 0)
+    a4 = (rest - 5 * b5) // 4
+    seq = np.array([19] * w + [0] * a4 + [4] * b5, dtype=np.uint8)   # codes (synth.ALPHABET): A=0 E=4 W=19
+    rng.shuffle(seq)
+    assert 11 * w + 4 * a4 + 5 * b5 == target
+    return seq
+
+
+@pytest.mark.parametrize("cell_bits", [11, 16])
+def test_scores_around_the_fp16_ceiling(hip_ctx, oracle, cell_bits):
+    """Self-alignments scoring 2040..2056 and 4000: the packed-fp16 first pass is exact below 2048 and hands
+    everything from 2048 on to the int32 kernel; either way the reported score is the exact one."""
+    targets = [2040, 2045, 2046, 2047, 2048, 2049, 2050, 2056, 4000]
+    qs = [_self_scoring(t, 100 + t) for t in targets]
+    seqs = [q.copy() for q in qs] + [synth.mutate(q, 0.02, 7 + i) for i, q in enumerate(qs)]
+    seqs += [synth.random_residues(900 + i, 0, 150 + 7 * i) for i in range(40)]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2, cell_bits=cell_bits)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    best = want.max(axis=1)
+    assert best.tolist() == targets
+    assert ((want >= 2040) & (want < 2048)).any() and (want >= 2048).any()
 
 
 def test_long_query_many_strips(hip_ctx, oracle):
@@ -148,7 +182,7 @@ def test_topr_on_device_tie_order(hip_ctx, oracle):
     b, n, disp, sl, _ = layout(L, R, O, 16)
     sm = submat.load("blosum62")
     a, m, ad = pack_queries(qs)
-    hip_ctx.set_scoring(sm, 10, 2, 16)
+    hip_ctx.set_scoring(sm, 10, 2)
     hip_ctx.set_queries(a, m, ad)
     h = hip_ctx.chunk_upload(b, n, disp, 16)
     out = np.zeros((2, len(n) * 16), np.int32)

@@ -7,7 +7,7 @@ from oswald_amd import capi, submat, synth
 from oracle import pyoracle
 from helpers import layout, pack_queries, random_db
 
-def run(qlens, nseq, maxlen, env, bits=16):
+def run(qlens, nseq, maxlen, env, bits=0):
     for k in ("OSWALD_HIP_FORCE_LG", "OSWALD_HIP_FORCE_WG", "OSWALD_HIP_PAIRS"):
         os.environ.pop(k, None)
     os.environ.update(env)

@@ -55,6 +55,29 @@ __global__ __launch_bounds__(256) void i32_rate(uint32_t *out, int c1, int c2, i
     if (acc == 0x12345678u) out[threadIdx.x] = acc;
 }
 
+// packed fp16 with the gfx950 three-operand maximum (candidate cell arithmetic for a 2047-ceiling first pass)
+template <int ILP>
+__global__ __launch_bounds__(256) void f16_rate(uint32_t *out, uint32_t c1, uint32_t c2, int iters)
+{
+    uint32_t x[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) x[i] = 0x3c003c00u + (threadIdx.x & 1) + i; // ~1.0 in both halves
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) {
+            uint32_t t;
+            asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(t) : "v"(x[i]), "v"(c1));
+            asm volatile("v_pk_maximum3_f16 %0, %1, %2, 0" : "=v"(x[i]) : "v"(t), "v"(c2));
+            asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x[i]), "v"(c1));
+            asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(x[i]) : "v"(t), "v"(c2), "v"(c1));
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc ^= x[i];
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
 // LDS: ds_read_b64 of 4 profile rows at residue*8 + imm, 16 reads per "column"
 __global__ __launch_bounds__(256) void lds_rate(uint32_t *out, const uint32_t *res, int iters)
 {
@@ -140,6 +163,17 @@ int main(int argc, char **argv)
         run(pk_rate<2>, 2, "ilp2");
         run(pk_rate<8>, 8, "ilp8");
     }
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        auto run = [&](auto kern, int ilp, const char *name) {
+            double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(cus * wps), dim3(256), 0, 0, out, 0x3c003c00u, 0x40004000u, iters); }, 3);
+            double ops = (double)cus * wps * 4 * iters * ilp * 4.0;
+            printf("f16_rate %-6s waves/SIMD=%d : %.3f ms = %.2f cycles/instr/SIMD at 2.4GHz\n", name, wps, ms, (double)cus * 4 * 2.4e9 / (ops / (ms * 1e-3)));
+        };
+        run(f16_rate<1>, 1, "ilp1");
+        run(f16_rate<2>, 2, "ilp2");
+        run(f16_rate<8>, 8, "ilp8");
+    }
+    if (argc > 1 && !strcmp(argv[1], "f16")) return 0;
     for (int wps = 1; wps <= 8; wps *= 2) {
         auto run = [&](auto kern, int ilp, const char *name) {
             double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(cus * wps), dim3(256), 0, 0, out, 3, 1, iters); }, 3);
