@@ -119,6 +119,57 @@ struct oswald_hip_ctx {
 
 namespace {
 
+// Pair up queries of similar length (sorted by length, neighbours): a pair costs 9 (fp16 first pass: 7.5)
+// instructions per row of the LONGER query for one sequence, two singles 10 (8.5) per row for two
+// sequences, so pairing pays when the shorter one is longer than ~0.85 (0.8) of the longer one.
+// OSWALD_HIP_PAIRS=0 disables it, =2 pairs every neighbour (test hook).
+void plan_pairs(oswald_hip_ctx *ctx)
+{
+    const uint32_t nq = ctx->nq;
+    const std::vector<uint16_t> &m = ctx->m;
+    const double pair_row = ctx->cell_bits == 11 ? 7.5 : 9.0, single_row = ctx->cell_bits == 11 ? 8.5 : 10.0;
+    ctx->pair_q.clear(); ctx->pair_off.clear(); ctx->pair_len.clear(); ctx->singles.clear();
+    ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
+    int mode = 1;
+    if (const char *e = getenv("OSWALD_HIP_PAIRS")) mode = atoi(e);
+    const double margin = getenv("OSWALD_HIP_PAIR_MARGIN") ? atof(getenv("OSWALD_HIP_PAIR_MARGIN")) : 1.03;
+    std::vector<uint32_t> order(nq);
+    for (uint32_t q = 0; q < nq; ++q) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return m[x] < m[y]; });
+    // cheapest set of neighbour pairs in length order (dynamic programme over the sorted list):
+    // a single costs single_row x m, a pair 2 x pair_row x (longer m) (x margin: padding, second pass)
+    std::vector<double> best(nq + 1, 0.0);
+    std::vector<uint8_t> paired(nq + 1, 0); // paired[k]: the optimum for the first k queries ends in a pair
+    for (uint32_t k = 1; k <= nq; ++k) {
+        best[k] = best[k - 1] + single_row * m[order[k - 1]];
+        if (mode > 0 && k >= 2) {
+            const double mb = m[order[k - 1]];
+            const double c2 = best[k - 2] + 2.0 * pair_row * margin * mb;
+            const bool ok = mode >= 2 ? mb > 0 && ((k & 1u) == (nq & 1u)) : mb >= 64;
+            if (ok && (mode >= 2 || c2 < best[k])) { best[k] = c2; paired[k] = 1; }
+        }
+    }
+    std::vector<uint8_t> is_pair_end(nq + 1, 0);
+    for (uint32_t k = nq; k > 0;) {
+        if (paired[k]) { is_pair_end[k] = 1; k -= 2; } else k -= 1;
+    }
+    for (uint32_t k = 0; k < nq;) {
+        if (k + 2 <= nq && is_pair_end[k + 2]) {
+            const uint32_t mb = m[order[k + 1]], rb = std::max(1u, (mb + 3u) / 4u);
+            ctx->pair_q.push_back(order[k]);
+            ctx->pair_q.push_back(order[k + 1]);
+            ctx->pair_len.push_back((uint16_t)mb);
+            ctx->pair_off.push_back(ctx->pair_rowblocks);
+            ctx->pair_rowblocks += rb;
+            ctx->pair_max_rowblocks = std::max(ctx->pair_max_rowblocks, rb);
+            k += 2;
+        } else {
+            ctx->singles.push_back(order[k]);
+            k += 1;
+        }
+    }
+}
+
 int check_dev(oswald_hip_ctx *ctx, int dev)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
@@ -487,9 +538,11 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     memcpy(ctx->submat, submat, 24 * 32);
     ctx->open_gap = open_gap;
     ctx->extend_gap = extend_gap;
+    const bool repair = ctx->have_queries && cell_bits != ctx->cell_bits; // the pairing rule depends on the arithmetic
     ctx->cell_bits = cell_bits;
     ctx->have_scoring = true;
     ctx->scoring_version++;
+    if (repair) { plan_pairs(ctx); ctx->queries_version++; }
     return 0;
 }
 
@@ -514,39 +567,7 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
     ctx->total_rowblocks = off;
     ctx->max_rowblocks = mx;
     ctx->nq = nq;
-    // Pair up queries of similar length (sorted by length, neighbours): a pair costs 9 instructions per
-    // row of the LONGER query for one sequence, two singles 10 per row for two sequences, so pairing pays
-    // when the shorter one is longer than ~0.85 of the longer one.  OSWALD_HIP_PAIRS=0 disables it,
-    // =2 pairs every neighbour (test hook).
-    ctx->pair_q.clear(); ctx->pair_off.clear(); ctx->pair_len.clear(); ctx->singles.clear();
-    ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
-    {
-        int mode = 1;
-        if (const char *e = getenv("OSWALD_HIP_PAIRS")) mode = atoi(e);
-        std::vector<uint32_t> order(nq);
-        for (uint32_t q = 0; q < nq; ++q) order[q] = q;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return m[x] < m[y]; });
-        for (uint32_t k = 0; k < nq;) {
-            bool pair = false;
-            if (mode > 0 && k + 1 < nq) {
-                const double ma = m[order[k]], mb = m[order[k + 1]];
-                pair = mode >= 2 ? mb > 0 : (mb >= 64 && 9.0 * 1.03 * mb < 5.0 * (ma + mb));
-            }
-            if (pair) {
-                const uint32_t mb = m[order[k + 1]], rb = std::max(1u, (mb + 3u) / 4u);
-                ctx->pair_q.push_back(order[k]);
-                ctx->pair_q.push_back(order[k + 1]);
-                ctx->pair_len.push_back((uint16_t)mb);
-                ctx->pair_off.push_back(ctx->pair_rowblocks);
-                ctx->pair_rowblocks += rb;
-                ctx->pair_max_rowblocks = std::max(ctx->pair_max_rowblocks, rb);
-                k += 2;
-            } else {
-                ctx->singles.push_back(order[k]);
-                k += 1;
-            }
-        }
-    }
+    plan_pairs(ctx);
     ctx->have_queries = true;
     ctx->queries_version++;
     return 0;
