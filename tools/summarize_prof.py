@@ -5,7 +5,8 @@ averages, HBM traffic per launch of the DP kernel)."""
 import csv, glob, json, os, sys
 
 out, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNELS = ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
+DP = ("osw_sw_f16q", "osw_sw_f16", "osw_sw_pk16q", "osw_sw_pk16")  # first-pass DP kernels (fp16 / int16 mode)
+KERNELS = DP + ("osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
 
 
 def find(sub, pattern):
@@ -23,7 +24,7 @@ if f:
     allrows = list(csv.DictReader(open(f)))
     def kname(r):
         return r.get("Kernel_Name", "").split("(")[0].strip()
-    for kn in ("osw_sw_pk16q", "osw_sw_pk16"):
+    for kn in DP:
         rows = [r for r in allrows if kname(r) == kn]
         if rows:
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
@@ -31,7 +32,7 @@ if f:
                                       "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"), "lds": rows[0].get("LDS_Block_Size")}
     # one search step = the pair launch and the single-query launch side by side (two streams) + the int32 re-run:
     # span from the first start to the last end of the k-th dispatches
-    dp = {kn: sorted([r for r in allrows if kname(r) == kn], key=lambda r: int(r["Start_Timestamp"])) for kn in ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32")}
+    dp = {kn: sorted([r for r in allrows if kname(r) == kn], key=lambda r: int(r["Start_Timestamp"])) for kn in DP + ("osw_sw_i32",)}
     nstep = len(dp["osw_sw_i32"])
     spans = []
     for k in range(nstep):
@@ -39,7 +40,7 @@ if f:
         spans.append(max(int(r["End_Timestamp"]) for r in rs) - min(int(r["Start_Timestamp"]) for r in rs))
     if spans:
         summary["dp_step_span"] = {"steps": len(spans), "avg_ms": sum(spans) / len(spans) / 1e6, "min_ms": min(spans) / 1e6, "max_ms": max(spans) / 1e6,
-                                   "what": "osw_sw_pk16q + osw_sw_pk16 (concurrent) + osw_sw_i32 of one search; compare with bench.py roofline.kernel_ms"}
+                                   "what": "pair kernel + single-query kernel (concurrent) + osw_sw_i32 of one search; compare with bench.py roofline.kernel_ms"}
 
 
 def pmc(sub):
@@ -75,22 +76,24 @@ summary["pmc_fetch"] = pmc("fetch")
 summary["pmc_write"] = pmc("write")
 summary["pmc_sq"] = pmc("sq")
 try:
-    fs = sum(summary["pmc_fetch"].get(k, {}).get("FETCH_SIZE", {}).get("per_dispatch", 0.0) for k in ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32"))
-    ws = sum(summary["pmc_write"].get(k, {}).get("WRITE_SIZE", {}).get("per_dispatch", 0.0) for k in ("osw_sw_pk16q", "osw_sw_pk16", "osw_sw_i32"))
+    fs = sum(summary["pmc_fetch"].get(k, {}).get("FETCH_SIZE", {}).get("per_dispatch", 0.0) for k in DP + ("osw_sw_i32",))
+    ws = sum(summary["pmc_write"].get(k, {}).get("WRITE_SIZE", {}).get("per_dispatch", 0.0) for k in DP + ("osw_sw_i32",))
     if fs == 0 and ws == 0:
         raise KeyError("no DP kernel counters")
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts 64 B per
     # 128-B request for wide coalesced reads, other widths must be calibrated on a known byte count in the kernel's own
     # access pattern.  The DP kernel moves 8 B per lane; `ubench calib` reads and writes exactly 1 GiB that way.
     GIB = float(1 << 30)
-    cf = calib("calib_fetch", "FETCH_SIZE", "stream_read8")
-    cw = calib("calib_write", "WRITE_SIZE", "stream_write8")
+    # (two dword accesses per 8-B entry, as the kernels' column loop issues them; the 8-B variant is kept for comparison)
+    cf = calib("calib_fetch", "FETCH_SIZE", "stream_read4x2") or calib("calib_fetch", "FETCH_SIZE", "stream_read8")
+    cw = calib("calib_write", "WRITE_SIZE", "stream_write4x2") or calib("calib_write", "WRITE_SIZE", "stream_write8")
+    summary["calib_8B_access"] = {"fetch_kib_for_1GiB": calib("calib_fetch", "FETCH_SIZE", "stream_read8"), "write_kib_for_1GiB": calib("calib_write", "WRITE_SIZE", "stream_write8")}
     kf = GIB / (cf * 1024) if cf else 2.0
     kw = GIB / (cw * 1024) if cw else 1.0
     summary["traffic"] = {"fetch_kib_raw": fs, "write_kib_raw": ws, "calib_fetch_kib_for_1GiB": cf, "calib_write_kib_for_1GiB": cw,
                           "fetch_factor": kf, "write_factor": kw,
                           "hbm_bytes_per_launch": int((kf * fs + kw * ws) * 1024),
-                          "correction": "bytes = KiB * 1024 * factor; factor = 1 GiB / counter value of a 1-GiB 8-B-per-lane stream (same access width as the DP kernel)"}
+                          "correction": "bytes = KiB * 1024 * factor; factor = 1 GiB / counter value of a 1-GiB stream of 8-B entries accessed as 2 dwords per lane (the DP kernels' spill access)"}
 except KeyError:
     pass
 print(json.dumps(summary, indent=1))

@@ -111,6 +111,25 @@ __global__ __launch_bounds__(256) void stream_write8(uint2 *dst, size_t n)
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = make_uint2((uint32_t)i, 7u);
 }
 
+// the same bytes moved the way the DP kernels spill since the fixed-register column loop: {H, F} entries of 8 B,
+// read / written as two dword accesses per lane (offset 0 and 4)
+__global__ __launch_bounds__(256) void stream_read4x2(const uint32_t *src, uint32_t *out, size_t n)
+{
+    uint32_t acc = 0;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t a, b;
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:4\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(src + 2 * i) : "memory");
+        acc += a ^ b;
+    }
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void stream_write4x2(uint32_t *dst, size_t n)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        asm volatile("global_store_dword %0, %1, off\n\tglobal_store_dword %0, %2, off offset:4" ::"v"(dst + 2 * i), "v"((uint32_t)i), "v"(7u) : "memory");
+    }
+}
+
 template <class F>
 static double time_ms(F f, int reps)
 {
@@ -137,6 +156,8 @@ int main(int argc, char **argv)
         hipMemset(buf, 1, n * 8);
         hipLaunchKernelGGL(stream_write8, dim3(2048), dim3(256), 0, 0, buf, n);
         hipLaunchKernelGGL(stream_read8, dim3(2048), dim3(256), 0, 0, (const uint2 *)buf, o, n);
+        hipLaunchKernelGGL(stream_write4x2, dim3(2048), dim3(256), 0, 0, (uint32_t *)buf, n);
+        hipLaunchKernelGGL(stream_read4x2, dim3(2048), dim3(256), 0, 0, (const uint32_t *)buf, o, n);
         hipDeviceSynchronize();
         printf("calib: wrote %zu bytes (stream_write8), read %zu bytes (stream_read8)\n", n * 8, n * 8);
         return 0;
