@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,20 @@ int fail(int code, const char *fmt, ...)
             return fail(e__ == hipErrorOutOfMemory ? OSWALD_HIP_ENOMEM : OSWALD_HIP_ERUNTIME, "%s: %s", #expr, \
                         hipGetErrorString(e__));                                                              \
     } while (0)
+
+// OSWALD_HIP_DEBUG_PHASES=1: wall time of the host-side phases of an upload / search (diagnostics)
+struct PhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseTimer() : on(getenv("OSWALD_HIP_DEBUG_PHASES") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[oswald_hip] phase %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 // A device buffer that only ever grows.
 struct DevBuf {
@@ -84,7 +99,8 @@ struct Device {
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_f16, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
-    DevBuf topr_scores, topr_index, wg_times;
+    DevBuf topr_scores, topr_index, wg_times, scores_packed;
+    std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
     uint64_t scoring_version = ~0ull;
@@ -425,6 +441,13 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     return 0;
 }
 
+// after the stream has been synchronised: the downloads are done, unpin the callers' tables
+void release_registered(Device &d)
+{
+    for (void *p : d.registered) (void)hipHostUnregister(p);
+    d.registered.clear();
+}
+
 void drain_events(Device &d)
 {
     for (auto &e : d.ev_used) {
@@ -482,6 +505,29 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         d.grid = (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu;
         r = d.counters.reserve((2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
+        // Bring-up costs that would otherwise land in the first search (the reference times its searches after
+        // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
+        // copy of a process takes ~10 ms, later ones run at ~20 GB/s) and the first launch of every kernel.
+        {
+            std::vector<char> tmp(16u << 20, 1);
+            DevBuf scratch;
+            r = scratch.reserve(tmp.size());
+            if (r == hipSuccess) r = hipMemcpyAsync(scratch.p, tmp.data(), tmp.size(), hipMemcpyHostToDevice, d.stream);
+            if (r == hipSuccess) r = hipMemcpyAsync(tmp.data(), scratch.p, tmp.size(), hipMemcpyDeviceToHost, d.stream);
+            if (r == hipSuccess) r = hipMemsetAsync(d.counters.p, 0, (2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream);
+            OswSearchArgs a;
+            memset(&a, 0, sizeof a); // empty queues: every wave leaves at once
+            a.counters = (uint32_t *)d.counters.p;
+            a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
+            if (r == hipSuccess) r = osw_launch_f16q(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_f16(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_pk16(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_i32(a, 1, d.stream);
+            if (r == hipSuccess) r = hipStreamSynchronize(d.stream);
+            scratch.release();
+            if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "warm-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
+        }
     }
     *out = ctx;
     return 0;
@@ -493,9 +539,10 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
     for (Device &d : ctx->dev) {
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
+        release_registered(d);
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_f16, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
-                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.wg_times})
+                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.wg_times, &d.scores_packed})
             b->release();
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -589,6 +636,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     for (size_t i = 0; i < d.chunks.size(); ++i) if (!d.chunks[i].live) { slot = (int)i; break; }
     if (slot < 0) { d.chunks.emplace_back(); slot = (int)d.chunks.size() - 1; }
     Chunk &c = d.chunks[slot];
+    PhaseTimer pt;
     const uint32_t gpb = OSW_BLOCK_SEQS / W;
     c.ngroups = ngroups;
     c.W = W;
@@ -617,6 +665,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     HIP_TRY(d.staging_b.reserve(vD + 64));
     HIP_TRY(d.staging_n.reserve(ngroups * sizeof(uint16_t) + 16));
     HIP_TRY(d.staging_disp.reserve(ngroups * sizeof(uint32_t) + 16));
+    pt.lap("upload: plan + allocations");
     if (ngroups > 0) {
         HIP_TRY(hipMemcpyAsync(d.staging_b.p, b, vD, hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemcpyAsync(d.staging_n.p, n, ngroups * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
@@ -626,6 +675,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         HIP_TRY(osw_launch_retile((const uint8_t *)d.staging_b.p, (const uint16_t *)d.staging_n.p, (const uint32_t *)d.staging_disp.p,
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, d.stream));
     }
+    if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("upload: H2D + re-tile"); }
     // strip-boundary scratch: one region per resident wave, sized for the longest block
     // {H,F} entries per wave slot: the longest block at G = 1, capped (longer blocks get a wider geometry, build_items)
     const uint64_t stride = std::min<uint64_t>(((uint64_t)c.max_ncols4 * 4 + OSW_SCRATCH_PAD_COLS) * 64, OSW_SCRATCH_MAX_ENTRIES);
@@ -635,10 +685,12 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         // two launches may be in flight side by side; every region starts with its zero and trash pages
         const size_t bytes = 2 * slots * (stride + OSW_SCRATCH_DATA) * sizeof(uint2);
         HIP_TRY(d.bnd.reserve(bytes));
-        HIP_TRY(hipMemsetAsync(d.bnd.p, 0, bytes, d.stream)); // the zero pages are never written again
+        // the zero page of every slot is never written again (the trash page may hold anything; cleared with it)
+        HIP_TRY(hipMemset2DAsync(d.bnd.p, (stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream));
         d.bnd_stride = stride;
     }
     HIP_TRY(hipStreamSynchronize(d.stream)); // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
+    pt.lap("upload: spill scratch + sync");
     c.items_version = ~0ull;
     c.searched = false;
     c.live = true;
@@ -653,8 +705,11 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
+    PhaseTimer pt;
     if (int r = sync_queries(ctx, d)) return r;
+    pt.lap("search: queries + profiles");
     if (int r = build_items(ctx, d, c)) return r;
+    pt.lap("search: work-queue plan");
     if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return 0; }
 
     OswSearchArgs a;
@@ -770,10 +825,27 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_end[k]);
         fprintf(stderr, "\n");
     }
+    if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: kernels"); }
     if (scores_out) {
-        const size_t row = (size_t)c.ngroups * c.W * sizeof(int32_t);
-        HIP_TRY(hipMemcpy2DAsync(scores_out, row, c.scores.p, (size_t)c.score_stride * sizeof(int32_t), row, ctx->nq,
-                                 hipMemcpyDeviceToHost, d.stream));
+        // the caller's table is [nq][ngroups*W]; ours is pitched to whole wave blocks: pack on the device (a pitched
+        // copy into pageable memory runs at a fraction of a GB/s), then one linear copy
+        const uint32_t row = c.ngroups * c.W;
+        const void *src = c.scores.p;
+        if (row != c.score_stride && ctx->nq > 1) {
+            HIP_TRY(d.scores_packed.reserve((size_t)ctx->nq * row * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy2DAsync(d.scores_packed.p, (size_t)row * sizeof(int32_t), c.scores.p, (size_t)c.score_stride * sizeof(int32_t),
+                                     (size_t)row * sizeof(int32_t), ctx->nq, hipMemcpyDeviceToDevice, d.stream));
+            src = d.scores_packed.p;
+        }
+        // pin the caller's table for the copy: the DMA engine then writes it directly (a copy into a pageable
+        // buffer it has not seen before runs at ~1 GB/s here, 8.9 ms for the 8 MB of C2; this way 0.5 ms)
+        const size_t bytes = (size_t)ctx->nq * row * sizeof(int32_t);
+        if (bytes >= (1u << 20)) {
+            if (hipHostRegister(scores_out, bytes, hipHostRegisterDefault) == hipSuccess) d.registered.push_back(scores_out);
+            else (void)hipGetLastError(); // e.g. already pinned by the caller: the plain copy below is still correct
+        }
+        HIP_TRY(hipMemcpyAsync(scores_out, src, bytes, hipMemcpyDeviceToHost, d.stream));
+        if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: D2H of the score table"); }
     }
     return 0;
 }
@@ -808,6 +880,7 @@ int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
         if (dev >= 0 && i != dev) continue;
         HIP_TRY(hipSetDevice(ctx->dev[i].id));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream));
+        release_registered(ctx->dev[i]);
     }
     return 0;
 }

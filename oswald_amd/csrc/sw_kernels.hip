@@ -303,22 +303,24 @@ struct CellSeqPair {
 
     template <int R, int RB, int P>
     struct Batch {
-        // s = scores of this row-block (paired), r1 = raw next block (in flight or landed), r2 = free
+        // s = scores of this row-block (paired), r1 = raw next block (in flight); once r1 has been
+        // paired up its registers take the load of the block after it (one block ahead is enough:
+        // a block is ~35 VALU instructions, LDS latency a fraction of that)
         static __device__ __forceinline__ void run(uint32_t a_lo, uint32_t a_hi, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge,
-                                                   T &score, T (&s)[4], Raw &r1, Raw &r2)
+                                                   T &score, T (&s)[4], Raw &r1)
         {
             T sn[4];
-            if constexpr (RB + 2 < R / 4) ld<RB + 2>(a_lo, a_hi, r2);
             if constexpr (RB + 1 < R / 4) {
-                if constexpr (RB + 2 < R / 4) landed<2>(r1); else landed<0>(r1);
+                landed<0>(r1);
                 pair_up(r1, sn);
+                if constexpr (RB + 2 < R / 4) ld<RB + 2>(a_lo, a_hi, r1);
             }
             A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s[1], ge, goe);
             A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s[2], ge, goe);
             A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s[3], ge, goe);
             if constexpr (RB + 1 < R / 4) {
                 A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn[0], ge, goe);
-                Batch<R, RB + 1, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, sn, r2, r1);
+                Batch<R, RB + 1, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, sn, r1);
             } else {
                 A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe);
             }
@@ -343,13 +345,13 @@ struct CellSeqPair {
             asm volatile("v_add_u32_sdwa %0, %2, " OSW_VC1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
                          "v_add_u32_sdwa %1, %2, " OSW_VC1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
                          : "=&v"(a_lo), "=&v"(a_hi) : "v"(base) : OSW_INFLIGHT);
-        Raw r0, r1, r2;
+        Raw r0, r1;
         T s[4];
         ld<0>(a_lo, a_hi, r0);
         if constexpr (R / 4 > 1) { ld<1>(a_lo, a_hi, r1); landed<2>(r0); } else { landed<0>(r0); }
         pair_up(r0, s);
         T x = A::first_diag(top_prev, s[0]);
-        Batch<R, 0, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, s, r1, r2);
+        Batch<R, 0, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, s, r1);
     }
 };
 
@@ -393,21 +395,19 @@ struct CellQueryPair {
     template <int R, int RB, int P>
     struct Batch {
         static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge, T &score,
-                                                   u32x4 &r0, u32x4 &r1, u32x4 &r2)
+                                                   u32x4 &r0, u32x4 &r1)
         {
-            // r0 = this row-block (landed), r1 = next (in flight), r2 = free
-            if constexpr (RB + 2 < R / 4) ld<RB + 2>(a, r2);
-            if constexpr (RB + 1 < R / 4) {
-                if constexpr (RB + 2 < R / 4) landed<1>(r1); else landed<0>(r1);
-            }
+            // r0 = this row-block (landed; .x was used by the row above), r1 = next (in flight); r0 takes
+            // the load of the block after next as soon as its last score has been read
             T s1 = as_v2s(r0.y), s2 = as_v2s(r0.z), s3 = as_v2s(r0.w);
             A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s1, ge, goe);
             A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s2, ge, goe);
             A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s3, ge, goe);
             if constexpr (RB + 1 < R / 4) {
+                if constexpr (RB + 2 < R / 4) { ld<RB + 2>(a, r0); landed<1>(r1); } else { landed<0>(r1); }
                 T sn = as_v2s(r1.x);
                 A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn, ge, goe);
-                Batch<R, RB + 1, P>::run(a, D, E, x, hl, goe, ge, score, r1, r2, r0);
+                Batch<R, RB + 1, P>::run(a, D, E, x, hl, goe, ge, score, r1, r0);
             } else {
                 A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe);
             }
@@ -429,11 +429,11 @@ struct CellQueryPair {
             asm volatile("v_bfe_u32 %0, " OSW_VC1 ", %2, 8\n\t"
                          "v_lshl_add_u32 %0, %0, 1, %1"
                          : "=&v"(a) : "v"(base), "s"(sh) : OSW_INFLIGHT);
-        u32x4 r0, r1, r2;
+        u32x4 r0, r1;
         ld<0>(a, r0);
         if constexpr (R / 4 > 1) { ld<1>(a, r1); landed<1>(r0); } else { landed<0>(r0); }
         T x = A::first_diag(top_prev, as_v2s(r0.x));
-        Batch<R, 0, P>::run(a, D, E, x, hl, goe, ge, score, r0, r1, r2);
+        Batch<R, 0, P>::run(a, D, E, x, hl, goe, ge, score, r0, r1);
     }
 };
 
