@@ -350,3 +350,21 @@ def test_pairing_is_invisible(hip_ctx, oracle, monkeypatch):
     on = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 12, 3)
     np.testing.assert_array_equal(on, off)
     np.testing.assert_array_equal(on, expect(oracle, qs, b, n, disp, 16, sm, 12, 3))
+
+
+@pytest.mark.parametrize("seq_len,qlen", [(9000, 300), (30000, 150)])
+def test_very_long_sequences_with_multi_round_queries(hip_ctx, oracle, seq_len, qlen):
+    """Blocks longer than a wave's spill region holds at G = 1 (4096 columns): the planner must pick a
+    geometry with fewer lanes per group, and the boundary row still has to come back exactly."""
+    q = synth.random_residues(5, 0, qlen)
+    long_seq = synth.random_residues(6, 0, seq_len)
+    hom = synth.mutate(q, 0.1, 3)[:qlen]
+    long_seq[seq_len // 2:seq_len // 2 + len(hom)] = hom
+    seqs = [synth.random_residues(200 + i, 0, 40 + i) for i in range(20)] + [long_seq, synth.random_residues(7, 0, seq_len - 17)]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, [q, q[:77]], b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, [q, q[:77]], b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want.max() > 300
