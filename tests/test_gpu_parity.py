@@ -368,3 +368,35 @@ def test_very_long_sequences_with_multi_round_queries(hip_ctx, oracle, seq_len, 
     want = expect(oracle, [q, q[:77]], b, n, disp, 16, sm, 10, 2)
     np.testing.assert_array_equal(got, want)
     assert want.max() > 300
+
+
+def test_two_devices_in_one_context(oracle):
+    """The reference drives several accelerators from one thread: chunk c of a round goes to device
+    c mod ndev, all are awaited together (FPGAsearch.c:132-138, :223).  Two context devices mapped onto
+    the one GPU of the test box exercise that path: per-device streams, buffers, queues and downloads."""
+    from oswald_amd import capi
+    qs = synth.make_queries([150, 61, 300, 290], seed=41)
+    L, R, O = random_db(900, seed=43, max_len=260, queries=qs, homologs=2)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
+    sm = submat.load("blosum62")
+    plan = dblayout.chunk_plan(nfull, 16, 40000, 2)
+    assert len(plan) >= 3
+    a, m, ad = pack_queries(qs)
+    with capi.Context(2, [0, 0]) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        parts = [None] * len(plan)
+        for k in range(0, len(plan), 2):
+            live = []
+            for d in range(min(2, len(plan) - k)):
+                g0, g1 = plan[k + d]
+                b, n, disp = dblayout.interleave(sl, sr, so, 16, g_begin=g0, g_end=g1)
+                out = np.full((len(qs), len(n) * 16), -3, np.int32)
+                ctx.search_chunk_async(b, n, disp.astype(np.uint32), out, 16, dev=d)
+                live.append((k + d, out, b, n, disp))  # keep the inputs alive until wait()
+            ctx.wait()
+            for idx, out, *_ in live:
+                parts[idx] = out
+    want = expect(oracle, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
+    np.testing.assert_array_equal(np.concatenate(parts, axis=1), want)
