@@ -6,43 +6,50 @@
 //
 // Formulation (MI355X-first, not a translation of the 28-wide FPGA pipeline):
 //   * inter-sequence parallel: a wave works on a "block" of 128 database
-//     sequences, 2 per lane, packed as the two 16-bit halves of a VGPR
-//     (v_pk_add_i16 clamp / v_pk_max_i16 / v_pk_sub_u16 clamp).  No MFMA: this
-//     is integer DP.  Packed-int16 VALU issues at 4 cycles per wave
-//     instruction per SIMD on gfx950 (measured, tools/ubench.hip), so the cell
-//     is kept at 9 VOP3P instructions + 1 v_perm_b32 and hand-scheduled.
+//     sequences, 2 per lane, packed as the two 16-bit halves of a VGPR.  No
+//     MFMA: this is a max-plus DP.  Packed 16-bit VALU issues at ~4 cycles per
+//     wave instruction per SIMD on gfx950 (measured, tools/ubench.hip), so the
+//     cell is kept as short as the ISA allows and hand-scheduled:
+//       - first pass in packed fp16 (exact for integers below 2048) with
+//         v_pk_maximum3_f16: 7.5 VOP3P instructions per row (+1 v_perm_b32 when
+//         a lane holds two sequences); an item in which a sequence reaches 2048
+//         is redone at once in packed int16 (9 / 10 instructions per row);
+//       - sequences that reach 32767 in int16 are queued for the int32 kernel
+//     (the reference's int8->int16->int32 escalation, host/src/HybridSearch.c:
+//     1670-1680,:1774-1784, yields exact scores; so does this).
 //   * the query is cut into strips of R <= 32 rows held in registers (E and
 //     the diagonal H of every row, 2 VGPRs per row); database columns stream
 //     through.  The strip's slice of the query profile lives in a wave-private
 //     LDS region and is read with conflict-free ds_read_b64 (4 rows per read,
-//     address = residue*8 + imm).
+//     address = 8*residue + imm; `tiled` stores 8*residue).
 //   * "wave geometry" G (1,2,4,...,64): the 64 lanes form G groups of 64/G
 //     lanes.  Group g runs strip (round*G + g) of the SAME 128/G sequences, one
-//     column behind group g-1, and receives that group's bottom row (H, F) and
-//     residues through ds_bpermute -- a systolic array inside the wave, no
-//     inter-wave synchronisation.  G = 1 is the plain case; G groups keep G
-//     strips' boundaries in registers (only every G-th strip boundary touches
-//     HBM) and shorten the critical path of heavy (long query x long sequence)
-//     items by G so that the work queue balances; G = 64 is the exact int32
-//     re-run of single lanes.
+//     column behind group g-1, and receives that group's bottom row (H, F)
+//     through ds_bpermute -- a systolic array inside the wave, no inter-wave
+//     synchronisation.  G = 1 is the plain case; G groups keep G strips'
+//     boundaries in registers (only every G-th strip boundary touches HBM) and
+//     shorten the critical path of heavy (long query x long sequence) items by
+//     G so that the work queue balances; G = 64 is the exact int32 re-run of
+//     single sequences.
+//   * query pairs: the two halves of a register can also hold two QUERIES of
+//     similar length against one sequence per lane (no v_perm_b32).
 //   * workgroup items: the four waves of a workgroup run four sub-blocks of one
 //     heavy item and share ONE 4x larger profile slice (taller rounds at the
 //     same G); two workgroup barriers per round are the only synchronisation.
 //   * between rounds the bottom row of the last group spills to a wave-private
-//     HBM scratch {H, F} per column and lane, read back two columns ahead.
-//   * work items (query, block, sub-block, G) are pulled from atomic queues
-//     sorted by cost (planned on the host, oswald_hip.cpp::build_items), so one
-//     launch covers all queries of a chunk; every wave exits when the queues
-//     are drained: nothing ever waits for another workgroup.
-//   * lanes that hit the int16 ceiling are queued on the device and re-run by
-//     the int32 kernel (the reference's int8->int16->int32 escalation,
-//     host/src/HybridSearch.c:1670-1680,:1774-1784, yields exact scores; so
-//     does this).
+//     HBM scratch {H, F} per column and lane and is loaded back two columns
+//     ahead, straight into fixed registers (see "Input registers of a column
+//     step"): the column loop spends 6 VALU instructions besides the cells.
+//   * work items (query or pair, block, sub-block, G) are pulled from atomic
+//     queues sorted by cost (planned on the host, oswald_hip.cpp::build_items),
+//     so one launch covers all queries of a chunk; every wave exits when the
+//     queues are drained: nothing ever waits for another workgroup.
 //
 // Recurrence (reference sw.cl:60-78): H = max(0, Hdiag + S, E, F);
 // E,F <- max(E|F - ge, H - (go+ge)).  E and F are kept clamped at >= 0, which
-// is equivalent because they only ever enter a max with H >= 0; it turns the
-// max(.,0) into the saturation of the unsigned packed subtract.
+// is equivalent because they only ever enter a max with H >= 0; in int16 it turns
+// the max(.,0) into the saturation of the unsigned packed subtract, in fp16 it
+// is the third operand of the maximum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sw_kernels.h"
