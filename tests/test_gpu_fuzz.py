@@ -29,7 +29,9 @@ def cases(draw):
                 homolog=draw(st.booleans()))
 
 
-@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+# OSWALD_FUZZ_EXAMPLES=N widens the campaign (and un-derandomises it with OSWALD_FUZZ_SEED set)
+@settings(max_examples=int(os.environ.get("OSWALD_FUZZ_EXAMPLES", "60")), deadline=None, derandomize="OSWALD_FUZZ_SEED" not in os.environ,
+          suppress_health_check=list(HealthCheck))
 @given(cases())
 def test_random_cases(hip_ctx, oracle, case):
     rng = np.random.default_rng(case["seed"])
