@@ -65,7 +65,10 @@ struct DevBuf {
         if (bytes <= cap) return hipSuccess;
         if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 5.0 && getenv("OSWALD_HIP_DEBUG_SLOW")) fprintf(stderr, "[oswald_hip] slow hipMalloc: %zu bytes took %.1f ms\n", want, ms);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
         return hipSuccess;
@@ -505,6 +508,17 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         d.grid = (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu;
         r = d.counters.reserve((2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
+        // Strip-boundary spill scratch: one region per resident wave and launch (two launches run side by side),
+        // allocated here because a multi-GB hipMalloc occasionally takes ~200 ms.  Every region starts with its
+        // zero page (never written afterwards) and its trash page.
+        {
+            const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
+            d.bnd_stride = OSW_SCRATCH_ENTRIES;
+            r = d.bnd.reserve(2 * slots * (d.bnd_stride + OSW_SCRATCH_DATA) * sizeof(uint2));
+            if (r == hipSuccess)
+                r = hipMemset2DAsync(d.bnd.p, (d.bnd_stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream);
+            if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: spill scratch: %s", d.id, hipGetErrorString(r)); }
+        }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
         // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
         // copy of a process takes ~10 ms, later ones run at ~20 GB/s) and the first launch of every kernel.
@@ -676,21 +690,8 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, d.stream));
     }
     if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("upload: H2D + re-tile"); }
-    // strip-boundary scratch: one region per resident wave, sized for the longest block
-    // {H,F} entries per wave slot: the longest block at G = 1, capped (longer blocks get a wider geometry, build_items)
-    const uint64_t stride = std::min<uint64_t>(((uint64_t)c.max_ncols4 * 4 + OSW_SCRATCH_PAD_COLS) * 64, OSW_SCRATCH_MAX_ENTRIES);
-    if (stride > d.bnd_stride) {
-        const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
-        HIP_TRY(hipStreamSynchronize(d.stream));
-        // two launches may be in flight side by side; every region starts with its zero and trash pages
-        const size_t bytes = 2 * slots * (stride + OSW_SCRATCH_DATA) * sizeof(uint2);
-        HIP_TRY(d.bnd.reserve(bytes));
-        // the zero page of every slot is never written again (the trash page may hold anything; cleared with it)
-        HIP_TRY(hipMemset2DAsync(d.bnd.p, (stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream));
-        d.bnd_stride = stride;
-    }
     HIP_TRY(hipStreamSynchronize(d.stream)); // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
-    pt.lap("upload: spill scratch + sync");
+    pt.lap("upload: sync");
     c.items_version = ~0ull;
     c.searched = false;
     c.live = true;
@@ -836,13 +837,18 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             HIP_TRY(hipMemcpy2DAsync(d.scores_packed.p, (size_t)row * sizeof(int32_t), c.scores.p, (size_t)c.score_stride * sizeof(int32_t),
                                      (size_t)row * sizeof(int32_t), ctx->nq, hipMemcpyDeviceToDevice, d.stream));
             src = d.scores_packed.p;
+            if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: pack score table"); }
         }
         // pin the caller's table for the copy: the DMA engine then writes it directly (a copy into a pageable
         // buffer it has not seen before runs at ~1 GB/s here, 8.9 ms for the 8 MB of C2; this way 0.5 ms)
         const size_t bytes = (size_t)ctx->nq * row * sizeof(int32_t);
-        if (bytes >= (1u << 20)) {
+        if (bytes >= (1u << 20) && !getenv("OSWALD_HIP_NO_PIN")) {
+            const auto t0 = std::chrono::steady_clock::now();
             if (hipHostRegister(scores_out, bytes, hipHostRegisterDefault) == hipSuccess) d.registered.push_back(scores_out);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > 5.0 && getenv("OSWALD_HIP_DEBUG_SLOW")) fprintf(stderr, "[oswald_hip] slow hipHostRegister: %zu bytes took %.1f ms\n", bytes, ms);
             else (void)hipGetLastError(); // e.g. already pinned by the caller: the plain copy below is still correct
+            pt.lap("search: pin caller's table");
         }
         HIP_TRY(hipMemcpyAsync(scores_out, src, bytes, hipMemcpyDeviceToHost, d.stream));
         if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: D2H of the score table"); }

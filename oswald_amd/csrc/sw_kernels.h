@@ -13,8 +13,9 @@
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
 #define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
 #define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64), kept zero
-#define OSW_SCRATCH_MAX_ENTRIES ((4096u + OSW_SCRATCH_PAD_COLS) * 64u) // cap of a wave's spill columns ({H,F} entries, 2.1 MB):
-                                                                      // longer blocks must run at a geometry with fewer lanes per group
+#define OSW_SCRATCH_ENTRIES ((4096u + OSW_SCRATCH_PAD_COLS) * 32u) // a wave's spill columns ({H,F} entries, 1.07 MB): a 4096-column
+                                                                   // block at 32 lanes per group (G = 2); longer blocks, or G = 1 beyond
+                                                                   // 2012 columns, run at a geometry with fewer lanes per group
 // A wave's spill region: 64 entries that stay zero (the "row above" of a first round), 64 entries
 // that absorb the stores of steps / rounds that have nothing to spill, then the columns.
 #define OSW_SCRATCH_ZERO 0

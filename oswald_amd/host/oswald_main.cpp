@@ -173,8 +173,13 @@ int do_search(Options &o)
         fprintf(stderr, "OSWALD: hybrid mode (-m 1) splits work between host SIMD and the accelerator; this build runs the whole "
                         "database on the GPU(s) (as -m 0).\n");
 
+    const bool phases = getenv("OSWALD_DEBUG_PHASES") != nullptr; // wall time of the host-side phases, to stderr
+    double tp = dwalltime();
+    auto lap = [&](const char *what) { if (phases) { const double t = dwalltime(); fprintf(stderr, "[oswald] %-34s %8.3f ms\n", what, (t - tp) * 1e3); tp = t; } };
     oswald::Queries q = oswald::load_query_sequences(o.queries);
+    lap("load queries");
     oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, o.num_devices);
+    lap("load database + assemble chunks");
     const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength;
 
     printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)db.sequences_count, (long)db.D);
@@ -191,6 +196,7 @@ int do_search(Options &o)
     // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80)
     oswald_hip_ctx *ctx = nullptr;
     check(oswald_hip_init((int)o.num_devices, nullptr, &ctx), "device bring-up");
+    lap("device bring-up");
     const double tick = dwalltime();
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
@@ -212,9 +218,12 @@ int do_search(Options &o)
         }
     }
     const double workTime = dwalltime() - tick;
+    lap("search (timed region)");
     oswald_hip_finalize(ctx);
+    lap("device release");
 
     const std::vector<std::string> headers = oswald::load_database_headers(o.db, db.sequences_count);
+    lap("load headers");
     std::vector<int32_t> ts;
     std::vector<uint64_t> ti;
     for (uint64_t i = 0; i < nq; ++i) {
@@ -228,6 +237,7 @@ int do_search(Options &o)
             printf("%d\t%s\n", ts[j], h.empty() ? "" : h.c_str() + 1);
         }
     }
+    lap("top scores + report");
     printf("\nSearch date:\t\t\t%s", ctime(&current_time));
     printf("Search time:\t\t\t%lf seconds\n", workTime);
     printf("Search speed:\t\t\t%.2lf GCUPS\n", (double)(q.Q * db.D) / (workTime * 1000000000));
