@@ -94,6 +94,7 @@ struct OswBlock {
 struct OswSearchArgs {
     const uint16_t *tiled;     // [col][64 lanes] {8*residue of seq 2l, 8*residue of seq 2l+1}
     const OswBlock *blocks;
+    const uint16_t *sub_cols;  // [block][128]: live columns of sub-block sigma at geometry G, at (G-1) + sigma
     const uint2 *items;        // work queue, heaviest first: nitems_wg workgroup items, then nitems wave items
     uint32_t nitems;
     uint32_t nitems_wg;
@@ -127,7 +128,7 @@ hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          uint4 *prof_pair, hipStream_t s);
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
-                             OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, hipStream_t s);
+                             OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
                                     const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, uint2 *prof, hipStream_t s);
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,

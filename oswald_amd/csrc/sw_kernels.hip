@@ -68,7 +68,8 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // of the column live in two alternating register sets (even / odd column):
 //   H, F : written for ALL lanes by the ds_bpermute hand-off at the end of the
 //          previous step (lane groups 1.. take the bottom row of the group
-//          below; the lanes of group 0 receive junk),
+//          below; the lanes of group 0 receive junk); one register each: a
+//          step reads them before its own hand-off overwrites them,
 //   LH,LF: for the lanes of group 0, the boundary row of the previous round,
 //          LOADED from the spill scratch two columns ahead; merged into H / F
 //          with one EXEC-masked v_mov each,
@@ -83,17 +84,15 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // written by name inside the asm text only.  tests/test_isa_inflight.py checks
 // the generated ISA: no compiler-scheduled instruction touches them.
 // ---------------------------------------------------------------------------
-#define OSW_VH0 "v118"
-#define OSW_VF0 "v119"
-#define OSW_VC0 "v120"
-#define OSW_VLH0 "v121"
-#define OSW_VLF0 "v122"
-#define OSW_VH1 "v123"
-#define OSW_VF1 "v124"
-#define OSW_VC1 "v125"
+#define OSW_VH "v120"   // H of the row above: handed over at the end of a step, read at the end of the next
+#define OSW_VF "v121"   // F of the row above, then the F chain of the step (in place), then handed on
+#define OSW_VC0 "v122"  // residues, even / odd column (loaded two columns ahead)
+#define OSW_VC1 "v123"
+#define OSW_VLH0 "v124" // boundary row of the previous round, group 0, even / odd column (loaded two ahead)
+#define OSW_VLF0 "v125"
 #define OSW_VLH1 "v126"
 #define OSW_VLF1 "v127"
-#define OSW_INFLIGHT "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define OSW_INFLIGHT "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
 // ---------------------------------------------------------------------------
 // Packed-int16 cell, hand-scheduled.  State per row r: E[r] and D[r] =
@@ -214,14 +213,12 @@ struct ArithI16 {
     template <int P, bool ODD>
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s /*Dp*/, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe)
     {
-        if constexpr (P == 0) OSW_PK16_ROW(OSW_VF0, x, Er, Dn, sc, s_next, ge, goe);
-        else OSW_PK16_ROW(OSW_VF1, x, Er, Dn, sc, s_next, ge, goe);
+        OSW_PK16_ROW(OSW_VF, x, Er, Dn, sc, s_next, ge, goe);
     }
     template <int P>
     static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s /*Dp*/, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe)
     {
-        if constexpr (P == 0) OSW_PK16_ROW_LAST(OSW_VF0, x, Er, hl, sc, ge, goe);
-        else OSW_PK16_ROW_LAST(OSW_VF1, x, Er, hl, sc, ge, goe);
+        OSW_PK16_ROW_LAST(OSW_VF, x, Er, hl, sc, ge, goe);
     }
     static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0) { return __builtin_elementwise_add_sat(top_prev, s0); }
     static __device__ __forceinline__ int to_int(short bits) { return bits; }
@@ -237,20 +234,14 @@ struct ArithF16 {
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t nge, uint32_t ngoe)
     {
         v2s xn;
-        if constexpr (ODD) {
-            if constexpr (P == 0) OSW_F16_ROW_ODD(OSW_VF0, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe);
-            else OSW_F16_ROW_ODD(OSW_VF1, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe);
-        } else {
-            if constexpr (P == 0) OSW_F16_ROW_EVEN(OSW_VF0, x, xn, Er, Dn, s_next, nge, ngoe);
-            else OSW_F16_ROW_EVEN(OSW_VF1, x, xn, Er, Dn, s_next, nge, ngoe);
-        }
+        if constexpr (ODD) OSW_F16_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe);
+        else OSW_F16_ROW_EVEN(OSW_VF, x, xn, Er, Dn, s_next, nge, ngoe);
         x = xn;
     }
     template <int P>
     static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t nge, uint32_t ngoe)
     {
-        if constexpr (P == 0) OSW_F16_ROW_LAST(OSW_VF0, x, Er, hl, Dp, sc, nge, ngoe);
-        else OSW_F16_ROW_LAST(OSW_VF1, x, Er, hl, Dp, sc, nge, ngoe);
+        OSW_F16_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, nge, ngoe);
     }
     static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0)
     {
@@ -518,39 +509,42 @@ static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 // Per column on top of the cells: 2 VALU (LDS addresses) + 1 (first diagonal
 // add) + 1 (top_prev) + 2 (group 0 merges); the rest is SALU, LDS and VMEM.
 // ---------------------------------------------------------------------------
-#define OSW_STEP_BEGIN_ASM(FP, LFP)                                                                          \
+#define OSW_STEP_BEGIN_ASM(LFP)                                                                              \
     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\t"                                                         \
                  "s_mov_b64 %[sv], exec\n\t"                                                                 \
                  "s_mov_b64 exec, %[mg0]\n\t"                                                                \
-                 "v_mov_b32 " FP ", " LFP "\n\t"                                                             \
+                 "v_mov_b32 " OSW_VF ", " LFP "\n\t"                                                         \
                  "s_mov_b64 exec, %[sv]"                                                                     \
                  : [sv] "=&s"(sv)                                                                            \
                  : [mg0] "s"(m_g0)                                                                           \
                  : "memory", OSW_INFLIGHT)
 
-#define OSW_STEP_END_ASM(HP, FP, CP, LHP, LFP, HQ, FQ)                                                       \
-    asm volatile("v_mov_b32 %[tp], " HP "\n\t"                                                               \
+// end of a step: top_prev for the next step (H of the row above of THIS step), spill of the last group's bottom
+// row, hand-off to the group above (H and F are overwritten by it: everything that reads them comes first), then
+// the loads for the next-but-one column
+#define OSW_STEP_END_ASM(CP, LHP, LFP)                                                                       \
+    asm volatile("v_mov_b32 %[tp], " OSW_VH "\n\t"                                                           \
                  "s_mov_b64 %[sv], exec\n\t"                                                                 \
                  "s_mov_b64 exec, %[mg0]\n\t"                                                                \
                  "v_mov_b32 %[tp], " LHP "\n\t"                                                              \
-                 "s_mov_b64 exec, %[mbp]\n\t"                                                                \
-                 "s_cbranch_execz 1f\n\t"                                                                    \
-                 "s_mov_b64 exec, %[sv]\n\t"                                                                 \
-                 "ds_bpermute_b32 " HQ ", %[src], %[ho]\n\t"                                                 \
-                 "ds_bpermute_b32 " FQ ", %[src], " FP "\n"                                                  \
-                 "1:\n\t"                                                                                    \
                  "s_mov_b64 exec, %[mst]\n\t"                                                                \
                  "global_store_dword %[voff], %[ho], %[sptr]\n\t"                                            \
-                 "global_store_dword %[voff], " FP ", %[sptr] offset:4\n\t"                                  \
+                 "global_store_dword %[voff], " OSW_VF ", %[sptr] offset:4\n\t"                              \
+                 "s_not_b64 exec, %[mg0]\n\t"                                                                \
+                 "s_cbranch_execz 1f\n\t"                                                                    \
+                 "s_mov_b64 exec, %[sv]\n\t"                                                                 \
+                 "ds_bpermute_b32 " OSW_VH ", %[src], %[ho]\n\t"                                             \
+                 "ds_bpermute_b32 " OSW_VF ", %[src], " OSW_VF "\n"                                           \
+                 "1:\n\t"                                                                                    \
                  "s_mov_b64 exec, %[mg0]\n\t"                                                                \
                  "global_load_dword " LHP ", %[voff], %[lptr]\n\t"                                           \
                  "global_load_dword " LFP ", %[voff], %[lptr] offset:4\n\t"                                  \
                  "s_mov_b64 exec, %[sv]\n\t"                                                                 \
                  "global_load_ushort " CP ", %[voffc], %[tptr]"                                              \
                  : [tp] "=&v"(tp), [sv] "=&s"(sv)                                                            \
-                 : [src] "v"(src), [ho] "v"(ho), [voff] "v"(voff), [voffc] "v"(voffc), [mbp] "s"(m_bp), [mst] "s"(m_st), \
+                 : [src] "v"(src), [ho] "v"(ho), [voff] "v"(voff), [voffc] "v"(voffc), [mst] "s"(m_st),       \
                    [mg0] "s"(m_g0), [sptr] "s"(sptr), [lptr] "s"(lptr), [tptr] "s"(tptr)                      \
-                 : "memory", OSW_INFLIGHT)
+                 : "memory", "scc", OSW_INFLIGHT)
 
 template <class C, int R>
 static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
@@ -563,7 +557,6 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     for (int r = 0; r < R; ++r) { D[r] = C::zero(); E[r] = C::zero(); }
     T top_prev = C::zero(); // H(i0-1, j-1)
     const uint64_t m_g0 = gl >= 64 ? ~0ull : (1ull << gl) - 1ull; // lanes of group 0
-    const uint64_t m_bp = ~m_g0;                                   // lanes that are handed their inputs (empty: no hand-off)
     const uint64_t m_st = ~0ull << (64u - gl);                     // lanes of the last group
     const uint32_t src = (uint32_t)((lane - (int)gl) & 63) << 2;   // ds_bpermute source: the lane one group below
     const uint32_t g = (uint32_t)lane / gl;
@@ -579,10 +572,8 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * 128u;
     uint64_t sv;
     // nothing has been handed over yet: zeros; columns 0 and 1 of the stream
-    asm volatile("v_mov_b32 " OSW_VH0 ", 0\n\t"
-                 "v_mov_b32 " OSW_VF0 ", 0\n\t"
-                 "v_mov_b32 " OSW_VH1 ", 0\n\t"
-                 "v_mov_b32 " OSW_VF1 ", 0\n\t"
+    asm volatile("v_mov_b32 " OSW_VH ", 0\n\t"
+                 "v_mov_b32 " OSW_VF ", 0\n\t"
                  "global_load_ushort " OSW_VC0 ", %[voffc], %[tptr]\n\t"
                  "global_load_ushort " OSW_VC1 ", %[voffc], %[tptr] offset:128\n\t"
                  "s_mov_b64 %[sv], exec\n\t"
@@ -602,22 +593,22 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
 #pragma unroll 1
     for (uint32_t t = 0; t < nsteps; t += 2) {
         {
-            OSW_STEP_BEGIN_ASM(OSW_VF0, OSW_VLF0);
+            OSW_STEP_BEGIN_ASM(OSW_VLF0);
             T hl, tp;
             C::template column<R, 0>(base, half, D, E, top_prev, hl, goe, ge, score);
             const uint32_t ho = C::to_bits(hl);
-            OSW_STEP_END_ASM(OSW_VH0, OSW_VF0, OSW_VC0, OSW_VLH0, OSW_VLF0, OSW_VH1, OSW_VF1);
+            OSW_STEP_END_ASM(OSW_VC0, OSW_VLH0, OSW_VLF0);
             top_prev = tp;
             sptr += sstep;
             lptr += lstep;
             tptr += 128;
         }
         if (t + 1 < nsteps) {
-            OSW_STEP_BEGIN_ASM(OSW_VF1, OSW_VLF1);
+            OSW_STEP_BEGIN_ASM(OSW_VLF1);
             T hl, tp;
             C::template column<R, 1>(base, half, D, E, top_prev, hl, goe, ge, score);
             const uint32_t ho = C::to_bits(hl);
-            OSW_STEP_END_ASM(OSW_VH1, OSW_VF1, OSW_VC1, OSW_VLH1, OSW_VLF1, OSW_VH0, OSW_VF0);
+            OSW_STEP_END_ASM(OSW_VC1, OSW_VLH1, OSW_VLF1);
             top_prev = tp;
             sptr += sstep;
             lptr += lstep;
@@ -729,15 +720,16 @@ static __device__ __forceinline__ void load_profile_round(const uint4 *prof_q, u
 // every round: as soon as any lane of the wave (workgroup) has reached it the
 // item is abandoned (`hit`) and the caller redoes it in packed int16.
 template <class C, bool WG>
-static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, const uint2 *prof, uint32_t q, const OswBlock &blk, uint32_t sigma,
-                                                         uint32_t lg, int lane, int half, uint2 *lds_region, uint2 *bnd_wave,
+static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, const uint2 *prof, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
+                                                         uint32_t lg, int lane, int half, uint2 *lds_region, uint32_t *wg_hit, uint2 *bnd_wave,
                                                          typename C::GapT goe, typename C::GapT ge, bool &hit)
 {
     typedef typename C::T T;
     constexpr uint32_t kLds = WG ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
     const uint32_t G = 1u << lg, gl = 64u >> lg;
     const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
-    const uint32_t ncols = __builtin_amdgcn_readfirstlane(blk.ncols4) * 4;
+    // the item's extent: the longest sequence of its sub-block
+    const uint32_t ncols = __builtin_amdgcn_readfirstlane((uint32_t)p.sub_cols[(size_t)B * 128 + (G - 1u) + sigma]);
     const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
     uint2 *bnd = (uint2 *)osw_uniform64((uint64_t)bnd_wave);
     const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
@@ -752,21 +744,28 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     T score = C::zero();
     bool lane_hit = false;
     hit = false;
+    // Workgroup-wide "some sequence has reached the ceiling": the waves OR into wg_hit[round & 1] before the
+    // barrier that opens a round and read it after; thread 0 clears the other flag between the round's two
+    // barriers, i.e. strictly before anybody can OR into it again.
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, nrb = G * R / 4, rb_end = plan.m4 / 4;
         if constexpr (WG) {
-            // every wave is done with the previous slice (and says whether it has hit the ceiling)
             if constexpr (C::kEarlyExit) {
-                if (__syncthreads_or(lane_hit ? 1 : 0)) { hit = true; break; }
-            } else {
-                __syncthreads();
+                if (rho > 0 && __any(lane_hit ? 1 : 0) && lane == 0) atomicOr(&wg_hit[rho & 1], 1u);
             }
+            __syncthreads(); // every wave is done with the previous slice
+            if constexpr (C::kEarlyExit) {
+                if (__builtin_amdgcn_readfirstlane(*(volatile uint32_t *)&wg_hit[rho & 1])) { hit = true; break; }
+                if (threadIdx.x == 0) wg_hit[(rho + 1) & 1] = 0;
+            }
+            uint32_t tid = threadIdx.x;
+            asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
             const uint4 *src = prof_q + (size_t)rb0 * rb16;
             uint4 *dst = (uint4 *)lds_region;
             const uint32_t n16 = nrb * rb16;
             const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * rb16 : 0;
-            for (uint32_t i = threadIdx.x; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
+            for (uint32_t i = tid; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
             __syncthreads();
         } else {
             if constexpr (C::kEarlyExit) {
@@ -779,14 +778,28 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         if constexpr (C::kEarlyExit) lane_hit = C::at_ceiling(score);
     }
     if constexpr (C::kEarlyExit) {
-        if (!hit) {
-            if constexpr (WG) hit = __syncthreads_or(lane_hit ? 1 : 0) != 0;
-            else hit = __any(lane_hit ? 1 : 0) != 0;
+        if constexpr (WG) {
+            if (!hit) {
+                const uint32_t rho = plan.rounds;
+                if (__any(lane_hit ? 1 : 0) && lane == 0) atomicOr(&wg_hit[rho & 1], 1u);
+                __syncthreads();
+                hit = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)&wg_hit[rho & 1]) != 0;
+                if (!hit && threadIdx.x == 0) wg_hit[(rho + 1) & 1] = 0;
+            }
+            if (hit) { // leave both flags clean for the next item (the redo opens with a barrier of its own)
+                __syncthreads();
+                if (threadIdx.x == 0) { wg_hit[0] = 0; wg_hit[1] = 0; }
+            }
+        } else {
+            if (!hit) hit = __any(lane_hit ? 1 : 0) != 0;
         }
     }
-    // best over the strips = best over the lane groups
+    // best over the strips = best over the lane groups (the lane index is laundered so that the permute
+    // addresses are computed here instead of being kept in registers across all the rounds)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     for (uint32_t off = gl; off < 64; off <<= 1)
-        score = C::vmax(score, C::from_bits((uint32_t)__shfl_xor((int)C::to_bits(score), (int)off)));
+        score = C::vmax(score, C::from_bits((uint32_t)__builtin_amdgcn_ds_bpermute((ln ^ (int)off) << 2, (int)C::to_bits(score))));
     return score;
 }
 
@@ -860,6 +873,8 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8];
     __shared__ uint32_t wg_item;
+    __shared__ uint32_t wg_hit[2]; // see run_item
+    if (threadIdx.x < 2) wg_hit[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
@@ -900,9 +915,9 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             bool hit;
-            v2s score = run_item<C, true>(p, p.prof, q, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk, hit);
+            v2s score = run_item<C, true>(p, p.prof, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
             if (C::kEarlyExit && hit) {
-                score = run_item<CF, true>(p, p.prof_fb, q, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_fb, p.ge_fb, hit);
+                score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], wg_hit, bnd_wave, p.goe_fb, p.ge_fb, hit);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
             } else {
@@ -931,9 +946,9 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             bool hit;
-            v2s score = run_item<C, false>(p, p.prof, q, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk, hit);
+            v2s score = run_item<C, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_prof[wv], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
             if (C::kEarlyExit && hit) {
-                score = run_item<CF, false>(p, p.prof_fb, q, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_fb, p.ge_fb, hit);
+                score = run_item<CF, false>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, lds_prof[wv], wg_hit, bnd_wave, p.goe_fb, p.ge_fb, hit);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
             } else {
@@ -990,7 +1005,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
             bool hit;
-            const int score = run_item<CellI32, false>(p, p.prof, q, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge, hit);
+            const int score = run_item<CellI32, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_wave, nullptr, bnd_wave, p.goe, p.ge, hit);
             if ((uint32_t)lane < gl)
                 p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }
@@ -1034,24 +1049,32 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__re
     }
 }
 
-// Trailing columns in which every sequence of the block holds the dummy
-// residue score 0 against everything (reference submat.c: column 23 is zero)
-// and therefore cannot raise any maximum: drop them from the block's extent.
-extern "C" __global__ __launch_bounds__(64) void osw_block_extent(OswBlock *blocks, const uint16_t *__restrict__ tiled)
+// Live extents.  Columns past a sequence's end hold the dummy residue, which scores 0 against
+// everything (reference submat.c: column 23 is zero) and therefore cannot raise any maximum: an item
+// stops at the longest sequence of ITS sub-block (the sequences are sorted by length, so this trims
+// almost all padding).  sub_cols[B*128 + (G-1) + sigma] = columns up to the last real residue of
+// sub-block sigma at geometry G (a binary heap over the 64 lanes: G = 1 is the whole block, G = 64 a
+// single lane); blocks[B].ncols4 = 4-column groups of the whole block.
+extern "C" __global__ __launch_bounds__(128) void osw_block_extent(OswBlock *blocks, const uint16_t *__restrict__ tiled, uint16_t *__restrict__ sub_cols)
 {
+    __shared__ uint32_t lane_n[64];
     const uint32_t B = blockIdx.x;
-    const int lane = threadIdx.x;
+    const uint32_t t = threadIdx.x;
     const OswBlock blk = blocks[B];
     const uint16_t dummy = (uint16_t)(OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8));
-    uint32_t c4 = blk.ncols4_alloc;
-    while (c4 > 0) {
-        bool live = false;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) live |= tiled[((size_t)(blk.col4_off + c4 - 1) * 4 + k) * 64 + lane] != dummy;
-        if (__any(live)) break;
-        --c4;
+    if (t < 64) {
+        uint32_t n = blk.ncols4_alloc * 4;
+        while (n > 0 && tiled[((size_t)blk.col4_off * 4 + n - 1) * 64 + t] == dummy) --n;
+        lane_n[t] = n;
     }
-    if (lane == 0) blocks[B].ncols4 = c4;
+    __syncthreads();
+    if (t < 127) {
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(t + 1u), sigma = t + 1u - (1u << lg), gl = 64u >> lg;
+        uint32_t mx = 0;
+        for (uint32_t k = 0; k < gl; ++k) mx = lane_n[sigma * gl + k] > mx ? lane_n[sigma * gl + k] : mx;
+        sub_cols[(size_t)B * 128 + t] = (uint16_t)mx;
+        if (t == 0) blocks[B].ncols4 = (mx + 3) / 4;
+    }
 }
 
 // Query profile in the layout the search kernels read:
@@ -1224,12 +1247,12 @@ hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 }
 
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
-                             OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, hipStream_t s)
+                             OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL(osw_retile, dim3(nblocks), dim3(256), 0, s, b, n, disp, ngroups, W, (const OswBlock *)blocks, tiled);
     OSW_LAUNCH_CHECK();
-    hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(64), 0, s, blocks, (const uint16_t *)tiled);
+    hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(128), 0, s, blocks, (const uint16_t *)tiled, sub_cols);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

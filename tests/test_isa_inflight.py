@@ -24,7 +24,7 @@ def _reserved():
     text = open(SRC).read()
     m = re.search(r'#define OSW_INFLIGHT (.*)', text)
     regs = [int(x) for x in re.findall(r'"v(\d+)"', m.group(1))]
-    assert len(regs) == 10
+    assert len(regs) == 8
     return set(regs)
 
 
