@@ -82,8 +82,10 @@ struct Chunk {
     uint32_t score_stride = 0;   // nblocks*128
     uint32_t max_ncols4 = 0;     // largest stored extent of a block
     uint64_t total_col4 = 0;     // stored 4-column groups incl. the pad group per block
-    DevBuf tiled, blocks, sub_cols, items, items_q, scores, ovf;
+    DevBuf tiled, blocks, sub_cols_buf, items, items_q, scores, ovf;
+    const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
+    std::vector<uint16_t> sub_cols;     // host copy of the live extents (see osw_block_extent), for the planner
     uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
     uint32_t nitems_q = 0, nitems_q_wg = 0; // the same for the query-pair kernel's queue
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
@@ -384,11 +386,12 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
                 while ((4u << lg) > (wg ? kd.ldsr * wgx : kd.ldsr) && lg > 0) --lg;
                 if (lg < lg_scratch) return fail(OSWALD_HIP_EINVAL, "a sequence block of %u columns does not fit the spill scratch at any geometry", ncols);
             }
-            cost = item_cost(e, lg, ncols, wg);
             const uint32_t G = 1u << lg;
             c.max_lg = std::max(c.max_lg, lg);
-            if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg[e.kind].push_back({cost, OSW_ITEM_PACK(e.id, s, lg, 3u), b});
-            else for (uint32_t s = 0; s < G; ++s) its[e.kind].push_back({cost, OSW_ITEM_PACK(e.id, s, lg, 3u), b});
+            // an item runs to the last real residue of its own sub-block (workgroup item: of its four sub-blocks)
+            const uint16_t *sc = c.sub_cols.data() + (size_t)b * 128 + (G - 1);
+            if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg[e.kind].push_back({item_cost(e, lg, std::max(std::max(sc[s], sc[s + 1]), std::max(sc[s + 2], sc[s + 3])), wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
+            else for (uint32_t s = 0; s < G; ++s) its[e.kind].push_back({item_cost(e, lg, sc[s], wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
         }
     auto by_cost = [](const It &x, const It &y) { return x.cost > y.cost; };
     // issue priority of the long items (see set_wave_prio in sw_kernels.hip)
@@ -554,7 +557,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         release_registered(d);
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_f16, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
                           &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.wg_times, &d.scores_packed})
             b->release();
@@ -676,7 +679,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     c.total_col4 = off;
     HIP_TRY(c.tiled.reserve((off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2)));
     HIP_TRY(c.blocks.reserve(c.nblocks * sizeof(OswBlock) + 16));
-    HIP_TRY(c.sub_cols.reserve((size_t)c.nblocks * 128 * sizeof(uint16_t) + 16));
+    HIP_TRY(c.sub_cols_buf.reserve((size_t)c.nblocks * 128 * sizeof(uint16_t) + 16));
     HIP_TRY(d.staging_b.reserve(vD + 64));
     HIP_TRY(d.staging_n.reserve(ngroups * sizeof(uint16_t) + 16));
     HIP_TRY(d.staging_disp.reserve(ngroups * sizeof(uint32_t) + 16));
@@ -688,9 +691,11 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         HIP_TRY(hipMemcpyAsync(c.blocks.p, blocks.data(), c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemsetAsync(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), d.stream)); // pads = dummy residue
         HIP_TRY(osw_launch_retile((const uint8_t *)d.staging_b.p, (const uint16_t *)d.staging_n.p, (const uint32_t *)d.staging_disp.p,
-                                  ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, (uint16_t *)c.sub_cols.p, d.stream));
+                                  ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, (uint16_t *)c.sub_cols_buf.p, d.stream));
     }
     if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("upload: H2D + re-tile"); }
+    c.sub_cols.assign((size_t)c.nblocks * 128, 0);
+    if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols.data(), c.sub_cols_dev(), c.sub_cols.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipStreamSynchronize(d.stream)); // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
     pt.lap("upload: sync");
     c.items_version = ~0ull;
@@ -718,7 +723,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     memset(&a, 0, sizeof a);
     a.tiled = (const uint16_t *)c.tiled.p;
     a.blocks = (const OswBlock *)c.blocks.p;
-    a.sub_cols = (const uint16_t *)c.sub_cols.p;
+    a.sub_cols = c.sub_cols_dev();
     a.items = (const uint2 *)c.items.p;
     a.nitems = c.nitems;
     a.nitems_wg = c.nitems_wg;
