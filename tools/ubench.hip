@@ -78,6 +78,44 @@ __global__ __launch_bounds__(256) void f16_rate(uint32_t *out, uint32_t c1, uint
     if (acc == 0x12345678u) out[threadIdx.x] = acc;
 }
 
+// Issue rate of single VALU instruction kinds under a sustained load, in CORE CLOCK cycles: s_memtime
+// (core clock counter) and s_memrealtime (100 MHz) are read inside the kernel, so neither launch overhead
+// nor an assumed frequency enters.  OP: 0 v_pk_add_f16, 1 v_pk_maximum3_f16, 2 v_pk_add_i16 clamp,
+// 3 v_pk_max_i16, 4 v_perm_b32, 5 v_mov_b32, 6 alternating add_f16 / maximum3_f16.  8 independent chains.
+template <int OP>
+__global__ __launch_bounds__(256) void clk_probe(unsigned long long *out, uint32_t c1, uint32_t c2, int iters)
+{
+    extern __shared__ uint32_t pad_lds[]; // sized by the host so that exactly `waves per SIMD` workgroups fit a CU
+    if (iters < 0) pad_lds[threadIdx.x] = c1;
+    uint32_t x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0x3c003c00u + threadIdx.x + i;
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (OP == 0) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(x[i]) : "v"(c1));
+                if constexpr (OP == 1) asm volatile("v_pk_maximum3_f16 %0, %0, %1, 0" : "+v"(x[i]) : "v"(c2));
+                if constexpr (OP == 2) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(x[i]) : "v"(c1));
+                if constexpr (OP == 3) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(x[i]) : "v"(c2));
+                if constexpr (OP == 4) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c2), "s"(0x07060302u));
+                if constexpr (OP == 5) asm volatile("v_mov_b32 %0, %1" : "=v"(x[i]) : "v"(c2));
+                if constexpr (OP == 6) {
+                    if (k == 0) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(x[i]) : "v"(c1));
+                    else asm volatile("v_pk_maximum3_f16 %0, %0, %1, 0" : "+v"(x[i]) : "v"(c2));
+                }
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc ^= x[i];
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0 + (acc == 0x12345678u); out[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
 // LDS: ds_read_b64 of 4 profile rows at residue*8 + imm, 16 reads per "column"
 __global__ __launch_bounds__(256) void lds_rate(uint32_t *out, const uint32_t *res, int iters)
 {
@@ -165,6 +203,36 @@ int main(int argc, char **argv)
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
+    if (argc > 1 && !strcmp(argv[1], "clk")) {
+        const int iters = 100000;
+        unsigned long long *o; hipMalloc(&o, cus * 8 * 16);
+        const char *names[7] = {"v_pk_add_f16", "v_pk_maximum3_f16", "v_pk_add_i16 clamp", "v_pk_max_i16", "v_perm_b32", "v_mov_b32", "add_f16/maximum3_f16"};
+        for (int wps = 1; wps <= 8; wps *= 2) {
+            for (int op = 0; op < 7; ++op) {
+                const int nb = cus * wps;
+                const size_t lds = (size_t)(160 * 1024 / wps) - 1024; // exactly wps workgroups per CU: one wave of each per SIMD
+                auto launch = [&](auto kern) {
+                    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, 0, o, 0x3c003c00u, 0x40004000u, iters);
+                };
+                switch (op) {
+                case 0: launch(clk_probe<0>); break; case 1: launch(clk_probe<1>); break; case 2: launch(clk_probe<2>); break;
+                case 3: launch(clk_probe<3>); break; case 4: launch(clk_probe<4>); break; case 5: launch(clk_probe<5>); break;
+                default: launch(clk_probe<6>); break;
+                }
+                hipDeviceSynchronize();
+                std::vector<unsigned long long> h(nb * 2);
+                hipMemcpy(h.data(), o, nb * 16, hipMemcpyDeviceToHost);
+                double cyc = 0, ref = 0, cmax = 0, cmin = 1e30;
+                for (int i = 0; i < nb; ++i) { cyc += (double)h[2 * i]; ref += (double)h[2 * i + 1]; cmax = std::max(cmax, (double)h[2 * i]); cmin = std::min(cmin, (double)h[2 * i]); }
+                // workgroups start staggered, so the early and late ones run partly alone: the slowest one shared its
+                // SIMDs with wps-1 others all the way and gives the loaded rate
+                printf("clk %-22s waves/SIMD=%d: %6.0f MHz, %5.2f core cycles per wave instruction per SIMD (from the slowest workgroup; cycles min %.3g avg %.3g max %.3g)\n",
+                       names[op], wps, cyc / ref * 100.0, cmax / ((double)iters * 16) / wps, cmin, cyc / nb, cmax);
+            }
+        }
+        return 0;
+    }
     printf("device %s, %d CUs, clock %d MHz\n", p.name, cus, p.clockRate / 1000);
     uint32_t *out, *res;
     hipMalloc(&out, 4096);
