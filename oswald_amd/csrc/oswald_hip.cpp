@@ -614,6 +614,7 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (nq > 0 && (!m || !a_disp || (Q > 0 && !a))) return fail(OSWALD_HIP_EINVAL, "null query arrays");
+    if (nq > 65535) return fail(OSWALD_HIP_EINVAL, "at most 65535 queries per set (work items carry a 16-bit query index); search in several sets");
     for (uint32_t q = 0; q < nq; ++q)
         if ((uint64_t)a_disp[q] + m[q] > Q) return fail(OSWALD_HIP_EINVAL, "query %u runs past the residue buffer (disp %u + len %u > %llu)", q, a_disp[q], m[q], (unsigned long long)Q);
     ctx->a.assign(a, a + Q);

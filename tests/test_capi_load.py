@@ -50,3 +50,10 @@ def test_product_code_never_touches_the_oracle():
                 if re.search(r"pyoracle|sw_oracle|liboswald_oracle|osw_oracle_|oracle/", txt):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_header_documents_the_first_pass_modes():
+    """cell_bits 0 / 11 / 16 / 32 are part of the ABI contract (include/oswald_hip.h)."""
+    text = open(os.path.join(ROOT, "include", "oswald_hip.h")).read()
+    for word in ("11", "packed fp16", "packed", "int32"):
+        assert word in text
