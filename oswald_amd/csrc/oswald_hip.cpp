@@ -104,7 +104,7 @@ struct Device {
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_f16, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
-    DevBuf topr_scores, topr_index, wg_times, scores_packed;
+    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed;
     std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
@@ -559,7 +559,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         release_registered(d);
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_f16, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
-                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.wg_times, &d.scores_packed})
+                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed})
             b->release();
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -913,7 +913,9 @@ int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nval
     const size_t cnt = (size_t)ctx->nq * r;
     HIP_TRY(d.topr_scores.reserve(cnt * sizeof(int32_t)));
     HIP_TRY(d.topr_index.reserve(cnt * sizeof(uint32_t)));
-    HIP_TRY(osw_launch_topr((const int32_t *)c.scores.p, c.score_stride, nvalid, r, ctx->nq, (int32_t *)d.topr_scores.p,
+    if (r > 1024) return fail(OSWALD_HIP_EINVAL, "top-r on the device supports r <= 1024 (asked for %u)", r);
+    HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * osw_topr_parts(nvalid) * r * sizeof(unsigned long long)));
+    HIP_TRY(osw_launch_topr((const int32_t *)c.scores.p, c.score_stride, nvalid, r, ctx->nq, (unsigned long long *)d.topr_cand.p, (int32_t *)d.topr_scores.p,
                             (uint32_t *)d.topr_index.p, d.stream));
     HIP_TRY(hipMemcpyAsync(scores, d.topr_scores.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipMemcpyAsync(index, d.topr_index.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));

@@ -131,8 +131,9 @@ hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
                                     const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, uint2 *prof, hipStream_t s);
+uint32_t osw_topr_parts(uint32_t nvalid); // partitions per score row; `cand` holds nq * parts * r tagged keys
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
-                           int32_t *out_scores, uint32_t *out_index, hipStream_t s);
+                           unsigned long long *cand, int32_t *out_scores, uint32_t *out_index, hipStream_t s);
 int osw_occupancy_pk16(int *blocks_per_cu);
 
 #endif

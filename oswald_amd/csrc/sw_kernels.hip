@@ -1142,29 +1142,25 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile(const u
 // Top-r selection with the reference's tie rule (reference host/src/utils.c:
 // 3-86 sorts descending and, on equal scores, puts the LATER database index
 // first).  key = score << 32 | index, so "descending key" is exactly that
-// order.  One workgroup per query; round k picks the largest key below the
-// key of round k-1.  r rounds of one coalesced pass over the score row.
+// order.  Two levels: every (query, partition of the score row) workgroup picks
+// its r largest keys in r rounds of a coalesced max-scan (round k takes the
+// largest key below the key of round k-1), then one workgroup per query picks
+// the r largest of the partitions' candidates the same way.  Keys are stored
+// as (key << 1) | 1, 0 = none (scores are >= 0 and < 2^31: the shift is lossless).
 // ---------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(1024) void osw_topr(const int32_t *__restrict__ scores, uint32_t score_stride,
-                                                             uint32_t nvalid, uint32_t r, int32_t *__restrict__ out_scores,
-                                                             uint32_t *__restrict__ out_index)
+template <class KeyAt>
+static __device__ __forceinline__ void osw_select_top(KeyAt key_at, uint32_t n, uint32_t r, unsigned long long *out /* r tagged keys */)
 {
-    __shared__ unsigned long long red[16];
+    __shared__ unsigned long long red[4];
     __shared__ unsigned long long bound_s;
-    const uint32_t q = blockIdx.x;
-    const int32_t *row = scores + (size_t)q * score_stride;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long bound = ~0ull;
+    unsigned long long bound = ~0ull; // tagged keys below this one are still available
     for (uint32_t k = 0; k < r; ++k) {
-        unsigned long long best = 0;
-        bool found = false;
-        for (uint32_t i = threadIdx.x; i < nvalid; i += blockDim.x) {
-            const unsigned long long key = ((unsigned long long)(uint32_t)row[i] << 32) | i;
-            if (key < bound && (!found || key > best)) { best = key; found = true; }
+        unsigned long long v = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long key = key_at(i); // tagged, 0 = none
+            if (key < bound && key > v) v = key;
         }
-        // "found" goes into bit 0 of the shifted key so that an empty thread loses;
-        // scores are >= 0 and < 2^31, so best < 2^63 and the shift is lossless
-        unsigned long long v = found ? ((best << 1) | 1ull) : 0ull;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = __shfl_xor(v, off);
@@ -1176,20 +1172,36 @@ extern "C" __global__ __launch_bounds__(1024) void osw_topr(const int32_t *__res
             unsigned long long m = 0;
             for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) m = red[w] > m ? red[w] : m;
             bound_s = m;
+            out[k] = m;
         }
         __syncthreads();
-        const unsigned long long m = bound_s;
-        if (threadIdx.x == 0) {
-            if (m & 1ull) {
-                out_scores[(size_t)q * r + k] = (int32_t)((m >> 1) >> 32);
-                out_index[(size_t)q * r + k] = (uint32_t)((m >> 1) & 0xffffffffull);
-            } else {
-                out_scores[(size_t)q * r + k] = -1;
-                out_index[(size_t)q * r + k] = 0xffffffffu;
-            }
-        }
-        bound = (m & 1ull) ? (m >> 1) : 0ull;
+        bound = bound_s ? bound_s : 0ull; // nothing left: every later round finds nothing either
         __syncthreads();
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void osw_topr_part(const int32_t *__restrict__ scores, uint32_t score_stride, uint32_t nvalid,
+                                                                 uint32_t r, uint32_t part, unsigned long long *__restrict__ cand)
+{
+    const uint32_t q = blockIdx.x, p = blockIdx.y, P = gridDim.y;
+    const uint32_t i0 = p * part, n = i0 < nvalid ? (nvalid - i0 < part ? nvalid - i0 : part) : 0;
+    const int32_t *row = scores + (size_t)q * score_stride + i0;
+    osw_select_top([&](uint32_t i) { return ((((unsigned long long)(uint32_t)row[i] << 32) | (i0 + i)) << 1) | 1ull; }, n, r,
+                   cand + ((size_t)q * P + p) * r);
+}
+
+extern "C" __global__ __launch_bounds__(256) void osw_topr_merge(const unsigned long long *__restrict__ cand, uint32_t ncand, uint32_t r,
+                                                                  int32_t *__restrict__ out_scores, uint32_t *__restrict__ out_index)
+{
+    __shared__ unsigned long long best[1024];
+    const uint32_t q = blockIdx.x;
+    const unsigned long long *c = cand + (size_t)q * ncand;
+    osw_select_top([&](uint32_t i) { return c[i]; }, ncand, r, best);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < r; k += blockDim.x) {
+        const unsigned long long m = best[k];
+        out_scores[(size_t)q * r + k] = (m & 1ull) ? (int32_t)((m >> 1) >> 32) : -1;
+        out_index[(size_t)q * r + k] = (m & 1ull) ? (uint32_t)((m >> 1) & 0xffffffffull) : 0xffffffffu;
     }
 }
 
@@ -1268,11 +1280,21 @@ hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, co
     return hipSuccess;
 }
 
+// candidates buffer: osw_topr_cand_count(nvalid, r, nq) tagged keys
+uint32_t osw_topr_parts(uint32_t nvalid)
+{
+    uint32_t P = nvalid / 4096;
+    return P < 1 ? 1 : P > 64 ? 64 : P;
+}
+
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
-                           int32_t *out_scores, uint32_t *out_index, hipStream_t s)
+                           unsigned long long *cand, int32_t *out_scores, uint32_t *out_index, hipStream_t s)
 {
     if (nq == 0 || r == 0) return hipSuccess;
-    hipLaunchKernelGGL(osw_topr, dim3(nq), dim3(1024), 0, s, scores, score_stride, nvalid, r, out_scores, out_index);
+    const uint32_t P = osw_topr_parts(nvalid), part = (nvalid + P - 1) / P;
+    hipLaunchKernelGGL(osw_topr_part, dim3(nq, P), dim3(256), 0, s, scores, score_stride, nvalid, r, part, cand);
+    OSW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(osw_topr_merge, dim3(nq), dim3(256), 0, s, (const unsigned long long *)cand, P * r, r, out_scores, out_index);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }
