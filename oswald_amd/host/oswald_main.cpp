@@ -9,6 +9,8 @@
 // the mirror of fpga_search() (reference host/src/FPGAsearch.c:4-374) with
 // GPUs where the reference has FPGAs.  There is no host compute path here.
 #include <argp.h>
+#include <algorithm>
+#include <utility>
 #include <sys/time.h>
 
 #include <cstdio>
@@ -190,8 +192,15 @@ int do_search(Options &o)
     printf("Query filename:\t\t\t%s\n", o.queries);
 
     if (db.sequences_count < o.top) o.top = db.sequences_count;
-    std::vector<int32_t> scores(nq * db.vect_sequences_count * W, 0);
+    // The report needs the top-r scores per query only.  For r <= 1024 they are selected on the device, chunk
+    // by chunk, with the reference's tie rule (utils.c:3-86: equal scores -> later database index first) and
+    // merged here; the full score table (the reference downloads and sorts it, FPGAsearch.c:232, :312-321)
+    // is only brought to the host for larger r.
+    const bool device_top = o.top <= 1024;
+    std::vector<int32_t> scores;
+    if (!device_top) scores.assign(nq * db.vect_sequences_count * W, 0);
     std::vector<std::vector<int32_t>> tmp(o.num_devices);
+    std::vector<std::vector<std::pair<int32_t, uint64_t>>> cand(nq); // (score, database index) per query, all chunks
 
     // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80)
     oswald_hip_ctx *ctx = nullptr;
@@ -201,20 +210,40 @@ int do_search(Options &o)
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
     // chunk c of a round goes to device c mod ndev (reference FPGAsearch.c:132-138)
+    std::vector<int> handle(o.num_devices, -1);
+    std::vector<int32_t> ts_dev;
+    std::vector<uint32_t> ti_dev;
     for (size_t k = 0; k < db.chunks.size(); k += o.num_devices) {
         const size_t active = std::min<size_t>(o.num_devices, db.chunks.size() - k);
         for (size_t d = 0; d < active; ++d) {
             const oswald::Chunk &c = db.chunks[k + d];
-            tmp[d].resize(nq * c.n.size() * W);
-            check(oswald_hip_search_chunk_async(ctx, (int)d, c.b.data(), c.b.size(), c.n.data(), c.disp.data(), (uint32_t)c.n.size(),
-                                                (uint32_t)W, tmp[d].data()), "chunk search");
+            if (device_top) {
+                check(oswald_hip_chunk_upload(ctx, (int)d, c.b.data(), c.b.size(), c.n.data(), c.disp.data(), (uint32_t)c.n.size(), (uint32_t)W,
+                                              &handle[d]), "chunk upload");
+                check(oswald_hip_chunk_search(ctx, (int)d, handle[d], nullptr), "chunk search");
+            } else {
+                tmp[d].resize(nq * c.n.size() * W);
+                check(oswald_hip_search_chunk_async(ctx, (int)d, c.b.data(), c.b.size(), c.n.data(), c.disp.data(), (uint32_t)c.n.size(),
+                                                    (uint32_t)W, tmp[d].data()), "chunk search");
+            }
         }
-        check(oswald_hip_wait(ctx, -1), "wait");
+        if (!device_top) check(oswald_hip_wait(ctx, -1), "wait");
         for (size_t d = 0; d < active; ++d) {
             const oswald::Chunk &c = db.chunks[k + d];
-            const size_t row = c.n.size() * W;
-            for (uint64_t qi = 0; qi < nq; ++qi)
-                memcpy(scores.data() + (qi * db.vect_sequences_count + c.accum) * W, tmp[d].data() + qi * row, row * sizeof(int32_t));
+            if (device_top) {
+                const uint64_t first = c.accum * W, last = std::min<uint64_t>(db.sequences_count, (c.accum + c.n.size()) * W);
+                const uint32_t nvalid = (uint32_t)(last - first), r = (uint32_t)std::min<uint64_t>(o.top, nvalid);
+                ts_dev.resize(nq * r);
+                ti_dev.resize(nq * r);
+                check(oswald_hip_chunk_topr(ctx, (int)d, handle[d], nvalid, r, ts_dev.data(), ti_dev.data()), "top scores"); // waits for the device
+                check(oswald_hip_chunk_release(ctx, (int)d, handle[d]), "chunk release");
+                for (uint64_t qi = 0; qi < nq; ++qi)
+                    for (uint32_t j = 0; j < r; ++j) cand[qi].push_back({ts_dev[qi * r + j], first + ti_dev[qi * r + j]});
+            } else {
+                const size_t row = c.n.size() * W;
+                for (uint64_t qi = 0; qi < nq; ++qi)
+                    memcpy(scores.data() + (qi * db.vect_sequences_count + c.accum) * W, tmp[d].data() + qi * row, row * sizeof(int32_t));
+            }
         }
     }
     const double workTime = dwalltime() - tick;
@@ -227,7 +256,19 @@ int do_search(Options &o)
     std::vector<int32_t> ts;
     std::vector<uint64_t> ti;
     for (uint64_t i = 0; i < nq; ++i) {
-        oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, ts, ti);
+        if (device_top) {
+            // merge of the chunks' lists: descending score, ties by descending database index
+            auto &cd = cand[i];
+            std::sort(cd.begin(), cd.end(), [](const std::pair<int32_t, uint64_t> &x, const std::pair<int32_t, uint64_t> &y) {
+                return x.first != y.first ? x.first > y.first : x.second > y.second;
+            });
+            const size_t r = std::min<size_t>(o.top, cd.size());
+            ts.resize(r);
+            ti.resize(r);
+            for (size_t j = 0; j < r; ++j) { ts[j] = cd[j].first; ti[j] = cd[j].second; }
+        } else {
+            oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, ts, ti);
+        }
         printf("\nQuery no.\t\t\t%d\n", (int)i + 1);
         printf("Query description: \t\t%s\n", q.titles[i].c_str() + 1);
         printf("Query length:\t\t\t%d residues\n", q.m[i]);
