@@ -507,15 +507,13 @@ static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 // drain steps of the lane groups) are zero in the scratch, and `tiled` holds
 // dummy residues before and after every block (warm-up / drain of the groups).
 // Per column on top of the cells: 2 VALU (LDS addresses) + 1 (first diagonal
-// add) + 1 (top_prev) + 2 (group 0 merges); the rest is SALU, LDS and VMEM.
+// add) + 1 (top_prev, merged with group 0's loaded H by a v_cndmask) + 1 (F
+// merge); the rest is SALU, LDS and VMEM.
 // ---------------------------------------------------------------------------
 #define OSW_STEP_BEGIN_ASM(LFP)                                                                              \
     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\t"                                                         \
-                 "s_mov_b64 %[sv], exec\n\t"                                                                 \
-                 "s_mov_b64 exec, %[mg0]\n\t"                                                                \
-                 "v_mov_b32 " OSW_VF ", " LFP "\n\t"                                                         \
-                 "s_mov_b64 exec, %[sv]"                                                                     \
-                 : [sv] "=&s"(sv)                                                                            \
+                 "v_cndmask_b32 " OSW_VF ", " OSW_VF ", " LFP ", %[mg0]"                                     \
+                 :                                                                                           \
                  : [mg0] "s"(m_g0)                                                                           \
                  : "memory", OSW_INFLIGHT)
 
@@ -523,10 +521,8 @@ static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 // row, hand-off to the group above (H and F are overwritten by it: everything that reads them comes first), then
 // the loads for the next-but-one column
 #define OSW_STEP_END_ASM(CP, LHP, LFP)                                                                       \
-    asm volatile("v_mov_b32 %[tp], " OSW_VH "\n\t"                                                           \
+    asm volatile("v_cndmask_b32 %[tp], " OSW_VH ", " LHP ", %[mg0]\n\t"                                       \
                  "s_mov_b64 %[sv], exec\n\t"                                                                 \
-                 "s_mov_b64 exec, %[mg0]\n\t"                                                                \
-                 "v_mov_b32 %[tp], " LHP "\n\t"                                                              \
                  "s_mov_b64 exec, %[mst]\n\t"                                                                \
                  "global_store_dword %[voff], %[ho], %[sptr]\n\t"                                            \
                  "global_store_dword %[voff], " OSW_VF ", %[sptr] offset:4\n\t"                              \
