@@ -39,7 +39,7 @@
 //   * between rounds the bottom row of the last group spills to a wave-private
 //     HBM scratch {H, F} per column and lane and is loaded back two columns
 //     ahead, straight into fixed registers (see "Input registers of a column
-//     step"): the column loop spends 6 VALU instructions besides the cells.
+//     step"): the column loop spends 5 VALU instructions besides the cells.
 //   * work items (query or pair, block, sub-block, G) are pulled from atomic
 //     queues sorted by cost (planned on the host, oswald_hip.cpp::build_items),
 //     so one launch covers all queries of a chunk; every wave exits when the
