@@ -187,6 +187,9 @@ def main():
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
                                   "instr_per_128_cells": ops_row,
                                   "note": "the DP is VALU-issue bound: instr_per_128_cells VALU instructions per wave per query row (query-pair cell for a multi-query search), one packed 16-bit instruction per 4 cycles per SIMD"}},
+            # the north star's ">= 0.5 x HBM roofline" is only well posed under the reference's own traffic
+            # model, 1 B of substitution score per cell streamed from device DRAM (sw.cl:57): 8 TB/s = 8000 GCUPS
+            "reference_traffic_model": {"bytes_per_cell": 1.0, "roofline_gcups": HBM_PEAK_GBS, "frac": round(gcups / world / HBM_PEAK_GBS, 4)},
             "rerun_items_int32": int(rerun), "work_items": int(ctx.chunk_geometry(chunk)["work_items"]), "max_log2_geometry": int(ctx.chunk_geometry(chunk)["max_log2_geometry"]), "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
             "setup_s": round(t_gen, 1),
         }
