@@ -730,6 +730,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.nitems_wg = c.nitems_wg;
     a.two_ended_waves = getenv("OSWALD_HIP_TWO_ENDED") ? (uint32_t)atoi(getenv("OSWALD_HIP_TWO_ENDED")) : 0u;
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
+    a.debug_nospill = getenv("OSWALD_HIP_DEBUG_NOSPILL") ? 1u : 0u; // timing experiment only: results are wrong
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;
     a.qlen = (const uint16_t *)d.qlen.p;

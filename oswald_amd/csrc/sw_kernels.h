@@ -115,6 +115,7 @@ struct OswSearchArgs {
     uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves; fp16 kernels: negated, as fp16
     uint32_t goe_fb, ge_fb;    // fp16 kernels: the int16 penalties for redone items
     int32_t goe, ge;
+    uint32_t debug_nospill;    // diagnostics: every round reads the zero page and stores to the trash page (WRONG scores; timing only)
     unsigned long long *wg_times; // diagnostics (or null): per workgroup {start, end of phase 1, end, end} in 100 MHz ticks
 };
 

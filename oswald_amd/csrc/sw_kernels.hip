@@ -770,7 +770,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             load_profile_round(prof_q, rb0, nrb, rb_end, rb16, lds_region, lane);
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * R * C::kRowBytes);
-        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, rho == 0, rho + 1 == plan.rounds, G, gl, lane, half, goe, ge, score);
+        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, rho == 0 || p.debug_nospill, rho + 1 == plan.rounds || p.debug_nospill, G, gl, lane, half, goe, ge, score);
         if constexpr (C::kEarlyExit) lane_hit = C::at_ceiling(score);
     }
     if constexpr (C::kEarlyExit) {
