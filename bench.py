@@ -11,10 +11,8 @@ query profile) are resident in HBM before the timed region starts.
 
 Workload at N = 1: BASELINE.json configs[1] -- 20 queries of length 100..1000
 (sum 11 000) against a 100k-sequence synthetic length-binned database
-(~36.5 M residues), BLOSUM62, gap 10/2, int16 cells (packed; sequences that
-saturate are re-run in int32).  --cell-bits 11 measures the library's default
-mode instead (packed fp16 first pass, same exact scores); at N = 1 it is also
-timed in the same run and reported as `fp16_first_pass`.  For N > 1 every
+(~36.5 M residues), BLOSUM62, gap 10/2, int16 cells (packed, exact below 30576;
+sequences above are re-run in int32).  For N > 1 every
 rank holds its own 100k-sequence shard (weak scaling; shards are chunk-sharded
 parts of an N x 100k-sequence database, no data-path collective).
 
@@ -41,9 +39,9 @@ SIMD_PER_CU = 4
 PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (tools/ubench.hip, measured 4.2-4.5)
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
-PK_OPS_PER_ROW = {11: (8.5, 7.5), 16: (10.0, 9.0), 32: (24.0, 24.0)}
+PK_OPS_PER_ROW = {11: (8.5, 7.5), 16: (8.5, 7.5), 32: (24.0, 24.0)}
 DTYPE = {11: "f16", 16: "int16", 32: "int32"}
-CELL_LABEL = {11: "packed fp16 first pass (exact < 2048), int16 / int32 re-runs", 16: "int16 cells (packed), int32 re-run of saturated sequences",
+CELL_LABEL = {11: "packed fp16 first pass (exact < 2048), int16 / int32 re-runs", 16: "int16 cells (packed, exact < 30576), int32 re-run above",
               32: "int32 cells"}
 
 
@@ -55,12 +53,10 @@ def parse():
     ap.add_argument("--nseq", type=int, default=100000, help="database sequences per GPU")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
-    ap.add_argument("--cell-bits", type=int, default=None, choices=[11, 16, 32],
-                    help="first-pass arithmetic: 16 = packed int16 (the cells BASELINE.json names for C2; default), "
-                         "11 = packed fp16 with int16 / int32 re-runs (the library's own default; default for C3, whose "
-                         "BASELINE entry asks for a narrow packed first pass with an int16 overflow re-run), 32 = int32 only")
+    ap.add_argument("--cell-bits", type=int, default=16, choices=[11, 16, 32],
+                    help="first-pass arithmetic: 16 = packed int16 (the cells BASELINE.json names; the library's default), "
+                         "11 = packed fp16 (exact < 2048) with int16 / int32 re-runs, 32 = int32 only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
-    ap.add_argument("--no-extra-mode", action="store_true", help="skip the additional timing of the library's default (fp16) mode (profiling runs)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
     return ap.parse_args()
 
@@ -122,7 +118,7 @@ def main():
     t_gen = time.time() - t0
 
     ctx = capi.Context(1, [gpu])
-    cell_bits = args.cell_bits if args.cell_bits is not None else (11 if args.workload == "c3" else 16)
+    cell_bits = args.cell_bits
     ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
     ctx.set_queries(a, m, a_disp)
     if b.size >= 2**32:
@@ -209,23 +205,6 @@ def main():
         ctx.chunk_release(h2)
         result["pcie_inclusive"] = {"gcups": round(sum_m * d_local / t_pcie / 1e9, 1), "ms": round(t_pcie * 1e3, 2),
                                     "what": "chunk_upload (H2D + re-tile) + search + D2H of all scores, pageable host memory"}
-        if world == 1 and cell_bits == 16 and not args.no_extra_mode:
-            # the same steps in the library's default mode: packed fp16 first pass (exact below 2048; sequences
-            # above it are redone in int16 / int32 on the device).  Same exact scores, 7.5 instead of 9
-            # instructions per 128 cells; reported beside `value`, which stays on the int16 cells BASELINE names.
-            ctx.set_scoring(sm, wl["go"], wl["ge"], 11)
-            step()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                top11 = step()
-            torch.cuda.synchronize(dev)
-            t11 = time.perf_counter() - t0
-            result["fp16_first_pass"] = {"value": round(cells_per_step * args.steps / t11 / 1e9, 2), "unit": "GCUPS",
-                                         "ms_per_step": round(t11 / args.steps * 1e3, 3),
-                                         "same_top_scores": bool(np.array_equal(top11[0], top[0]) and np.array_equal(top11[1], top[1])),
-                                         "what": "library default (cell_bits 0/11): packed fp16 first pass, exact; int16 / int32 re-runs on the device"}
-            ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
         if args.cpu_seconds > 0 and world == 1:  # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args, a, m, a_disp, sl, sr, so, sm, wl, sum_m, ctx, chunk, n)
     ctx.chunk_release(chunk)

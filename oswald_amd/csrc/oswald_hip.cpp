@@ -104,7 +104,7 @@ struct Device {
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_f16, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
-    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed;
+    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages;
     std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
@@ -140,15 +140,15 @@ struct oswald_hip_ctx {
 
 namespace {
 
-// Pair up queries of similar length (sorted by length, neighbours): a pair costs 9 (fp16 first pass: 7.5)
-// instructions per row of the LONGER query for one sequence, two singles 10 (8.5) per row for two
-// sequences, so pairing pays when the shorter one is longer than ~0.85 (0.8) of the longer one.
+// Pair up queries of similar length (sorted by length, neighbours): a pair costs 7.5 instructions per row of
+// the LONGER query for one sequence, two singles 8.5 per row for two sequences, so pairing pays when the
+// shorter one is longer than ~0.8 of the longer one.
 // OSWALD_HIP_PAIRS=0 disables it, =2 pairs every neighbour (test hook).
 void plan_pairs(oswald_hip_ctx *ctx)
 {
     const uint32_t nq = ctx->nq;
     const std::vector<uint16_t> &m = ctx->m;
-    const double pair_row = ctx->cell_bits == 11 ? 7.5 : 9.0, single_row = ctx->cell_bits == 11 ? 8.5 : 10.0;
+    const double pair_row = 7.5, single_row = 8.5; // both packed cells: 7 + 1/2 instructions per row, +1 v_perm_b32 for two sequences per lane
     ctx->pair_q.clear(); ctx->pair_off.clear(); ctx->pair_len.clear(); ctx->singles.clear();
     ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
     int mode = 1;
@@ -266,10 +266,9 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0;
     const bool i32 = ctx->cell_bits == 32;
     struct Kind { uint32_t rmax, ldsr; double row_cost, passes; };
-    const bool f16 = ctx->cell_bits == 11; // 7.5 instead of 9 instructions per row (+1 for the sequence-pair cell)
     const Kind kinds[2] = {
-        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16, f16 ? 8.5 : 10.0, 1.0},
-        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, f16 ? 7.5 : 9.0, 2.0}};
+        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16, i32 ? 24.0 : 8.5, 1.0},
+        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, 7.5, 2.0}};
     struct Entity { uint32_t m, id, kind; };
     std::vector<Entity> ents;
     if (i32) {
@@ -522,6 +521,14 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
                 r = hipMemset2DAsync(d.bnd.p, (d.bnd_stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream);
             if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: spill scratch: %s", d.id, hipGetErrorString(r)); }
         }
+        // the constant "row above a first round": 64 {H,F} entries of zeros, then 64 of the biased-int16 floor (1024)
+        {
+            std::vector<uint32_t> pages(2 * 64 * 2, 0u);
+            for (size_t i = 128; i < pages.size(); ++i) pages[i] = 0x04000400u;
+            r = d.top_pages.reserve(pages.size() * sizeof(uint32_t));
+            if (r == hipSuccess) r = hipMemcpy(d.top_pages.p, pages.data(), pages.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
+        }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
         // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
         // copy of a process takes ~10 ms, later ones run at ~20 GB/s) and the first launch of every kernel.
@@ -559,7 +566,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         release_registered(d);
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_f16, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
-                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed})
+                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages})
             b->release();
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -597,7 +604,7 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     if (!ctx || !submat) return fail(OSWALD_HIP_EINVAL, "null argument");
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
     if (open_gap + extend_gap > 32767) return fail(OSWALD_HIP_EINVAL, "open+extend must fit int16");
-    if (cell_bits == 0) cell_bits = getenv("OSWALD_HIP_CELL_BITS") ? atoi(getenv("OSWALD_HIP_CELL_BITS")) : 11;
+    if (cell_bits == 0) cell_bits = getenv("OSWALD_HIP_CELL_BITS") ? atoi(getenv("OSWALD_HIP_CELL_BITS")) : 16;
     if (cell_bits != 11 && cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 11, 16 or 32");
     memcpy(ctx->submat, submat, 24 * 32);
     ctx->open_gap = open_gap;
@@ -735,6 +742,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.prof_off = (const uint32_t *)d.prof_off.p;
     a.qlen = (const uint16_t *)d.qlen.p;
     a.bnd = (uint2 *)d.bnd.p;
+    a.top_pages = (const uint2 *)d.top_pages.p;
     a.bnd_stride = d.bnd_stride + OSW_SCRATCH_DATA;
     a.scores = (int32_t *)c.scores.p;
     a.score_stride = c.score_stride;

@@ -104,6 +104,7 @@ struct OswSearchArgs {
     const uint2 *prof_fb;      // fp16 kernels: the int16 profile of the same queries / pairs (items redone in int16)
     const uint32_t *prof_off;
     const uint16_t *qlen;
+    const uint2 *top_pages;    // 2 x 64 constant {H,F} entries: the row above a first round -- zeros, then the biased-int16 floor
     uint2 *bnd;                // strip-boundary spill {H,F} per column and lane, one region per resident wave
     uint64_t bnd_stride;       // uint2 per region (OSW_SCRATCH_DATA + columns x lanes per group)
     int32_t *scores;           // [nq][score_stride]

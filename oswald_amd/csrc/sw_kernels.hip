@@ -95,51 +95,15 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 #define OSW_INFLIGHT "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
 // ---------------------------------------------------------------------------
-// Packed-int16 cell, hand-scheduled.  State per row r: E[r] and D[r] =
-// H(i0+r-1, j-1), the diagonal input of row r (D[0] is only a name: the top
-// input comes from the strip above).  The cell of row r is 9 VOP3P
-// instructions; it also issues the diagonal add of row r+1 *before* it
-// overwrites D[r+1] with its own H, so every state register is updated in
-// place (no copies), and every result is consumed at a distance of >= 2 issue
-// slots, which is what gfx950 needs between a packed-math write and a dependent
-// VALU read (no s_nop inside the cell).  F runs down the column in the F
-// register of the step's input set (FREG), where the next strip picks it up.
-//   x   in: D[r] + S[r]          out: D[r+1] + S[r+1]
-//   Dn  in: D[r+1] (old column)  out: H(i0+r, j)  (= D[r+1] of the next column)
+// The cell, hand-scheduled.  State per row r: E[r] and D[r] = H(i0+r-1, j-1),
+// the diagonal input of row r (D[0] is only a name: the top input comes from
+// the strip above).  A row also issues the diagonal add of row r+1 *before* it
+// overwrites D[r+1] with its own H, so every state register is updated in place
+// (no copies), and every result is consumed at a distance of >= 2 issue slots,
+// which is what gfx950 needs between a packed-math write and a dependent VALU
+// read (no s_nop inside the cell).  F runs down the column in the F register of
+// the step's input set (FREG), where the next strip picks it up.
 // ---------------------------------------------------------------------------
-#define OSW_PK16_ROW(FREG, x, Er, Dn, sc, s_next, ge, goe)                                   \
-    do {                                                                                     \
-        v2s tmp_;                                                                            \
-        asm volatile("v_pk_max_i16 %[tmp], %[x_], %[E_]\n\t"                                 \
-                     "v_pk_add_i16 %[x_], %[Dn_], %[sn_] clamp\n\t"                          \
-                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
-                     "v_pk_max_i16 %[Dn_], %[tmp], " FREG "\n\t"                             \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
-                     "v_pk_sub_u16 %[tmp], %[Dn_], %[goe_] clamp\n\t"                        \
-                     "v_pk_max_i16 %[sc_], %[sc_], %[Dn_]\n\t"                               \
-                     "v_pk_max_i16 %[E_], %[E_], %[tmp]\n\t"                                 \
-                     "v_pk_max_i16 " FREG ", " FREG ", %[tmp]"                               \
-                     : [tmp] "=&v"(tmp_), [x_] "+v"(x), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
-                     : [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe)                     \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-// last row of the strip: its H goes to `hl` (handed to the next strip)
-#define OSW_PK16_ROW_LAST(FREG, x, Er, hl, sc, ge, goe)                                      \
-    do {                                                                                     \
-        v2s tmp_;                                                                            \
-        asm volatile("v_pk_max_i16 %[tmp], %[x_], %[E_]\n\t"                                 \
-                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
-                     "v_pk_max_i16 %[hl_], %[tmp], " FREG "\n\t"                             \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
-                     "v_pk_sub_u16 %[tmp], %[hl_], %[goe_] clamp\n\t"                        \
-                     "v_pk_max_i16 %[sc_], %[sc_], %[hl_]\n\t"                               \
-                     "v_pk_max_i16 %[E_], %[E_], %[tmp]\n\t"                                 \
-                     "v_pk_max_i16 " FREG ", " FREG ", %[tmp]"                               \
-                     : [tmp] "=&v"(tmp_), [hl_] "=&v"(hl), [E_] "+v"(Er), [sc_] "+v"(sc)     \
-                     : [x_] "v"(x), [ge_] "s"(ge), [goe_] "s"(goe)                           \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
 
 // ---------------------------------------------------------------------------
 // Packed-fp16 cell for a first pass with a 2047 ceiling (the reference's first
@@ -203,30 +167,100 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
                      : OSW_INFLIGHT);                                                        \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// Packed-int16 cell with the three-operand maximum ("biased int16").  For
+// non-negative 16-bit patterns below 0x7C00 the fp16 ordering IS the integer
+// ordering, so v_pk_maximum3_f16 computes an integer max3 -- as long as no
+// operand is a NaN pattern (negative small integers are) or a flushed
+// denormal (integers below 1024 are denormal patterns).  All values therefore
+// carry a bias B = 1024 (the smallest normal fp16): H, E, F >= B always; the
+// diagonal sum D + S >= B - 128 may be a denormal, but then it loses against E
+// and F either way; the gap terms use the unsigned saturating subtract, so they
+// are never negative.  Adds and subtracts are plain packed int16: nothing is
+// rounded.  Patterns from 0x7C00 (31744) on would be inf / NaN: a sequence whose
+// biased score reaches 31600 (true score 30576) is re-run in int32, and below
+// that threshold no sum can reach 31744 (|S| <= 128).  7.5 VOP3P instructions
+// per row like the fp16 cell, with fifteen times its ceiling.
+//   floor (the value of "zero"): B in both halves; profile: the plain int16 one
+// ---------------------------------------------------------------------------
+#define OSW_I16B_BIAS 0x04000400u
+#define OSW_I16B_ROW_EVEN(FREG, x, xn, Er, Dn, s_next, ge, goe)                              \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
+                     "v_pk_sub_u16 %[t], %[Dn_], %[goe_] clamp\n\t"                          \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[b_]\n\t"                       \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[b_]"                     \
+                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn)         \
+                     : [x_] "v"(x), [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe), [b_] "s"(OSW_I16B_BIAS) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
+#define OSW_I16B_ROW_ODD(FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, goe)                       \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
+                     "v_pk_sub_u16 %[t], %[Dn_], %[goe_] clamp\n\t"                          \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
+                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[Dn_]\n\t"                  \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[b_]\n\t"                       \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[b_]"                     \
+                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
+                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe), [b_] "s"(OSW_I16B_BIAS) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
+#define OSW_I16B_ROW_LAST(FREG, x, Er, hl, Dp, sc, ge, goe)                                  \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_maximum3_f16 %[hl_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
+                     "v_pk_sub_u16 %[t], %[hl_], %[goe_] clamp\n\t"                          \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
+                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[hl_]\n\t"                  \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[b_]\n\t"                       \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[b_]"                     \
+                     : [hl_] "=&v"(hl), [t] "=&v"(t_), [E_] "+v"(Er), [sc_] "+v"(sc)         \
+                     : [x_] "v"(x), [Dp_] "v"(Dp), [ge_] "s"(ge), [goe_] "s"(goe), [b_] "s"(OSW_I16B_BIAS) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
 // Cell arithmetic policies: the row forms on input set P (0: even column, 1: odd
 // column) and what a finished score means.
-//   row<P, ODD>: x in/out, Dp = H of the row above (= D[r], fp16 only)
-struct ArithI16 {
-    static constexpr int kCeiling = 32767; // a lane that reaches it is re-run in int32
+//   row<P, ODD>: x in/out, Dp = H of the row above (= D[r]); odd rows fold two rows' H into the running maximum
+struct ArithI16B {
+    static constexpr int kCeiling = 31600 - 1024; // true score from which a sequence is re-run in int32
+    static constexpr uint32_t kFloor = OSW_I16B_BIAS;
     static constexpr bool kEarlyExit = false;
     static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
     template <int P, bool ODD>
-    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s /*Dp*/, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe)
+    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe)
     {
-        OSW_PK16_ROW(OSW_VF, x, Er, Dn, sc, s_next, ge, goe);
+        v2s xn;
+        if constexpr (ODD) OSW_I16B_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, goe);
+        else OSW_I16B_ROW_EVEN(OSW_VF, x, xn, Er, Dn, s_next, ge, goe);
+        x = xn;
     }
     template <int P>
-    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s /*Dp*/, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe)
+    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe)
     {
-        OSW_PK16_ROW_LAST(OSW_VF, x, Er, hl, sc, ge, goe);
+        OSW_I16B_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, ge, goe);
     }
     static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0) { return __builtin_elementwise_add_sat(top_prev, s0); }
-    static __device__ __forceinline__ int to_int(short bits) { return bits; }
+    static __device__ __forceinline__ int to_int(short bits) { return (int)bits - 1024; }
+    // at or past the threshold -- or any pattern the maximum may have turned into a NaN of either sign
+    static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 31600u; }
 };
 
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 struct ArithF16 {
     static constexpr int kCeiling = 2048; // scores at or above it are not exact in fp16
+    static constexpr uint32_t kFloor = 0;
     static constexpr bool kEarlyExit = true; // checked after every round: the item is redone in packed int16 at once
     // non-negative fp16 values order like their bit patterns; 2048.0 = 0x6800
     static __device__ __forceinline__ bool at_ceiling(v2s s) { return (uint16_t)s.x >= 0x6800u || (uint16_t)s.y >= 0x6800u; }
@@ -248,6 +282,7 @@ struct ArithF16 {
         return __builtin_bit_cast(v2s, __builtin_bit_cast(v2h, top_prev) + __builtin_bit_cast(v2h, s0));
     }
     static __device__ __forceinline__ int to_int(short bits) { return (int)(float)__builtin_bit_cast(_Float16, bits); }
+    static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 0x6800u; }
 };
 
 template <class A>
@@ -257,11 +292,12 @@ struct CellSeqPair {
     typedef uint32_t GapT; // (value, value) packed, wave-uniform
     static constexpr bool kFast = true;
     static constexpr bool kEarlyExit = A::kEarlyExit;
+    static constexpr uint32_t kFloorBits = A::kFloor;
     static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16;
     static constexpr int kRowBytes = 64; // profile bytes per query row: 32 codes x int16
-    static __device__ __forceinline__ T zero() { return (T)(0); }
+    static __device__ __forceinline__ T zero() { return as_v2s(A::kFloor); } // the value that stands for 0
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
@@ -369,11 +405,12 @@ struct CellQueryPair {
     typedef uint32_t GapT;
     static constexpr bool kFast = true;
     static constexpr bool kEarlyExit = A::kEarlyExit;
+    static constexpr uint32_t kFloorBits = A::kFloor;
     static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
     static constexpr int kRowBytes = 128; // 32 codes x 2 queries x int16
-    static __device__ __forceinline__ T zero() { return (T)(0); }
+    static __device__ __forceinline__ T zero() { return as_v2s(A::kFloor); } // the value that stands for 0
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
@@ -435,8 +472,8 @@ struct CellQueryPair {
     }
 };
 
-typedef CellSeqPair<ArithI16> CellPK16;
-typedef CellQueryPair<ArithI16> CellPK16Q;
+typedef CellSeqPair<ArithI16B> CellPK16B;
+typedef CellQueryPair<ArithI16B> CellPK16BQ;
 typedef CellSeqPair<ArithF16> CellPKF16;
 typedef CellQueryPair<ArithF16> CellPKF16Q;
 
@@ -447,6 +484,7 @@ struct CellI32 {
     typedef int GapT;
     static constexpr bool kFast = false;
     static constexpr bool kEarlyExit = false;
+    static constexpr uint32_t kFloorBits = 0;
     static __device__ __forceinline__ bool at_ceiling(T) { return false; }
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
@@ -544,7 +582,7 @@ static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 
 template <class C, int R>
 static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
-                                                     bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
+                                                     const uint2 *top_pages, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
                                                      typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
     typedef typename C::T T;
@@ -563,13 +601,14 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     // still before column 0 (the store pointer starts G-1 columns before the data: inside the trash page)
     const uint64_t data = (uint64_t)(bnd + OSW_SCRATCH_DATA);
     const uint32_t lstep = first ? 0u : gl * 8u, sstep = last ? 0u : gl * 8u;
-    uint64_t lptr = first ? (uint64_t)(bnd + OSW_SCRATCH_ZERO) : data;
+    // a first round reads the row above it -- "zero" in the cell's representation -- from a constant page
+    uint64_t lptr = first ? (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0)) : data;
     uint64_t sptr = last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u;
     uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * 128u;
     uint64_t sv;
     // nothing has been handed over yet: zeros; columns 0 and 1 of the stream
-    asm volatile("v_mov_b32 " OSW_VH ", 0\n\t"
-                 "v_mov_b32 " OSW_VF ", 0\n\t"
+    asm volatile("v_mov_b32 " OSW_VH ", %[fl]\n\t"
+                 "v_mov_b32 " OSW_VF ", %[fl]\n\t"
                  "global_load_ushort " OSW_VC0 ", %[voffc], %[tptr]\n\t"
                  "global_load_ushort " OSW_VC1 ", %[voffc], %[tptr] offset:128\n\t"
                  "s_mov_b64 %[sv], exec\n\t"
@@ -581,7 +620,8 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
                  "s_mov_b64 exec, %[sv]\n\t"
                  "s_waitcnt vmcnt(0)"
                  : [sv] "=&s"(sv)
-                 : [voff] "v"(voff), [voffc] "v"(voffc), [mg0] "s"(m_g0), [lptr] "s"(lptr), [lptr2] "s"(lptr + lstep), [tptr] "s"(tptr)
+                 : [voff] "v"(voff), [voffc] "v"(voffc), [mg0] "s"(m_g0), [lptr] "s"(lptr), [lptr2] "s"(lptr + lstep), [tptr] "s"(tptr),
+                   [fl] "s"(C::kFloorBits)
                  : "memory", OSW_INFLIGHT);
     lptr += 2 * lstep;
     tptr += 256;
@@ -618,7 +658,7 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
 // Compiler-scheduled version of the same round (int32 cell).
 template <class C, int R>
 static __device__ __forceinline__ void sw_round_plain(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
-                                                      bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
+                                                      const uint2 * /*top_pages*/, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
                                                       typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
     typedef typename C::T T;
@@ -656,13 +696,13 @@ static __device__ __forceinline__ void sw_round_plain(const uint16_t *tcol, uint
 
 template <class C>
 static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
-                                                         bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
+                                                         const uint2 *top_pages, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
                                                          typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
 #define OSW_ROUND_CASE(RR)                                                                                                      \
     case RR:                                                                                                                    \
-        if constexpr (C::kFast) sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, first, last, G, gl, lane, half, goe, ge, score); \
-        else sw_round_plain<C, RR>(tcol, u, ncols, base, bnd, first, last, G, gl, lane, half, goe, ge, score);                  \
+        if constexpr (C::kFast) sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score); \
+        else sw_round_plain<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);                  \
         break
     switch (R) {
         OSW_ROUND_CASE(4);
@@ -733,9 +773,9 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     const uint4 *prof_q = (const uint4 *)prof + (size_t)p.prof_off[q] * rb16;
     if (plan.rounds > 1) {
         // the scratch columns the prefetch and the drain steps read past the block's last one are the
-        // row above of dummy columns: zero (other items, at other geometries, have written here)
+        // row above of dummy columns: "zero" in the cell's representation (other items have written here)
         uint2 *pad = bnd + OSW_SCRATCH_DATA + (size_t)ncols * gl;
-        for (uint32_t k = lane; k < (G + 2u) * gl; k += 64) pad[k] = make_uint2(0, 0);
+        for (uint32_t k = lane; k < (G + 2u) * gl; k += 64) pad[k] = make_uint2(C::kFloorBits, C::kFloorBits);
     }
     T score = C::zero();
     bool lane_hit = false;
@@ -770,7 +810,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             load_profile_round(prof_q, rb0, nrb, rb_end, rb16, lds_region, lane);
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * R * C::kRowBytes);
-        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, rho == 0 || p.debug_nospill, rho + 1 == plan.rounds || p.debug_nospill, G, gl, lane, half, goe, ge, score);
+        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, p.top_pages, rho == 0 || p.debug_nospill, rho + 1 == plan.rounds || p.debug_nospill, G, gl, lane, half, goe, ge, score);
         if constexpr (C::kEarlyExit) lane_hit = C::at_ceiling(score);
     }
     if constexpr (C::kEarlyExit) {
@@ -827,7 +867,7 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
         out.x = A::to_int(score.x);
         out.y = A::to_int(score.y);
         *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lam) = out;
-        const uint32_t hm = (out.x >= A::kCeiling ? 1u : 0u) | (out.y >= A::kCeiling ? 2u : 0u);
+        const uint32_t hm = (A::over(score.x) ? 1u : 0u) | (A::over(score.y) ? 2u : 0u);
         if (hm) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
@@ -849,11 +889,11 @@ static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint
         const int sa = A::to_int(score.x), sb = A::to_int(score.y);
         p.scores[(size_t)qa * p.score_stride + seq] = sa;
         p.scores[(size_t)qb * p.score_stride + seq] = sb;
-        if (sa >= A::kCeiling) {
+        if (A::over(score.x)) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam, 6u, 1u << half), B);
         }
-        if (sb >= A::kCeiling) {
+        if (A::over(score.y)) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(qb, lam, 6u, 1u << half), B);
         }
@@ -957,19 +997,19 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     if (p.wg_times && lane == 0) p.wg_times[blockIdx.x * 4 + 2 + (wv & 1)] = __builtin_amdgcn_s_memrealtime(); // waves 0/1 (or 2/3) race: any is fine
 }
 
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16, CellPK16, false>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16B, CellPK16B, false>(p); }
 
 // Query pairs: `items` / `qlen` / `prof` / `prof_off` describe pairs (length = the longer query,
 // profile = packed (A, B) scores); pair_q maps a pair to its two query rows of the score table.
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16Q, CellPK16Q, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true>(p); }
 
 // The same two kernels with a packed-fp16 first pass (ceiling 2047, see ArithF16): goe_pk / ge_pk carry
 // the NEGATED penalties as fp16 pairs and `prof` holds fp16 scores.  An item in which any sequence
 // reaches the ceiling is redone on the spot in packed int16 (prof_fb, goe_fb, ge_fb), by the wave or
 // workgroup that found out, after the round in which it happened; from there on it is an int16 item
 // (a score at the int16 ceiling goes to the int32 kernel).
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16(OswSearchArgs p) { pk16_body<CellPKF16, CellPK16, false>(p); }
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16q(OswSearchArgs p) { pk16_body<CellPKF16Q, CellPK16Q, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16(OswSearchArgs p) { pk16_body<CellPKF16, CellPK16B, false>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16q(OswSearchArgs p) { pk16_body<CellPKF16Q, CellPK16BQ, true>(p); }
 
 // ---------------------------------------------------------------------------
 // Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at

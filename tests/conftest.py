@@ -19,8 +19,8 @@ def pytest_configure(config):
 
 
 def pytest_generate_tests(metafunc):
-    # every GPU test runs once per first-pass arithmetic of the library (packed fp16 = the default,
-    # packed int16); a test that passes cell_bits explicitly is unaffected by the setting
+    # every GPU test runs once per first-pass arithmetic of the library (packed int16 = the default,
+    # packed fp16 with int16 redo); a test that passes cell_bits explicitly is unaffected by the setting
     if metafunc.definition.get_closest_marker("gpu") and "first_pass" in metafunc.fixturenames:
         metafunc.parametrize("first_pass", ["f16", "i16"], indirect=True)
 

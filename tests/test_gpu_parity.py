@@ -400,3 +400,21 @@ def test_two_devices_in_one_context(oracle):
                 parts[idx] = out
     want = expect(oracle, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), want)
+
+
+def test_scores_around_the_int16_ceiling(hip_ctx, oracle):
+    """The packed-int16 cell is exact below 30576 (its values carry a bias of 1024 and must stay below the fp16
+    inf/NaN patterns, see ArithI16B); sequences at or above it are re-run in int32.  Self-alignments scoring just
+    below, at and above that threshold and up to the int16 limit must all come back exact."""
+    targets = [30500, 30574, 30575, 30576, 30577, 30640, 31743, 32000, 32767]
+    qs = [_self_scoring(t, 300 + t) for t in targets[::2]]          # 5 long queries ...
+    seqs = [_self_scoring(t, 300 + t) for t in targets]             # ... against all 9 sequences (5 are exact copies)
+    seqs += [synth.random_residues(1900 + i, 0, 400 + 31 * i) for i in range(12)]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want.max(axis=1).tolist() == targets[::2]
+    assert ((want > 30000) & (want < 30576)).any() and (want >= 30576).any()

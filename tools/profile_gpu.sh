@@ -12,7 +12,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_${WL}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --workload $WL --nseq $NSEQ --cpu-seconds 0 --no-extra-mode ${BENCH_EXTRA:-}"  # e.g. BENCH_EXTRA="--cell-bits 11"
+BENCH="python3 $REPO/bench.py --workload $WL --nseq $NSEQ --cpu-seconds 0 ${BENCH_EXTRA:-}"  # e.g. BENCH_EXTRA="--cell-bits 11"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 5 --warmup 1 > "$OUT/stats.log" 2>&1
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH --steps 2 --warmup 0 > "$OUT/fetch.log" 2>&1
