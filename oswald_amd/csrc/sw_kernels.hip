@@ -10,13 +10,14 @@
 //     MFMA: this is a max-plus DP.  Packed 16-bit VALU issues at ~4 cycles per
 //     wave instruction per SIMD on gfx950 (measured, tools/ubench.hip), so the
 //     cell is kept as short as the ISA allows and hand-scheduled:
-//       - first pass in packed fp16 (exact for integers below 2048) with
-//         v_pk_maximum3_f16: 7.5 VOP3P instructions per row (+1 v_perm_b32 when
-//         a lane holds two sequences); an item in which a sequence reaches 2048
-//         is redone at once in packed int16 (9 / 10 instructions per row);
-//       - sequences that reach 32767 in int16 are queued for the int32 kernel
+//       - packed int16 values carrying a bias of 1024, on which gfx950's
+//         v_pk_maximum3_f16 is an integer max3: 7.5 VOP3P instructions per row
+//         (+1 v_perm_b32 when a lane holds two sequences), exact below 30576;
+//       - sequences that reach that ceiling are queued for the int32 kernel
 //     (the reference's int8->int16->int32 escalation, host/src/HybridSearch.c:
-//     1670-1680,:1774-1784, yields exact scores; so does this).
+//     1670-1680,:1774-1784, yields exact scores; so does this);
+//       - alternative first pass in real packed fp16 (exact below 2048, redone
+//         in int16 above), same instruction count, kept for comparison.
 //   * the query is cut into strips of R <= 32 rows held in registers (E and
 //     the diagonal H of every row, 2 VGPRs per row); database columns stream
 //     through.  The strip's slice of the query profile lives in a wave-private
@@ -47,9 +48,8 @@
 //
 // Recurrence (reference sw.cl:60-78): H = max(0, Hdiag + S, E, F);
 // E,F <- max(E|F - ge, H - (go+ge)).  E and F are kept clamped at >= 0, which
-// is equivalent because they only ever enter a max with H >= 0; in int16 it turns
-// the max(.,0) into the saturation of the unsigned packed subtract, in fp16 it
-// is the third operand of the maximum.
+// is equivalent because they only ever enter a max with H >= 0; the floor is
+// the third operand of the maximum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sw_kernels.h"
