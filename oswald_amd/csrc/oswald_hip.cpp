@@ -103,7 +103,7 @@ struct Device {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
-    DevBuf queries, qlen, a_disp, prof_off, prof, prof_f16, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
+    DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages;
     std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
@@ -140,6 +140,10 @@ struct oswald_hip_ctx {
 
 namespace {
 
+// cell_bits 16 runs the column-frame int16 cell (ArithI16S) with the plain biased cell as its fallback;
+// OSWALD_HIP_NO_FRAME=1 (test hook) runs the plain cell only
+bool first_pass_is_frame(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 16 && !getenv("OSWALD_HIP_NO_FRAME"); }
+
 // Pair up queries of similar length (sorted by length, neighbours): a pair costs 7.5 instructions per row of
 // the LONGER query for one sequence, two singles 8.5 per row for two sequences, so pairing pays when the
 // shorter one is longer than ~0.8 of the longer one.
@@ -148,7 +152,8 @@ void plan_pairs(oswald_hip_ctx *ctx)
 {
     const uint32_t nq = ctx->nq;
     const std::vector<uint16_t> &m = ctx->m;
-    const double pair_row = 7.5, single_row = 8.5; // both packed cells: 7 + 1/2 instructions per row, +1 v_perm_b32 for two sequences per lane
+    const bool fr = first_pass_is_frame(ctx); // 6.5 instead of 7.5 instructions per row; +1 v_perm_b32 for two sequences per lane
+    const double pair_row = fr ? 6.5 : 7.5, single_row = fr ? 7.5 : 8.5;
     ctx->pair_q.clear(); ctx->pair_off.clear(); ctx->pair_len.clear(); ctx->singles.clear();
     ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
     int mode = 1;
@@ -216,16 +221,31 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     HIP_TRY(hipMemcpyAsync(d.a_disp.p, ctx->a_disp.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.prof_off.p, ctx->prof_off.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.submat.p, ctx->submat, 24 * 32, hipMemcpyHostToDevice, d.stream));
-    // integer profile: the int16 first pass and the exact int32 kernel
+    // plain integer profile: the plain int16 cell and the exact int32 kernel
     HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                      (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                     0u, (uint2 *)d.prof.p, d.stream));
-    const bool f16 = ctx->cell_bits == 11;
-    if (f16) { // the same scores as fp16 for the packed-fp16 first pass
-        HIP_TRY(d.prof_f16.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
+                                     0u, 0, (uint2 *)d.prof.p, d.stream));
+    // the first pass's own profile where it differs: fp16 scores (cell_bits 11) or S + ge for the column-frame
+    // int16 cell (cell_bits 16)
+    const bool f16 = ctx->cell_bits == 11, frame = first_pass_is_frame(ctx), alt = f16 || frame;
+    if (alt) {
+        HIP_TRY(d.prof_alt.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
         HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                          (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                         1u, (uint2 *)d.prof_f16.p, d.stream));
+                                         f16 ? 1u : 0u, frame ? ctx->extend_gap : 0, (uint2 *)d.prof_alt.p, d.stream));
+    }
+    {
+        // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
+        // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern)
+        const size_t entries = 128 + OSW_I16S_TABLE;
+        std::vector<uint32_t> pages(entries * 2, 0u);
+        for (size_t i = 64; i < 128; ++i) pages[2 * i] = pages[2 * i + 1] = 0x04000400u;
+        for (size_t k = 0; k < OSW_I16S_TABLE; ++k) {
+            const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
+            pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);
+        }
+        HIP_TRY(d.top_pages.reserve(pages.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(d.top_pages.p, pages.data(), pages.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     const uint32_t np = (uint32_t)ctx->pair_len.size();
     if (np > 0) {
@@ -236,10 +256,10 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
         HIP_TRY(hipMemcpyAsync(d.pair_q.p, ctx->pair_q.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemcpyAsync(d.pair_off.p, ctx->pair_off.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipMemcpyAsync(d.pair_len.p, ctx->pair_len.data(), np * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(osw_launch_build_pair_profile((const uint2 *)(f16 ? d.prof_f16.p : d.prof.p), (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
+        HIP_TRY(osw_launch_build_pair_profile((const uint2 *)(alt ? d.prof_alt.p : d.prof.p), (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                               (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
                                               ctx->pair_max_rowblocks, (uint4 *)d.prof_pair.p, d.stream));
-        if (f16) { // int16 pair profile for the items the fp16 kernel redoes
+        if (alt) { // plain int16 pair profile for the items the first-pass cell hands to the plain cell
             HIP_TRY(d.prof_pair_i16.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096));
             HIP_TRY(osw_launch_build_pair_profile((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                                   (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
@@ -267,8 +287,9 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     const bool i32 = ctx->cell_bits == 32;
     struct Kind { uint32_t rmax, ldsr; double row_cost, passes; };
     const Kind kinds[2] = {
-        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16, i32 ? 24.0 : 8.5, 1.0},
-        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, 7.5, 2.0}};
+        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16,
+         i32 ? 24.0 : first_pass_is_frame(ctx) ? 7.5 : 8.5, 1.0},
+        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, first_pass_is_frame(ctx) ? 6.5 : 7.5, 2.0}};
     struct Entity { uint32_t m, id, kind; };
     std::vector<Entity> ents;
     if (i32) {
@@ -521,14 +542,6 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
                 r = hipMemset2DAsync(d.bnd.p, (d.bnd_stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream);
             if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: spill scratch: %s", d.id, hipGetErrorString(r)); }
         }
-        // the constant "row above a first round": 64 {H,F} entries of zeros, then 64 of the biased-int16 floor (1024)
-        {
-            std::vector<uint32_t> pages(2 * 64 * 2, 0u);
-            for (size_t i = 128; i < pages.size(); ++i) pages[i] = 0x04000400u;
-            r = d.top_pages.reserve(pages.size() * sizeof(uint32_t));
-            if (r == hipSuccess) r = hipMemcpy(d.top_pages.p, pages.data(), pages.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
-        }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
         // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
         // copy of a process takes ~10 ms, later ones run at ~20 GB/s) and the first launch of every kernel.
@@ -543,6 +556,8 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             memset(&a, 0, sizeof a); // empty queues: every wave leaves at once
             a.counters = (uint32_t *)d.counters.p;
             a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
+            if (r == hipSuccess) r = osw_launch_s16q(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_s16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_f16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_f16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
@@ -565,7 +580,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         release_registered(d);
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
-        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_f16, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
+        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
                           &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages})
             b->release();
         drain_events(d);
@@ -758,6 +773,13 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         a.ge_pk = nge | (nge << 16);
         a.goe_fb = goe | (goe << 16);
         a.ge_fb = ge | (ge << 16);
+    } else if (first_pass_is_frame(ctx)) {
+        // column-frame int16 cell: gap OPEN in the goe slot; the plain cell it falls back to gets (goe, ge)
+        const uint32_t go = (uint32_t)ctx->open_gap;
+        a.goe_pk = go | (go << 16);
+        a.ge_pk = ge | (ge << 16);
+        a.goe_fb = goe | (goe << 16);
+        a.ge_fb = ge | (ge << 16);
     } else {
         a.goe_pk = goe | (goe << 16);
         a.ge_pk = ge | (ge << 16);
@@ -781,11 +803,11 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, (2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
     const uint32_t grid = std::min<uint32_t>(d.grid, std::max<uint32_t>(1, (c.nitems + 3) / 4 + c.nitems_wg));
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
-    const bool f16 = ctx->cell_bits == 11;
-    const auto launch_single = f16 ? osw_launch_f16 : osw_launch_pk16;
-    const auto launch_pair = f16 ? osw_launch_f16q : osw_launch_pk16q;
-    OswSearchArgs as = a; // single queries, first pass (`a` itself stays on the integer profile for the int32 kernel)
-    if (f16) { as.prof = (const uint2 *)d.prof_f16.p; as.prof_fb = (const uint2 *)d.prof.p; }
+    const bool f16 = ctx->cell_bits == 11, frame = first_pass_is_frame(ctx);
+    const auto launch_single = f16 ? osw_launch_f16 : frame ? osw_launch_s16 : osw_launch_pk16;
+    const auto launch_pair = f16 ? osw_launch_f16q : frame ? osw_launch_s16q : osw_launch_pk16q;
+    OswSearchArgs as = a; // single queries, first pass (`a` itself stays on the plain integer profile for the int32 kernel)
+    if (f16 || frame) { as.prof = (const uint2 *)d.prof_alt.p; as.prof_fb = (const uint2 *)d.prof.p; }
     if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
         // query pairs first (the bulk of a multi-query search), on their own queue counters
         OswSearchArgs aq = a;

@@ -23,6 +23,7 @@
 #define OSW_SCRATCH_DATA 128
 #define OSW_TILED_PAD_GROUPS 18  // all-dummy 4-column groups stored after every block (prefetch + drain of G <= 64: 66 columns)
 #define OSW_TILED_TAIL_GROUPS 2  // readable groups past the last block
+#define OSW_I16S_TABLE 8448u     // entries of the column-frame cell's floor table (frame offsets stay <= 8192, + drain)
 #define OSW_DUMMY_CODE8 0xB8u    // residue code 23 (dummy), pre-multiplied by 8 as stored in `tiled`
 
 // Work item: x = query | sub-block << 16 | log2(G) << 24 | halves << 28 | priority << 30, y = block.
@@ -104,7 +105,8 @@ struct OswSearchArgs {
     const uint2 *prof_fb;      // fp16 kernels: the int16 profile of the same queries / pairs (items redone in int16)
     const uint32_t *prof_off;
     const uint16_t *qlen;
-    const uint2 *top_pages;    // 2 x 64 constant {H,F} entries: the row above a first round -- zeros, then the biased-int16 floor
+    const uint2 *top_pages;    // constant {H,F} entries, the row above a first round: 64 of zeros, 64 of the biased-int16 floor,
+                               // then the column-frame cell's floor table (entry k = 1024 + k * ge)
     uint2 *bnd;                // strip-boundary spill {H,F} per column and lane, one region per resident wave
     uint64_t bnd_stride;       // uint2 per region (OSW_SCRATCH_DATA + columns x lanes per group)
     int32_t *scores;           // [nq][score_stride]
@@ -124,6 +126,8 @@ struct OswSearchArgs {
 hipError_t osw_launch_pk16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_s16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_f16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_f16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
@@ -132,7 +136,7 @@ hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
-                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, uint2 *prof, hipStream_t s);
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, int add, uint2 *prof, hipStream_t s);
 uint32_t osw_topr_parts(uint32_t nvalid); // partitions per score row; `cand` holds nq * parts * r tagged keys
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
                            unsigned long long *cand, int32_t *out_scores, uint32_t *out_index, hipStream_t s);

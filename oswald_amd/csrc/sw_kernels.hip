@@ -230,16 +230,78 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
                      : OSW_INFLIGHT);                                                        \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// "Column frame" variant of the biased int16 cell: 6.5 instructions per row.
+// Every value of database column j is stored as  true + 1024 + (j + G) * ge.
+// The horizontal gap E then needs no decay at all -- in the frame of column
+// j+1 the same pattern stands for E - ge -- and the vertical one is taken out
+// of the maximum:  F' = max(F - ge, H - goe, 0)  =  max3(F, H - go, fl1) - ge,
+// with the SAME  u = H - go  (go = gap open) and the same floor fl1 ("zero" in
+// the frame of column j+1, a per-lane register bumped once per column) as
+// E' = max3(E, u, fl1).  The diagonal H(i-1, j-1) sits one frame back, which the
+// profile absorbs (it stores S + ge).  Per row: diagonal add, H = max3, u,
+// E = max3, F = max3, F - ge, and 1/2 for the column maximum; per column the
+// maximum is brought back to a true score (cm - "zero of column j") and folded
+// into the running one.  The frame offset must stay small: an item takes this
+// cell only if (columns + 2G + 2) * ge <= 8192 (else the plain biased cell), and
+// a sequence scoring 22256 or more is re-run in int32.
+//   x, Dn, E, F, sc as above; u_ in go_ slot: gap open; fl1: the floor operand
+// ---------------------------------------------------------------------------
+#define OSW_I16S_FRAME_MAX 8192u
+#define OSW_I16S_ROW_EVEN(FREG, x, xn, Er, Dn, s_next, ge, go, fl1)                          \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_sub_u16 %[t], %[Dn_], %[go_] clamp\n\t"                           \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn)         \
+                     : [x_] "v"(x), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
+#define OSW_I16S_ROW_ODD(FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1)                   \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_sub_u16 %[t], %[Dn_], %[go_] clamp\n\t"                           \
+                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[Dn_]\n\t"                  \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
+                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
+#define OSW_I16S_ROW_LAST(FREG, x, Er, hl, Dp, sc, ge, go, fl1)                              \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_maximum3_f16 %[hl_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_sub_u16 %[t], %[hl_], %[go_] clamp\n\t"                           \
+                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[hl_]\n\t"                  \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     : [hl_] "=&v"(hl), [t] "=&v"(t_), [E_] "+v"(Er), [sc_] "+v"(sc)         \
+                     : [x_] "v"(x), [Dp_] "v"(Dp), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
 // Cell arithmetic policies: the row forms on input set P (0: even column, 1: odd
 // column) and what a finished score means.
 //   row<P, ODD>: x in/out, Dp = H of the row above (= D[r]); odd rows fold two rows' H into the running maximum
 struct ArithI16B {
     static constexpr int kCeiling = 31600 - 1024; // true score from which a sequence is re-run in int32
+    static constexpr bool kShifted = false;
     static constexpr uint32_t kFloor = OSW_I16B_BIAS;
     static constexpr bool kEarlyExit = false;
     static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
     template <int P, bool ODD>
-    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe)
+    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe, v2s /*aux*/)
     {
         v2s xn;
         if constexpr (ODD) OSW_I16B_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, goe);
@@ -247,7 +309,7 @@ struct ArithI16B {
         x = xn;
     }
     template <int P>
-    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe)
+    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe, v2s /*aux*/)
     {
         OSW_I16B_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, ge, goe);
     }
@@ -257,15 +319,42 @@ struct ArithI16B {
     static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 31600u; }
 };
 
+// `goe` carries the gap OPEN penalty for this cell, `aux` the floor of the next column's frame, and the rows
+// accumulate the COLUMN maximum (in the column's frame) into `sc`; sw_round_fast turns it into a true score.
+struct ArithI16S {
+    static constexpr int kCeiling = 22256; // true score from which a sequence is re-run in int32 (31600 - 1024 - 8192 - 128)
+    static constexpr uint32_t kFloor = OSW_I16B_BIAS;
+    static constexpr bool kEarlyExit = false;
+    static constexpr bool kShifted = true;
+    static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
+    template <int P, bool ODD>
+    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t go, v2s fl1)
+    {
+        v2s xn;
+        if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
+        else OSW_I16S_ROW_EVEN(OSW_VF, x, xn, Er, Dn, s_next, ge, go, fl1);
+        x = xn;
+    }
+    template <int P>
+    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t ge, uint32_t go, v2s fl1)
+    {
+        OSW_I16S_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, ge, go, fl1);
+    }
+    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0) { return __builtin_elementwise_add_sat(top_prev, s0); }
+    static __device__ __forceinline__ int to_int(short bits) { return (int)(uint16_t)bits; } // the running score is a true one
+    static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 22256u; }
+};
+
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 struct ArithF16 {
     static constexpr int kCeiling = 2048; // scores at or above it are not exact in fp16
+    static constexpr bool kShifted = false;
     static constexpr uint32_t kFloor = 0;
     static constexpr bool kEarlyExit = true; // checked after every round: the item is redone in packed int16 at once
     // non-negative fp16 values order like their bit patterns; 2048.0 = 0x6800
     static __device__ __forceinline__ bool at_ceiling(v2s s) { return (uint16_t)s.x >= 0x6800u || (uint16_t)s.y >= 0x6800u; }
     template <int P, bool ODD>
-    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t nge, uint32_t ngoe)
+    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t nge, uint32_t ngoe, v2s /*aux*/)
     {
         v2s xn;
         if constexpr (ODD) OSW_F16_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe);
@@ -273,7 +362,7 @@ struct ArithF16 {
         x = xn;
     }
     template <int P>
-    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t nge, uint32_t ngoe)
+    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t nge, uint32_t ngoe, v2s /*aux*/)
     {
         OSW_F16_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, nge, ngoe);
     }
@@ -293,6 +382,7 @@ struct CellSeqPair {
     static constexpr bool kFast = true;
     static constexpr bool kEarlyExit = A::kEarlyExit;
     static constexpr uint32_t kFloorBits = A::kFloor;
+    static constexpr bool kShifted = A::kShifted;
     static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16;
@@ -341,7 +431,7 @@ struct CellSeqPair {
         // paired up its registers take the load of the block after it (one block ahead is enough:
         // a block is ~35 VALU instructions, LDS latency a fraction of that)
         static __device__ __forceinline__ void run(uint32_t a_lo, uint32_t a_hi, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge,
-                                                   T &score, T (&s)[4], Raw &r1)
+                                                   T &score, T (&s)[4], Raw &r1, T aux)
         {
             T sn[4];
             if constexpr (RB + 1 < R / 4) {
@@ -349,14 +439,14 @@ struct CellSeqPair {
                 pair_up(r1, sn);
                 if constexpr (RB + 2 < R / 4) ld<RB + 2>(a_lo, a_hi, r1);
             }
-            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s[1], ge, goe);
-            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s[2], ge, goe);
-            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s[3], ge, goe);
+            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s[1], ge, goe, aux);
+            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s[2], ge, goe, aux);
+            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s[3], ge, goe, aux);
             if constexpr (RB + 1 < R / 4) {
-                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn[0], ge, goe);
-                Batch<R, RB + 1, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, sn, r1);
+                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn[0], ge, goe, aux);
+                Batch<R, RB + 1, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, sn, r1, aux);
             } else {
-                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe);
+                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe, aux);
             }
         }
     };
@@ -368,7 +458,7 @@ struct CellSeqPair {
     //   top_prev = H(i0-1, j-1); hl = H(i0+R-1, j).
     template <int R, int P>
     static __device__ __forceinline__ void column(uint32_t base, int /*half*/, T (&D)[R], T (&E)[R], T top_prev, T &hl, GapT goe, GapT ge,
-                                                  T &score)
+                                                  T &score, T aux)
     {
         uint32_t a_lo, a_hi;
         if constexpr (P == 0)
@@ -385,7 +475,7 @@ struct CellSeqPair {
         if constexpr (R / 4 > 1) { ld<1>(a_lo, a_hi, r1); landed<2>(r0); } else { landed<0>(r0); }
         pair_up(r0, s);
         T x = A::first_diag(top_prev, s[0]);
-        Batch<R, 0, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, s, r1);
+        Batch<R, 0, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, s, r1, aux);
     }
 };
 
@@ -406,6 +496,7 @@ struct CellQueryPair {
     static constexpr bool kFast = true;
     static constexpr bool kEarlyExit = A::kEarlyExit;
     static constexpr uint32_t kFloorBits = A::kFloor;
+    static constexpr bool kShifted = A::kShifted;
     static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
@@ -430,28 +521,28 @@ struct CellQueryPair {
     template <int R, int RB, int P>
     struct Batch {
         static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge, T &score,
-                                                   u32x4 &r0, u32x4 &r1)
+                                                   u32x4 &r0, u32x4 &r1, T aux)
         {
             // r0 = this row-block (landed; .x was used by the row above), r1 = next (in flight); r0 takes
             // the load of the block after next as soon as its last score has been read
             T s1 = as_v2s(r0.y), s2 = as_v2s(r0.z), s3 = as_v2s(r0.w);
-            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s1, ge, goe);
-            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s2, ge, goe);
-            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s3, ge, goe);
+            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s1, ge, goe, aux);
+            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s2, ge, goe, aux);
+            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s3, ge, goe, aux);
             if constexpr (RB + 1 < R / 4) {
                 if constexpr (RB + 2 < R / 4) { ld<RB + 2>(a, r0); landed<1>(r1); } else { landed<0>(r1); }
                 T sn = as_v2s(r1.x);
-                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn, ge, goe);
-                Batch<R, RB + 1, P>::run(a, D, E, x, hl, goe, ge, score, r1, r0);
+                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn, ge, goe, aux);
+                Batch<R, RB + 1, P>::run(a, D, E, x, hl, goe, ge, score, r1, r0, aux);
             } else {
-                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe);
+                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe, aux);
             }
         }
     };
 
     template <int R, int P>
     static __device__ __forceinline__ void column(uint32_t base, int half, T (&D)[R], T (&E)[R], T top_prev, T &hl, GapT goe, GapT ge,
-                                                  T &score)
+                                                  T &score, T aux)
     {
         // profile entry of the lane's residue: 16 B per code = 2 x (8*code)
         uint32_t a;
@@ -468,12 +559,14 @@ struct CellQueryPair {
         ld<0>(a, r0);
         if constexpr (R / 4 > 1) { ld<1>(a, r1); landed<1>(r0); } else { landed<0>(r0); }
         T x = A::first_diag(top_prev, as_v2s(r0.x));
-        Batch<R, 0, P>::run(a, D, E, x, hl, goe, ge, score, r0, r1);
+        Batch<R, 0, P>::run(a, D, E, x, hl, goe, ge, score, r0, r1, aux);
     }
 };
 
 typedef CellSeqPair<ArithI16B> CellPK16B;
 typedef CellQueryPair<ArithI16B> CellPK16BQ;
+typedef CellSeqPair<ArithI16S> CellPK16S;
+typedef CellQueryPair<ArithI16S> CellPK16SQ;
 typedef CellSeqPair<ArithF16> CellPKF16;
 typedef CellQueryPair<ArithF16> CellPKF16Q;
 
@@ -485,6 +578,7 @@ struct CellI32 {
     static constexpr bool kFast = false;
     static constexpr bool kEarlyExit = false;
     static constexpr uint32_t kFloorBits = 0;
+    static constexpr bool kShifted = false;
     static __device__ __forceinline__ bool at_ceiling(T) { return false; }
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
@@ -571,12 +665,12 @@ static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
                  "ds_bpermute_b32 " OSW_VF ", %[src], " OSW_VF "\n"                                           \
                  "1:\n\t"                                                                                    \
                  "s_mov_b64 exec, %[mg0]\n\t"                                                                \
-                 "global_load_dword " LHP ", %[voff], %[lptr]\n\t"                                           \
-                 "global_load_dword " LFP ", %[voff], %[lptr] offset:4\n\t"                                  \
+                 "global_load_dword " LHP ", %[voffl], %[lptr]\n\t"                                          \
+                 "global_load_dword " LFP ", %[voffl], %[lptr] offset:4\n\t"                                 \
                  "s_mov_b64 exec, %[sv]\n\t"                                                                 \
                  "global_load_ushort " CP ", %[voffc], %[tptr]"                                              \
                  : [tp] "=&v"(tp), [sv] "=&s"(sv)                                                            \
-                 : [src] "v"(src), [ho] "v"(ho), [voff] "v"(voff), [voffc] "v"(voffc), [mst] "s"(m_st),       \
+                 : [src] "v"(src), [ho] "v"(ho), [voff] "v"(voff), [voffl] "v"(voffl), [voffc] "v"(voffc), [mst] "s"(m_st), \
                    [mg0] "s"(m_g0), [sptr] "s"(sptr), [lptr] "s"(lptr), [tptr] "s"(tptr)                      \
                  : "memory", "scc", OSW_INFLIGHT)
 
@@ -586,23 +680,34 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
                                                      typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
     typedef typename C::T T;
-    T D[R], E[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { D[r] = C::zero(); E[r] = C::zero(); }
-    T top_prev = C::zero(); // H(i0-1, j-1)
     const uint64_t m_g0 = gl >= 64 ? ~0ull : (1ull << gl) - 1ull; // lanes of group 0
     const uint64_t m_st = ~0ull << (64u - gl);                     // lanes of the last group
     const uint32_t src = (uint32_t)((lane - (int)gl) & 63) << 2;   // ds_bpermute source: the lane one group below
     const uint32_t g = (uint32_t)lane / gl;
+    // "zero" for this lane's first step.  Column-frame cell: the lane starts at column -g, whose frame offset is
+    // (G - g) * ge (see ArithI16S); the state that belongs to the column before it sits one frame back.
+    T fl = as_v2s(C::kFloorBits), fl_prev = fl;
+    if constexpr (C::kShifted) {
+        fl = as_v2s(C::kFloorBits + (G - g) * ge);        // ge holds the penalty in both halves: no carry between them below 2^15
+        fl_prev = as_v2s(C::kFloorBits + (G - g - 1u) * ge);
+    }
+    T D[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { D[r] = fl_prev; E[r] = fl; }
+    T top_prev = fl_prev; // H(i0-1, j-1)
     // group g reads its residues g columns behind group 0: the pointer runs G-1 columns behind,
     // the lanes' offsets make up for it (columns before the block are the dummy pad in front of it)
     const uint32_t voff = u * 8u, voffc = u * 2u + (G - 1u - g) * 128u;
     // a last round stores into the trash page; so do the G-1 warm-up steps in which the last group is
     // still before column 0 (the store pointer starts G-1 columns before the data: inside the trash page)
     const uint64_t data = (uint64_t)(bnd + OSW_SCRATCH_DATA);
-    const uint32_t lstep = first ? 0u : gl * 8u, sstep = last ? 0u : gl * 8u;
-    // a first round reads the row above it -- "zero" in the cell's representation -- from a constant page
-    uint64_t lptr = first ? (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0)) : data;
+    const uint32_t sstep = last ? 0u : gl * 8u;
+    // A first round reads the row above it -- "zero" in the cell's representation -- from constant memory: one
+    // entry for every column (zero stride), or, for the column-frame cell, the table of per-column floors
+    // (entry k = 1024 + k * ge; column 0 is entry G), 8 B per column, the same entry for every lane.
+    const uint32_t lstep = !first ? gl * 8u : C::kShifted ? 8u : 0u;
+    const uint32_t voffl = first && C::kShifted ? 0u : voff;
+    uint64_t lptr = !first ? data : C::kShifted ? (uint64_t)(top_pages + 128 + G) : (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0));
     uint64_t sptr = last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u;
     uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * 128u;
     uint64_t sv;
@@ -613,25 +718,38 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
                  "global_load_ushort " OSW_VC1 ", %[voffc], %[tptr] offset:128\n\t"
                  "s_mov_b64 %[sv], exec\n\t"
                  "s_mov_b64 exec, %[mg0]\n\t"
-                 "global_load_dword " OSW_VLH0 ", %[voff], %[lptr]\n\t"
-                 "global_load_dword " OSW_VLF0 ", %[voff], %[lptr] offset:4\n\t"
-                 "global_load_dword " OSW_VLH1 ", %[voff], %[lptr2]\n\t"
-                 "global_load_dword " OSW_VLF1 ", %[voff], %[lptr2] offset:4\n\t"
+                 "global_load_dword " OSW_VLH0 ", %[voffl], %[lptr]\n\t"
+                 "global_load_dword " OSW_VLF0 ", %[voffl], %[lptr] offset:4\n\t"
+                 "global_load_dword " OSW_VLH1 ", %[voffl], %[lptr2]\n\t"
+                 "global_load_dword " OSW_VLF1 ", %[voffl], %[lptr2] offset:4\n\t"
                  "s_mov_b64 exec, %[sv]\n\t"
                  "s_waitcnt vmcnt(0)"
                  : [sv] "=&s"(sv)
-                 : [voff] "v"(voff), [voffc] "v"(voffc), [mg0] "s"(m_g0), [lptr] "s"(lptr), [lptr2] "s"(lptr + lstep), [tptr] "s"(tptr),
-                   [fl] "s"(C::kFloorBits)
+                 : [voffl] "v"(voffl), [voffc] "v"(voffc), [mg0] "s"(m_g0), [lptr] "s"(lptr), [lptr2] "s"(lptr + lstep), [tptr] "s"(tptr),
+                   [fl] "v"(fl)
                  : "memory", OSW_INFLIGHT);
     lptr += 2 * lstep;
     tptr += 256;
     const uint32_t nsteps = ncols + G - 1;
+    // one column on input set P: the plain cells keep the running maximum themselves; the column-frame cell
+    // returns the column's maximum in its frame, which is turned into a true score here
+#define OSW_COLUMN(P)                                                                                              \
+    if constexpr (C::kShifted) {                                                                                   \
+        const T fl1 = fl + as_v2s(ge);                                                                             \
+        T cm = fl;                                                                                                 \
+        C::template column<R, P>(base, half, D, E, top_prev, hl, goe, ge, cm, fl1);                                \
+        const v2u tru = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, cm), __builtin_bit_cast(v2u, fl));   \
+        score = __builtin_bit_cast(v2s, __builtin_elementwise_max(__builtin_bit_cast(v2u, score), tru));           \
+        fl = fl1;                                                                                                  \
+    } else {                                                                                                       \
+        C::template column<R, P>(base, half, D, E, top_prev, hl, goe, ge, score, fl);                              \
+    }
 #pragma unroll 1
     for (uint32_t t = 0; t < nsteps; t += 2) {
         {
             OSW_STEP_BEGIN_ASM(OSW_VLF0);
             T hl, tp;
-            C::template column<R, 0>(base, half, D, E, top_prev, hl, goe, ge, score);
+            OSW_COLUMN(0)
             const uint32_t ho = C::to_bits(hl);
             OSW_STEP_END_ASM(OSW_VC0, OSW_VLH0, OSW_VLF0);
             top_prev = tp;
@@ -642,7 +760,7 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
         if (t + 1 < nsteps) {
             OSW_STEP_BEGIN_ASM(OSW_VLF1);
             T hl, tp;
-            C::template column<R, 1>(base, half, D, E, top_prev, hl, goe, ge, score);
+            OSW_COLUMN(1)
             const uint32_t ho = C::to_bits(hl);
             OSW_STEP_END_ASM(OSW_VC1, OSW_VLH1, OSW_VLF1);
             top_prev = tp;
@@ -651,6 +769,7 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
             tptr += 128;
         }
     }
+#undef OSW_COLUMN
     // the prefetches of the two columns past the end are still in flight
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", OSW_INFLIGHT);
 }
@@ -775,9 +894,14 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         // the scratch columns the prefetch and the drain steps read past the block's last one are the
         // row above of dummy columns: "zero" in the cell's representation (other items have written here)
         uint2 *pad = bnd + OSW_SCRATCH_DATA + (size_t)ncols * gl;
-        for (uint32_t k = lane; k < (G + 2u) * gl; k += 64) pad[k] = make_uint2(C::kFloorBits, C::kFloorBits);
+        for (uint32_t k = lane; k < (G + 2u) * gl; k += 64) {
+            uint32_t z = C::kFloorBits;
+            if constexpr (C::kShifted) z += (ncols + k / gl + G) * (uint32_t)ge; // zero in the frame of that column
+            pad[k] = make_uint2(z, z);
+        }
     }
     T score = C::zero();
+    if constexpr (C::kShifted) score = C::from_bits(0u); // the column-frame cell keeps a true (unbiased) running score
     bool lane_hit = false;
     hit = false;
     // Workgroup-wide "some sequence has reached the ceiling": the waves OR into wg_hit[round & 1] before the
@@ -949,10 +1073,14 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x) + wv, lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
+        // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest, and the
+        // items an early-exit cell gives up, run on the fallback cell CF
+        const bool cf_only = C::kShifted && (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX;
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
-            bool hit;
-            v2s score = run_item<C, true>(p, p.prof, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
-            if (C::kEarlyExit && hit) {
+            bool hit = cf_only;
+            v2s score;
+            if (!cf_only) score = run_item<C, true>(p, p.prof, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
+            if (hit) {
                 score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], wg_hit, bnd_wave, p.goe_fb, p.ge_fb, hit);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
@@ -980,10 +1108,12 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
+        const bool cf_only = C::kShifted && (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX;
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
-            bool hit;
-            v2s score = run_item<C, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_prof[wv], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
-            if (C::kEarlyExit && hit) {
+            bool hit = cf_only;
+            v2s score;
+            if (!cf_only) score = run_item<C, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_prof[wv], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
+            if (hit) {
                 score = run_item<CF, false>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, lds_prof[wv], wg_hit, bnd_wave, p.goe_fb, p.ge_fb, hit);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
@@ -1002,6 +1132,11 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswS
 // Query pairs: `items` / `qlen` / `prof` / `prof_off` describe pairs (length = the longer query,
 // profile = packed (A, B) scores); pair_q maps a pair to its two query rows of the score table.
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true>(p); }
+
+// Column-frame cell (6.5 instructions per row) with the plain biased cell for the blocks it cannot take:
+// `prof` holds S + ge, goe_pk the gap OPEN penalty; prof_fb / goe_fb / ge_fb serve the plain cell.
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_s16(OswSearchArgs p) { pk16_body<CellPK16S, CellPK16B, false>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
 
 // The same two kernels with a packed-fp16 first pass (ceiling 2047, see ArithF16): goe_pk / ge_pk carry
 // the NEGATED penalties as fp16 pairs and `prof` holds fp16 scores.  An item in which any sequence
@@ -1117,10 +1252,11 @@ extern "C" __global__ __launch_bounds__(128) void osw_block_extent(OswBlock *blo
 // prof[(prof_off[q] + i/4)*32 + code] = 4 x int16 = S(a[i..i+3], code);
 // rows past the query end and query codes >= 24 score 0 (the reference's
 // 24th matrix row is all zero, submat.c).  fp16 != 0: the scores as fp16 bit
-// patterns (for the packed-fp16 kernels).
+// patterns (for the packed-fp16 kernels); add: a constant added to every entry
+// (the column-frame int16 cell wants S + ge, also in the zero rows).
 extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_t *__restrict__ a, const uint32_t *__restrict__ a_disp,
                                                                      const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ prof_off,
-                                                                     const int8_t *__restrict__ submat, uint32_t nq, uint32_t fp16,
+                                                                     const int8_t *__restrict__ submat, uint32_t nq, uint32_t fp16, int add,
                                                                      uint2 *__restrict__ prof)
 {
     const uint32_t q = blockIdx.y;
@@ -1139,7 +1275,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_
                 const uint32_t ai = aq[i];
                 if (ai < 24) v = submat[ai * 32 + code];
             }
-            s[k] = fp16 ? __builtin_bit_cast(short, (_Float16)v) : (short)v; // |v| <= 128: exact in fp16
+            s[k] = fp16 ? __builtin_bit_cast(short, (_Float16)v) : (short)(v + add); // |v| <= 128: exact in fp16; add: column-frame cell
         }
         uint2 o;
         o.x = (uint32_t)(uint16_t)s[0] | ((uint32_t)(uint16_t)s[1] << 16);
@@ -1261,6 +1397,20 @@ hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s
     return hipSuccess;
 }
 
+hipError_t osw_launch_s16(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_s16, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_s16q, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t osw_launch_f16(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 {
     hipLaunchKernelGGL(osw_sw_f16, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
@@ -1306,12 +1456,12 @@ hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t
 }
 
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
-                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, uint2 *prof, hipStream_t s)
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, int add, uint2 *prof, hipStream_t s)
 {
     if (nq == 0) return hipSuccess;
     uint32_t gx = (max_rowblocks * 32 + 255) / 256;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, fp16, prof);
+    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, fp16, add, prof);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_line_schema(first_pass):
-    if first_pass != "f16":
+    if first_pass != "i16":
         pytest.skip("one run is enough: bench.py picks its own first-pass mode")
     env = dict(os.environ)
     env.pop("OSWALD_HIP_CELL_BITS", None)
