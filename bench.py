@@ -11,7 +11,7 @@ query profile) are resident in HBM before the timed region starts.
 
 Workload at N = 1: BASELINE.json configs[1] -- 20 queries of length 100..1000
 (sum 11 000) against a 100k-sequence synthetic length-binned database
-(~36.5 M residues), BLOSUM62, gap 10/2, int16 cells (packed, exact below 30576;
+(~36.5 M residues), BLOSUM62, gap 10/2, int16 cells (packed, exact below 22256;
 sequences above are re-run in int32).  For N > 1 every
 rank holds its own 100k-sequence shard (weak scaling; shards are chunk-sharded
 parts of an N x 100k-sequence database, no data-path collective).
@@ -39,9 +39,9 @@ SIMD_PER_CU = 4
 PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (tools/ubench.hip, measured 4.2-4.5)
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
-PK_OPS_PER_ROW = {11: (8.5, 7.5), 16: (8.5, 7.5), 32: (24.0, 24.0)}
+PK_OPS_PER_ROW = {11: (8.5, 7.5), 16: (7.5, 6.5), 32: (24.0, 24.0)}
 DTYPE = {11: "f16", 16: "int16", 32: "int32"}
-CELL_LABEL = {11: "packed fp16 first pass (exact < 2048), int16 / int32 re-runs", 16: "int16 cells (packed, exact < 30576), int32 re-run above",
+CELL_LABEL = {11: "packed fp16 first pass (exact < 2048), int16 / int32 re-runs", 16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above",
               32: "int32 cells"}
 
 
@@ -172,7 +172,7 @@ def main():
         kern_gcups = sum_m * d_local / kern_s / 1e9 if kern_s > 0 else 0.0
         ops_row = PK_OPS_PER_ROW[cell_bits][1 if nq > 1 else 0]  # a multi-query search runs (mostly) as query pairs
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / ops_row / 1e9
-        kname = {11: "osw_sw_f16q+osw_sw_f16(+osw_sw_i32)", 16: "osw_sw_pk16q+osw_sw_pk16(+osw_sw_i32)", 32: "osw_sw_i32"}[cell_bits]
+        kname = {11: "osw_sw_f16q+osw_sw_f16(+osw_sw_i32)", 16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32"}[cell_bits]
         traffic = measured_traffic(args.workload, args.nseq)
         result = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

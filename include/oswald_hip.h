@@ -75,7 +75,7 @@ int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen);
  * length L costs open + L*extend).  Replaces the static kernel arguments 3 and
  * 4 of FPGAsearch.c:101-109 and the score-profile build of :143-177 (done on
  * the device here).  cell_bits selects the first-pass cell arithmetic: 16
- * (packed int16, the default; also selected by 0: exact below 30576), 11
+ * (packed int16, the default; also selected by 0: exact below 22256), 11
  * (packed fp16: exact below 2048, sequences above it are redone in int16) or 32
  * (plain int32).  Results are exact in every mode: a sequence whose score
  * reaches the ceiling of the first pass is re-run in int32 on the device (the

@@ -418,3 +418,21 @@ def test_scores_around_the_int16_ceiling(hip_ctx, oracle):
     np.testing.assert_array_equal(got, want)
     assert want.max(axis=1).tolist() == targets[::2]
     assert ((want > 30000) & (want < 30576)).any() and (want >= 30576).any()
+
+
+@pytest.mark.parametrize("ge,go", [(2, 10), (0, 0), (1, 11), (7, 3)])
+def test_scores_around_the_frame_cell_ceiling(hip_ctx, oracle, ge, go):
+    """The column-frame int16 cell (default) hands sequences scoring 22256 or more to the int32 kernel; blocks whose
+    frame offset (columns + 2G + 2) * ge would pass 8192 run on the plain biased cell (30576).  Self-alignments just
+    below, at and above both thresholds, with several gap-extend penalties (ge = 7 makes the long blocks ineligible)."""
+    targets = [22200, 22255, 22256, 22257, 22300, 30575, 30576, 31000]
+    qs = [_self_scoring(t, 500 + t) for t in targets[1::3]]         # 22255, 22300, 31000
+    seqs = [_self_scoring(t, 500 + t) for t in targets]
+    seqs += [synth.random_residues(2900 + i, 0, 300 + 29 * i) for i in range(12)]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge)
+    want = expect(oracle, qs, b, n, disp, 16, sm, go, ge)
+    np.testing.assert_array_equal(got, want)
+    assert want.max(axis=1).tolist() == targets[1::3]
