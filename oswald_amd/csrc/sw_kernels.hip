@@ -243,8 +243,10 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // E = max3, F = max3, F - ge, and 1/2 for the column maximum; per column the
 // maximum is brought back to a true score (cm - "zero of column j") and folded
 // into the running one.  The frame offset must stay small: an item takes this
-// cell only if (columns + 2G + 2) * ge <= 8192 (else the plain biased cell), and
-// a sequence scoring 22256 or more is re-run in int32.
+// cell only if (columns + 2G + 2) * ge <= 8192 and ge <= 64 (else the plain biased
+// cell), and a sequence scoring 22256 or more is re-run in int32: the largest
+// pattern of a sequence that stays below is 22255 + 1024 + 8192, and a diagonal
+// sum adds at most 127 + ge to it: below 0x7C00.
 //   x, Dn, E, F, sc as above; u_ in go_ slot: gap open; fl1: the floor operand
 // ---------------------------------------------------------------------------
 #define OSW_I16S_FRAME_MAX 8192u
@@ -277,6 +279,22 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
                      : OSW_INFLIGHT);                                                        \
     } while (0)
 
+// first odd row of a column: starts the column maximum (sc is written, not read)
+#define OSW_I16S_ROW_ODD1(FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1)                  \
+    do {                                                                                     \
+        v2s t_;                                                                              \
+        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
+                     "v_pk_sub_u16 %[t], %[Dn_], %[go_] clamp\n\t"                           \
+                     "v_pk_maximum3_f16 %[sc_], %[Dp_], %[Dn_], %[Dn_]\n\t"                  \
+                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
+                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
+                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "=&v"(sc) \
+                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
+                     : OSW_INFLIGHT);                                                        \
+    } while (0)
+
 #define OSW_I16S_ROW_LAST(FREG, x, Er, hl, Dp, sc, ge, go, fl1)                              \
     do {                                                                                     \
         v2s t_;                                                                              \
@@ -300,7 +318,7 @@ struct ArithI16B {
     static constexpr uint32_t kFloor = OSW_I16B_BIAS;
     static constexpr bool kEarlyExit = false;
     static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
-    template <int P, bool ODD>
+    template <int P, bool ODD, bool FIRST = false>
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe, v2s /*aux*/)
     {
         v2s xn;
@@ -327,11 +345,12 @@ struct ArithI16S {
     static constexpr bool kEarlyExit = false;
     static constexpr bool kShifted = true;
     static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
-    template <int P, bool ODD>
+    template <int P, bool ODD, bool FIRST = false>
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t go, v2s fl1)
     {
         v2s xn;
-        if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
+        if constexpr (ODD && FIRST) OSW_I16S_ROW_ODD1(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
+        else if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
         else OSW_I16S_ROW_EVEN(OSW_VF, x, xn, Er, Dn, s_next, ge, go, fl1);
         x = xn;
     }
@@ -353,7 +372,7 @@ struct ArithF16 {
     static constexpr bool kEarlyExit = true; // checked after every round: the item is redone in packed int16 at once
     // non-negative fp16 values order like their bit patterns; 2048.0 = 0x6800
     static __device__ __forceinline__ bool at_ceiling(v2s s) { return (uint16_t)s.x >= 0x6800u || (uint16_t)s.y >= 0x6800u; }
-    template <int P, bool ODD>
+    template <int P, bool ODD, bool FIRST = false>
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t nge, uint32_t ngoe, v2s /*aux*/)
     {
         v2s xn;
@@ -440,7 +459,7 @@ struct CellSeqPair {
                 if constexpr (RB + 2 < R / 4) ld<RB + 2>(a_lo, a_hi, r1);
             }
             A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s[1], ge, goe, aux);
-            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s[2], ge, goe, aux);
+            A::template row<P, true, RB == 0>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s[2], ge, goe, aux);
             A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s[3], ge, goe, aux);
             if constexpr (RB + 1 < R / 4) {
                 A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn[0], ge, goe, aux);
@@ -527,7 +546,7 @@ struct CellQueryPair {
             // the load of the block after next as soon as its last score has been read
             T s1 = as_v2s(r0.y), s2 = as_v2s(r0.z), s3 = as_v2s(r0.w);
             A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s1, ge, goe, aux);
-            A::template row<P, true>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s2, ge, goe, aux);
+            A::template row<P, true, RB == 0>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s2, ge, goe, aux);
             A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s3, ge, goe, aux);
             if constexpr (RB + 1 < R / 4) {
                 if constexpr (RB + 2 < R / 4) { ld<RB + 2>(a, r0); landed<1>(r1); } else { landed<0>(r1); }
@@ -736,7 +755,7 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
 #define OSW_COLUMN(P)                                                                                              \
     if constexpr (C::kShifted) {                                                                                   \
         const T fl1 = fl + as_v2s(ge);                                                                             \
-        T cm = fl;                                                                                                 \
+        T cm; /* started by the first odd row */                                                                   \
         C::template column<R, P>(base, half, D, E, top_prev, hl, goe, ge, cm, fl1);                                \
         const v2u tru = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, cm), __builtin_bit_cast(v2u, fl));   \
         score = __builtin_bit_cast(v2s, __builtin_elementwise_max(__builtin_bit_cast(v2u, score), tru));           \
@@ -1075,7 +1094,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest, and the
         // items an early-exit cell gives up, run on the fallback cell CF
-        const bool cf_only = C::kShifted && (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX;
+        const bool cf_only = C::kShifted && ((uint32_t)p.ge > 64u || (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             bool hit = cf_only;
             v2s score;
@@ -1108,7 +1127,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        const bool cf_only = C::kShifted && (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX;
+        const bool cf_only = C::kShifted && ((uint32_t)p.ge > 64u || (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             bool hit = cf_only;
             v2s score;
