@@ -351,7 +351,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
     int force_lg = -1, force_wg = -1;
-    uint32_t wg_min_cols = 768, wg_wide_cols = 2048;
+    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048;
     if (const char *e = getenv("OSWALD_HIP_WG_MINCOLS")) wg_min_cols = (uint32_t)atoi(e);
     if (const char *e = getenv("OSWALD_HIP_WG_WIDECOLS")) wg_wide_cols = (uint32_t)atoi(e);
     if (const char *e = getenv("OSWALD_HIP_FORCE_LG")) force_lg = atoi(e);
