@@ -39,10 +39,9 @@ SIMD_PER_CU = 4
 PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (tools/ubench.hip, measured 4.2-4.5)
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
-PK_OPS_PER_ROW = {11: (8.5, 7.5), 16: (7.5, 6.5), 32: (24.0, 24.0)}
-DTYPE = {11: "f16", 16: "int16", 32: "int32"}
-CELL_LABEL = {11: "packed fp16 first pass (exact < 2048), int16 / int32 re-runs", 16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above",
-              32: "int32 cells"}
+PK_OPS_PER_ROW = {16: (7.5, 6.5), 32: (24.0, 24.0)}
+DTYPE = {16: "int16", 32: "int32"}
+CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells"}
 
 
 def parse():
@@ -53,9 +52,8 @@ def parse():
     ap.add_argument("--nseq", type=int, default=100000, help="database sequences per GPU")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
-    ap.add_argument("--cell-bits", type=int, default=16, choices=[11, 16, 32],
-                    help="first-pass arithmetic: 16 = packed int16 (the cells BASELINE.json names; the library's default), "
-                         "11 = packed fp16 (exact < 2048) with int16 / int32 re-runs, 32 = int32 only")
+    ap.add_argument("--cell-bits", type=int, default=16, choices=[16, 32],
+                    help="cell arithmetic: 16 = packed int16 (the cells BASELINE.json names; the library's default), 32 = int32 only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
     return ap.parse_args()
@@ -172,7 +170,7 @@ def main():
         kern_gcups = sum_m * d_local / kern_s / 1e9 if kern_s > 0 else 0.0
         ops_row = PK_OPS_PER_ROW[cell_bits][1 if nq > 1 else 0]  # a multi-query search runs (mostly) as query pairs
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / ops_row / 1e9
-        kname = {11: "osw_sw_f16q+osw_sw_f16(+osw_sw_i32)", 16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32"}[cell_bits]
+        kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32"}[cell_bits]
         traffic = measured_traffic(args.workload, args.nseq)
         result = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -74,13 +74,11 @@ int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen);
  * (host/src/submat.c); open_gap / extend_gap as on the command line (a gap of
  * length L costs open + L*extend).  Replaces the static kernel arguments 3 and
  * 4 of FPGAsearch.c:101-109 and the score-profile build of :143-177 (done on
- * the device here).  cell_bits selects the first-pass cell arithmetic: 16
- * (packed int16, the default; also selected by 0: exact below 22256), 11
- * (packed fp16: exact below 2048, sequences above it are redone in int16) or 32
- * (plain int32).  Results are exact in every mode: a sequence whose score
- * reaches the ceiling of the first pass is re-run in int32 on the device (the
- * reference escalates int8 -> int16 -> int32 on the host,
- * HybridSearch.c:1670-1680,:1774-1784). */
+ * the device here).  cell_bits selects the cell arithmetic: 16 (packed int16,
+ * the default; also selected by 0: exact below 22256) or 32 (plain int32).
+ * Results are exact in both modes: a sequence whose score reaches the ceiling
+ * of the int16 cell is re-run in int32 on the device (the reference escalates
+ * int8 -> int16 -> int32 on the host, HybridSearch.c:1670-1680,:1774-1784). */
 int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_gap, int extend_gap, int cell_bits);
 
 /* Query set: residues of all queries back to back (codes 0..23), lengths m[],

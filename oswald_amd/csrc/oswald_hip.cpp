@@ -224,15 +224,14 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     // plain integer profile: the plain int16 cell and the exact int32 kernel
     HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                      (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                     0u, 0, (uint2 *)d.prof.p, d.stream));
-    // the first pass's own profile where it differs: fp16 scores (cell_bits 11) or S + ge for the column-frame
-    // int16 cell (cell_bits 16)
-    const bool f16 = ctx->cell_bits == 11, frame = first_pass_is_frame(ctx), alt = f16 || frame;
+                                     0, (uint2 *)d.prof.p, d.stream));
+    // the column-frame int16 cell reads S + ge
+    const bool alt = first_pass_is_frame(ctx);
     if (alt) {
         HIP_TRY(d.prof_alt.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
         HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                          (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                         f16 ? 1u : 0u, frame ? ctx->extend_gap : 0, (uint2 *)d.prof_alt.p, d.stream));
+                                         ctx->extend_gap, (uint2 *)d.prof_alt.p, d.stream));
     }
     {
         // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
@@ -558,8 +557,6 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
             if (r == hipSuccess) r = osw_launch_s16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_s16(a, 1, d.stream);
-            if (r == hipSuccess) r = osw_launch_f16q(a, 1, d.stream);
-            if (r == hipSuccess) r = osw_launch_f16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_i32(a, 1, d.stream);
@@ -620,7 +617,7 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
     if (open_gap + extend_gap > 32767) return fail(OSWALD_HIP_EINVAL, "open+extend must fit int16");
     if (cell_bits == 0) cell_bits = getenv("OSWALD_HIP_CELL_BITS") ? atoi(getenv("OSWALD_HIP_CELL_BITS")) : 16;
-    if (cell_bits != 11 && cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 11, 16 or 32");
+    if (cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 16 or 32");
     memcpy(ctx->submat, submat, 24 * 32);
     ctx->open_gap = open_gap;
     ctx->extend_gap = extend_gap;
@@ -765,15 +762,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
     a.ovf_items = (uint2 *)c.ovf.p;
     const uint32_t goe = (uint32_t)(ctx->open_gap + ctx->extend_gap), ge = (uint32_t)ctx->extend_gap;
-    if (ctx->cell_bits == 11) {
-        // packed-fp16 kernels: the negated penalties as fp16 (values beyond 2048 need not be exact: every
-        // H of a lane that stays in the fp16 tier is below 2048, so H - goe is negative either way)
-        const uint32_t ngoe = __builtin_bit_cast(uint16_t, (_Float16)(-(float)goe)), nge = __builtin_bit_cast(uint16_t, (_Float16)(-(float)ge));
-        a.goe_pk = ngoe | (ngoe << 16);
-        a.ge_pk = nge | (nge << 16);
-        a.goe_fb = goe | (goe << 16);
-        a.ge_fb = ge | (ge << 16);
-    } else if (first_pass_is_frame(ctx)) {
+    if (first_pass_is_frame(ctx)) {
         // column-frame int16 cell: gap OPEN in the goe slot; the plain cell it falls back to gets (goe, ge)
         const uint32_t go = (uint32_t)ctx->open_gap;
         a.goe_pk = go | (go << 16);
@@ -803,11 +792,11 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, (2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
     const uint32_t grid = std::min<uint32_t>(d.grid, std::max<uint32_t>(1, (c.nitems + 3) / 4 + c.nitems_wg));
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
-    const bool f16 = ctx->cell_bits == 11, frame = first_pass_is_frame(ctx);
-    const auto launch_single = f16 ? osw_launch_f16 : frame ? osw_launch_s16 : osw_launch_pk16;
-    const auto launch_pair = f16 ? osw_launch_f16q : frame ? osw_launch_s16q : osw_launch_pk16q;
-    OswSearchArgs as = a; // single queries, first pass (`a` itself stays on the plain integer profile for the int32 kernel)
-    if (f16 || frame) { as.prof = (const uint2 *)d.prof_alt.p; as.prof_fb = (const uint2 *)d.prof.p; }
+    const bool frame = first_pass_is_frame(ctx);
+    const auto launch_single = frame ? osw_launch_s16 : osw_launch_pk16;
+    const auto launch_pair = frame ? osw_launch_s16q : osw_launch_pk16q;
+    OswSearchArgs as = a; // single queries (`a` itself stays on the plain integer profile for the int32 kernel)
+    if (frame) { as.prof = (const uint2 *)d.prof_alt.p; as.prof_fb = (const uint2 *)d.prof.p; }
     if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
         // query pairs first (the bulk of a multi-query search), on their own queue counters
         OswSearchArgs aq = a;

@@ -101,8 +101,8 @@ struct OswSearchArgs {
     uint32_t nitems_wg;
     uint32_t two_ended_waves;  // wave items: eat the queue from both ends (see osw_sw_pk16) or heaviest-first only
     uint32_t force_all;        // int32 kernel: run `items` instead of the overflow queue
-    const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16 (fp16 kernels: 4 x fp16)
-    const uint2 *prof_fb;      // fp16 kernels: the int16 profile of the same queries / pairs (items redone in int16)
+    const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16 (column-frame kernels: S + ge)
+    const uint2 *prof_fb;      // column-frame kernels: the plain profile of the same queries / pairs (blocks run on the plain cell)
     const uint32_t *prof_off;
     const uint16_t *qlen;
     const uint2 *top_pages;    // constant {H,F} entries, the row above a first round: 64 of zeros, 64 of the biased-int16 floor,
@@ -115,8 +115,8 @@ struct OswSearchArgs {
     uint32_t *counters_ovf;    // shared by all launches of a search: [0] = items queued for the int32 kernel
     const uint32_t *pair_q;    // query-pair kernel: the two queries of pair i (rows of the score table)
     uint2 *ovf_items;
-    uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves; fp16 kernels: negated, as fp16
-    uint32_t goe_fb, ge_fb;    // fp16 kernels: the int16 penalties for redone items
+    uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves; column-frame kernels: (open, extend)
+    uint32_t goe_fb, ge_fb;    // column-frame kernels: (open+extend, extend) for the plain cell
     int32_t goe, ge;
     uint32_t debug_nospill;    // diagnostics: every round reads the zero page and stores to the trash page (WRONG scores; timing only)
     unsigned long long *wg_times; // diagnostics (or null): per workgroup {start, end of phase 1, end, end} in 100 MHz ticks
@@ -128,15 +128,13 @@ hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
-hipError_t osw_launch_f16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
-hipError_t osw_launch_f16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          uint4 *prof_pair, hipStream_t s);
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
-                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, int add, uint2 *prof, hipStream_t s);
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, int add, uint2 *prof, hipStream_t s);
 uint32_t osw_topr_parts(uint32_t nvalid); // partitions per score row; `cand` holds nq * parts * r tagged keys
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
                            unsigned long long *cand, int32_t *out_scores, uint32_t *out_index, hipStream_t s);

@@ -11,13 +11,14 @@
 //     wave instruction per SIMD on gfx950 (measured, tools/ubench.hip), so the
 //     cell is kept as short as the ISA allows and hand-scheduled:
 //       - packed int16 values carrying a bias of 1024, on which gfx950's
-//         v_pk_maximum3_f16 is an integer max3: 7.5 VOP3P instructions per row
-//         (+1 v_perm_b32 when a lane holds two sequences), exact below 30576;
-//       - sequences that reach that ceiling are queued for the int32 kernel
+//         v_pk_maximum3_f16 is an integer max3, stored relative to a per-column
+//         frame that makes the horizontal gap decay free: 6.5 VOP3P
+//         instructions per row (+1 v_perm_b32 when a lane holds two sequences),
+//         exact below 22256 (plain biased cell for blocks whose frame would not
+//         fit: 7.5 per row, exact below 30576);
+//       - sequences that reach the ceiling are queued for the int32 kernel
 //     (the reference's int8->int16->int32 escalation, host/src/HybridSearch.c:
-//     1670-1680,:1774-1784, yields exact scores; so does this);
-//       - alternative first pass in real packed fp16 (exact below 2048, redone
-//         in int16 above), same instruction count, kept for comparison.
+//     1670-1680,:1774-1784, yields exact scores; so does this).
 //   * the query is cut into strips of R <= 32 rows held in registers (E and
 //     the diagonal H of every row, 2 VGPRs per row); database columns stream
 //     through.  The strip's slice of the query profile lives in a wave-private
@@ -104,68 +105,6 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // read (no s_nop inside the cell).  F runs down the column in the F register of
 // the step's input set (FREG), where the next strip picks it up.
 // ---------------------------------------------------------------------------
-
-// ---------------------------------------------------------------------------
-// Packed-fp16 cell for a first pass with a 2047 ceiling (the reference's first
-// tier is int8 with a 127 ceiling, host/src/HybridSearch.c:1573-1680).  fp16
-// represents every integer up to 2048 exactly, so as long as a lane's best score
-// stays below 2048 all its values are exact; a lane that reaches 2048 is queued
-// for the exact int32 kernel like a saturated int16 lane.  (x = D + S may round
-// above 2048, but then H >= x >= 2048 and the lane is re-run anyway.)
-// gfx950 has a packed three-operand maximum, v_pk_maximum3_f16: H = max3(x, E,
-// F) and E' = max3(E - ge, H - goe, 0) are one instruction each, and the running
-// maximum takes one instruction per TWO rows: 7.5 VOP3P instructions per row
-// against 9 for packed int16 (measured issue rate is the same, tools/ubench.hip).
-// Gap penalties arrive negated, as fp16 pairs.  Results are consumed at a
-// distance of >= 2 issue slots as in the int16 cell.
-//   x  in: D[r] + S[r];  xn out: D[r+1] + S[r+1];  Dn in: D[r+1], out: H(i0+r, j)
-//   odd rows also fold H of the row above (Dp) and their own H into the maximum
-// ---------------------------------------------------------------------------
-#define OSW_F16_ROW_EVEN(FREG, x, xn, Er, Dn, s_next, nge, ngoe)                             \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile("v_pk_add_f16 %[xn_], %[Dn_], %[sn_]\n\t"                               \
-                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_add_f16 %[E_], %[E_], %[ge_]\n\t"                                 \
-                     "v_pk_add_f16 %[t], %[Dn_], %[goe_]\n\t"                                \
-                     "v_pk_add_f16 " FREG ", " FREG ", %[ge_]\n\t"                           \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], 0\n\t"                           \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], 0"                         \
-                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn)         \
-                     : [x_] "v"(x), [sn_] "v"(s_next), [ge_] "s"(nge), [goe_] "s"(ngoe)      \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-#define OSW_F16_ROW_ODD(FREG, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe)                      \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile("v_pk_add_f16 %[xn_], %[Dn_], %[sn_]\n\t"                               \
-                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_add_f16 %[E_], %[E_], %[ge_]\n\t"                                 \
-                     "v_pk_add_f16 %[t], %[Dn_], %[goe_]\n\t"                                \
-                     "v_pk_add_f16 " FREG ", " FREG ", %[ge_]\n\t"                           \
-                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[Dn_]\n\t"                  \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], 0\n\t"                           \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], 0"                         \
-                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
-                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(nge), [goe_] "s"(ngoe) \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-#define OSW_F16_ROW_LAST(FREG, x, Er, hl, Dp, sc, nge, ngoe)                                 \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile("v_pk_maximum3_f16 %[hl_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_add_f16 %[E_], %[E_], %[ge_]\n\t"                                 \
-                     "v_pk_add_f16 %[t], %[hl_], %[goe_]\n\t"                                \
-                     "v_pk_add_f16 " FREG ", " FREG ", %[ge_]\n\t"                           \
-                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[hl_]\n\t"                  \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], 0\n\t"                           \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], 0"                         \
-                     : [hl_] "=&v"(hl), [t] "=&v"(t_), [E_] "+v"(Er), [sc_] "+v"(sc)         \
-                     : [x_] "v"(x), [Dp_] "v"(Dp), [ge_] "s"(nge), [goe_] "s"(ngoe)          \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
 
 // ---------------------------------------------------------------------------
 // Packed-int16 cell with the three-operand maximum ("biased int16").  For
@@ -316,8 +255,6 @@ struct ArithI16B {
     static constexpr int kCeiling = 31600 - 1024; // true score from which a sequence is re-run in int32
     static constexpr bool kShifted = false;
     static constexpr uint32_t kFloor = OSW_I16B_BIAS;
-    static constexpr bool kEarlyExit = false;
-    static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
     template <int P, bool ODD, bool FIRST = false>
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe, v2s /*aux*/)
     {
@@ -342,9 +279,7 @@ struct ArithI16B {
 struct ArithI16S {
     static constexpr int kCeiling = 22256; // true score from which a sequence is re-run in int32 (31600 - 1024 - 8192 - 128)
     static constexpr uint32_t kFloor = OSW_I16B_BIAS;
-    static constexpr bool kEarlyExit = false;
     static constexpr bool kShifted = true;
-    static __device__ __forceinline__ bool at_ceiling(v2s) { return false; }
     template <int P, bool ODD, bool FIRST = false>
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t go, v2s fl1)
     {
@@ -364,45 +299,14 @@ struct ArithI16S {
     static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 22256u; }
 };
 
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-struct ArithF16 {
-    static constexpr int kCeiling = 2048; // scores at or above it are not exact in fp16
-    static constexpr bool kShifted = false;
-    static constexpr uint32_t kFloor = 0;
-    static constexpr bool kEarlyExit = true; // checked after every round: the item is redone in packed int16 at once
-    // non-negative fp16 values order like their bit patterns; 2048.0 = 0x6800
-    static __device__ __forceinline__ bool at_ceiling(v2s s) { return (uint16_t)s.x >= 0x6800u || (uint16_t)s.y >= 0x6800u; }
-    template <int P, bool ODD, bool FIRST = false>
-    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t nge, uint32_t ngoe, v2s /*aux*/)
-    {
-        v2s xn;
-        if constexpr (ODD) OSW_F16_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, nge, ngoe);
-        else OSW_F16_ROW_EVEN(OSW_VF, x, xn, Er, Dn, s_next, nge, ngoe);
-        x = xn;
-    }
-    template <int P>
-    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t nge, uint32_t ngoe, v2s /*aux*/)
-    {
-        OSW_F16_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, nge, ngoe);
-    }
-    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0)
-    {
-        return __builtin_bit_cast(v2s, __builtin_bit_cast(v2h, top_prev) + __builtin_bit_cast(v2h, s0));
-    }
-    static __device__ __forceinline__ int to_int(short bits) { return (int)(float)__builtin_bit_cast(_Float16, bits); }
-    static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 0x6800u; }
-};
-
 template <class A>
 struct CellSeqPair {
     typedef A Arith;
     typedef v2s T;
     typedef uint32_t GapT; // (value, value) packed, wave-uniform
     static constexpr bool kFast = true;
-    static constexpr bool kEarlyExit = A::kEarlyExit;
     static constexpr uint32_t kFloorBits = A::kFloor;
     static constexpr bool kShifted = A::kShifted;
-    static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16;
     static constexpr int kRowBytes = 64; // profile bytes per query row: 32 codes x int16
@@ -513,10 +417,8 @@ struct CellQueryPair {
     typedef v2s T;
     typedef uint32_t GapT;
     static constexpr bool kFast = true;
-    static constexpr bool kEarlyExit = A::kEarlyExit;
     static constexpr uint32_t kFloorBits = A::kFloor;
     static constexpr bool kShifted = A::kShifted;
-    static __device__ __forceinline__ bool at_ceiling(T s) { return A::at_ceiling(s); }
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
     static constexpr int kRowBytes = 128; // 32 codes x 2 queries x int16
@@ -586,8 +488,6 @@ typedef CellSeqPair<ArithI16B> CellPK16B;
 typedef CellQueryPair<ArithI16B> CellPK16BQ;
 typedef CellSeqPair<ArithI16S> CellPK16S;
 typedef CellQueryPair<ArithI16S> CellPK16SQ;
-typedef CellSeqPair<ArithF16> CellPKF16;
-typedef CellQueryPair<ArithF16> CellPKF16Q;
 
 // Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.
 // Compiler-scheduled throughout (rare path: re-run of saturated lanes).
@@ -595,10 +495,8 @@ struct CellI32 {
     typedef int T;
     typedef int GapT;
     static constexpr bool kFast = false;
-    static constexpr bool kEarlyExit = false;
     static constexpr uint32_t kFloorBits = 0;
     static constexpr bool kShifted = false;
-    static __device__ __forceinline__ bool at_ceiling(T) { return false; }
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
     static constexpr int kRowBytes = 64;
@@ -890,13 +788,10 @@ static __device__ __forceinline__ void load_profile_round(const uint4 *prof_q, u
 //               the workgroup's whole LDS (4 x kLdsRows rows), which allows
 //               4x taller rounds for heavy items.  The only synchronisation
 //               is a pair of workgroup barriers around the slice reload.
-// A cell arithmetic with a low ceiling (packed fp16: 2047) is checked after
-// every round: as soon as any lane of the wave (workgroup) has reached it the
-// item is abandoned (`hit`) and the caller redoes it in packed int16.
 template <class C, bool WG>
 static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, const uint2 *prof, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
-                                                         uint32_t lg, int lane, int half, uint2 *lds_region, uint32_t *wg_hit, uint2 *bnd_wave,
-                                                         typename C::GapT goe, typename C::GapT ge, bool &hit)
+                                                         uint32_t lg, int lane, int half, uint2 *lds_region, uint2 *bnd_wave,
+                                                         typename C::GapT goe, typename C::GapT ge)
 {
     typedef typename C::T T;
     constexpr uint32_t kLds = WG ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
@@ -921,23 +816,11 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     }
     T score = C::zero();
     if constexpr (C::kShifted) score = C::from_bits(0u); // the column-frame cell keeps a true (unbiased) running score
-    bool lane_hit = false;
-    hit = false;
-    // Workgroup-wide "some sequence has reached the ceiling": the waves OR into wg_hit[round & 1] before the
-    // barrier that opens a round and read it after; thread 0 clears the other flag between the round's two
-    // barriers, i.e. strictly before anybody can OR into it again.
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, nrb = G * R / 4, rb_end = plan.m4 / 4;
         if constexpr (WG) {
-            if constexpr (C::kEarlyExit) {
-                if (rho > 0 && __any(lane_hit ? 1 : 0) && lane == 0) atomicOr(&wg_hit[rho & 1], 1u);
-            }
             __syncthreads(); // every wave is done with the previous slice
-            if constexpr (C::kEarlyExit) {
-                if (__builtin_amdgcn_readfirstlane(*(volatile uint32_t *)&wg_hit[rho & 1])) { hit = true; break; }
-                if (threadIdx.x == 0) wg_hit[(rho + 1) & 1] = 0;
-            }
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
             const uint4 *src = prof_q + (size_t)rb0 * rb16;
@@ -947,31 +830,10 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             for (uint32_t i = tid; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
             __syncthreads();
         } else {
-            if constexpr (C::kEarlyExit) {
-                if (__any(lane_hit ? 1 : 0)) { hit = true; break; }
-            }
             load_profile_round(prof_q, rb0, nrb, rb_end, rb16, lds_region, lane);
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * R * C::kRowBytes);
         sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, p.top_pages, rho == 0 || p.debug_nospill, rho + 1 == plan.rounds || p.debug_nospill, G, gl, lane, half, goe, ge, score);
-        if constexpr (C::kEarlyExit) lane_hit = C::at_ceiling(score);
-    }
-    if constexpr (C::kEarlyExit) {
-        if constexpr (WG) {
-            if (!hit) {
-                const uint32_t rho = plan.rounds;
-                if (__any(lane_hit ? 1 : 0) && lane == 0) atomicOr(&wg_hit[rho & 1], 1u);
-                __syncthreads();
-                hit = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)&wg_hit[rho & 1]) != 0;
-                if (!hit && threadIdx.x == 0) wg_hit[(rho + 1) & 1] = 0;
-            }
-            if (hit) { // leave both flags clean for the next item (the redo opens with a barrier of its own)
-                __syncthreads();
-                if (threadIdx.x == 0) { wg_hit[0] = 0; wg_hit[1] = 0; }
-            }
-        } else {
-            if (!hit) hit = __any(lane_hit ? 1 : 0) != 0;
-        }
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
     // addresses are computed here instead of being kept in registers across all the rounds)
@@ -1046,14 +908,12 @@ static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint
 // ---------------------------------------------------------------------------
 // Main kernel: packed int16.
 // ---------------------------------------------------------------------------
-// C = first-pass cell; CF = the cell an item is redone with when C reports its ceiling (CF = C: none)
+// C = the cell; CF = the cell for the blocks C cannot take (CF = C: none)
 template <class C, class CF, bool PAIR>
 static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8];
     __shared__ uint32_t wg_item;
-    __shared__ uint32_t wg_hit[2]; // see run_item
-    if (threadIdx.x < 2) wg_hit[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
@@ -1092,18 +952,15 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x) + wv, lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest, and the
-        // items an early-exit cell gives up, run on the fallback cell CF
+        // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest run on CF
         const bool cf_only = C::kShifted && ((uint32_t)p.ge > 64u || (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
-            bool hit = cf_only;
-            v2s score;
-            if (!cf_only) score = run_item<C, true>(p, p.prof, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
-            if (hit) {
-                score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], wg_hit, bnd_wave, p.goe_fb, p.ge_fb, hit);
+            if (cf_only) {
+                const v2s score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_fb, p.ge_fb);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
             } else {
+                const v2s score = run_item<C, true>(p, p.prof, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
                 if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
             }
@@ -1129,14 +986,12 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         const bool cf_only = C::kShifted && ((uint32_t)p.ge > 64u || (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
-            bool hit = cf_only;
-            v2s score;
-            if (!cf_only) score = run_item<C, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_prof[wv], wg_hit, bnd_wave, p.goe_pk, p.ge_pk, hit);
-            if (hit) {
-                score = run_item<CF, false>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, lds_prof[wv], wg_hit, bnd_wave, p.goe_fb, p.ge_fb, hit);
+            if (cf_only) {
+                const v2s score = run_item<CF, false>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_fb, p.ge_fb);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
             } else {
+                const v2s score = run_item<C, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
                 if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
             }
@@ -1156,14 +1011,6 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(Osw
 // `prof` holds S + ge, goe_pk the gap OPEN penalty; prof_fb / goe_fb / ge_fb serve the plain cell.
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_s16(OswSearchArgs p) { pk16_body<CellPK16S, CellPK16B, false>(p); }
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
-
-// The same two kernels with a packed-fp16 first pass (ceiling 2047, see ArithF16): goe_pk / ge_pk carry
-// the NEGATED penalties as fp16 pairs and `prof` holds fp16 scores.  An item in which any sequence
-// reaches the ceiling is redone on the spot in packed int16 (prof_fb, goe_fb, ge_fb), by the wave or
-// workgroup that found out, after the round in which it happened; from there on it is an int16 item
-// (a score at the int16 ceiling goes to the int32 kernel).
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16(OswSearchArgs p) { pk16_body<CellPKF16, CellPK16B, false>(p); }
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_f16q(OswSearchArgs p) { pk16_body<CellPKF16Q, CellPK16BQ, true>(p); }
 
 // ---------------------------------------------------------------------------
 // Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at
@@ -1194,8 +1041,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
         const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
-            bool hit;
-            const int score = run_item<CellI32, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_wave, nullptr, bnd_wave, p.goe, p.ge, hit);
+            const int score = run_item<CellI32, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge);
             if ((uint32_t)lane < gl)
                 p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }
@@ -1270,12 +1116,11 @@ extern "C" __global__ __launch_bounds__(128) void osw_block_extent(OswBlock *blo
 // Query profile in the layout the search kernels read:
 // prof[(prof_off[q] + i/4)*32 + code] = 4 x int16 = S(a[i..i+3], code);
 // rows past the query end and query codes >= 24 score 0 (the reference's
-// 24th matrix row is all zero, submat.c).  fp16 != 0: the scores as fp16 bit
-// patterns (for the packed-fp16 kernels); add: a constant added to every entry
+// 24th matrix row is all zero, submat.c).  add: a constant added to every entry
 // (the column-frame int16 cell wants S + ge, also in the zero rows).
 extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_t *__restrict__ a, const uint32_t *__restrict__ a_disp,
                                                                      const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ prof_off,
-                                                                     const int8_t *__restrict__ submat, uint32_t nq, uint32_t fp16, int add,
+                                                                     const int8_t *__restrict__ submat, uint32_t nq, int add,
                                                                      uint2 *__restrict__ prof)
 {
     const uint32_t q = blockIdx.y;
@@ -1294,7 +1139,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_
                 const uint32_t ai = aq[i];
                 if (ai < 24) v = submat[ai * 32 + code];
             }
-            s[k] = fp16 ? __builtin_bit_cast(short, (_Float16)v) : (short)(v + add); // |v| <= 128: exact in fp16; add: column-frame cell
+            s[k] = (short)(v + add); // add: the column-frame cell wants S + ge
         }
         uint2 o;
         o.x = (uint32_t)(uint16_t)s[0] | ((uint32_t)(uint16_t)s[1] << 16);
@@ -1430,20 +1275,6 @@ hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
     return hipSuccess;
 }
 
-hipError_t osw_launch_f16(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
-{
-    hipLaunchKernelGGL(osw_sw_f16, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
-    OSW_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-hipError_t osw_launch_f16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
-{
-    hipLaunchKernelGGL(osw_sw_f16q, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
-    OSW_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
 hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          uint4 *prof_pair, hipStream_t s)
@@ -1475,12 +1306,12 @@ hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t
 }
 
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
-                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, uint32_t fp16, int add, uint2 *prof, hipStream_t s)
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, int add, uint2 *prof, hipStream_t s)
 {
     if (nq == 0) return hipSuccess;
     uint32_t gx = (max_rowblocks * 32 + 255) / 256;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, fp16, add, prof);
+    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, add, prof);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -22,16 +22,16 @@ def pytest_generate_tests(metafunc):
     # every GPU test runs once per first-pass arithmetic of the library; a test that passes cell_bits explicitly
     # is unaffected by the setting
     if metafunc.definition.get_closest_marker("gpu") and "first_pass" in metafunc.fixturenames:
-        metafunc.parametrize("first_pass", ["i16", "i16plain", "f16"], indirect=True)
+        metafunc.parametrize("first_pass", ["i16", "i16plain"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
 def first_pass(request, monkeypatch):
     mode = getattr(request, "param", None)
     if mode is not None:
-        # i16: the default (column-frame int16 cell with the plain biased cell as fallback); i16plain: the plain
-        # biased int16 cell only; f16: packed fp16 first pass with int16 redo
-        monkeypatch.setenv("OSWALD_HIP_CELL_BITS", {"f16": "11", "i16": "16", "i16plain": "16"}[mode])
+        # i16: the default (column-frame int16 cell with the plain biased cell as fallback);
+        # i16plain: the plain biased int16 cell only
+        monkeypatch.setenv("OSWALD_HIP_CELL_BITS", "16")
         if mode == "i16plain":
             monkeypatch.setenv("OSWALD_HIP_NO_FRAME", "1")
         else:

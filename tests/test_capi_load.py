@@ -52,8 +52,8 @@ def test_product_code_never_touches_the_oracle():
     assert not bad, bad
 
 
-def test_header_documents_the_first_pass_modes():
-    """cell_bits 0 / 11 / 16 / 32 are part of the ABI contract (include/oswald_hip.h)."""
+def test_header_documents_the_cell_modes():
+    """cell_bits 0 / 16 / 32 are part of the ABI contract (include/oswald_hip.h)."""
     text = open(os.path.join(ROOT, "include", "oswald_hip.h")).read()
-    for word in ("11", "packed fp16", "packed", "int32"):
+    for word in ("cell_bits", "packed int16", "22256", "int32"):
         assert word in text

@@ -111,11 +111,9 @@ def test_int32_mode_equals_int16_mode(hip_ctx, oracle):
     sm = submat.load("pam250")
     got32 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=32)
     got16 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=16)
-    got11 = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 14, 2, cell_bits=11)
     want = expect(oracle, qs, b, n, disp, 16, sm, 14, 2)
     np.testing.assert_array_equal(got32, want)
     np.testing.assert_array_equal(got16, want)
-    np.testing.assert_array_equal(got11, want)
 
 
 def _self_scoring(target, seed):
@@ -131,10 +129,9 @@ def _self_scoring(target, seed):
     return seq
 
 
-@pytest.mark.parametrize("cell_bits", [11, 16])
-def test_scores_around_the_fp16_ceiling(hip_ctx, oracle, cell_bits):
-    """Self-alignments scoring 2040..2056 and 4000: the packed-fp16 first pass is exact below 2048 and hands
-    everything from 2048 on to the int32 kernel; either way the reported score is the exact one."""
+def test_scores_around_2048(hip_ctx, oracle, cell_bits=16):
+    """Self-alignments scoring 2040..2056 and 4000 (integers from 2048 on are no longer exact in fp16: the int16 cell
+    only uses the fp16 *ordering* of its bit patterns, so nothing may change here)."""
     targets = [2040, 2045, 2046, 2047, 2048, 2049, 2050, 2056, 4000]
     qs = [_self_scoring(t, 100 + t) for t in targets]
     seqs = [q.copy() for q in qs] + [synth.mutate(q, 0.02, 7 + i) for i, q in enumerate(qs)]

@@ -17,7 +17,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "oswald_amd", "csrc", "sw_kernels.hip")
-KERNELS = ("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q", "osw_sw_f16", "osw_sw_f16q")
+KERNELS = ("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q")
 
 
 def _reserved():

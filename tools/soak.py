@@ -32,7 +32,7 @@ for it in range(iters):
     a, m, ad = pack_queries(qs)
     sm = submat.load(mats[it % len(mats)])
     go, ge = int(rng.integers(0, 20)), int(rng.integers(0, 6))
-    bits = [0, 11, 16, 0][it % 4]
+    bits = [0, 16, 32, 0][it % 4] if it % 8 == 2 else 0
     ctx.set_scoring(sm, go, ge, bits)
     ctx.set_queries(a, m, ad)
     if h is None:

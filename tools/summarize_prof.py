@@ -5,7 +5,7 @@ averages, HBM traffic per launch of the DP kernel)."""
 import csv, glob, json, os, sys
 
 out, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
-DP = ("osw_sw_s16q", "osw_sw_s16", "osw_sw_f16q", "osw_sw_f16", "osw_sw_pk16q", "osw_sw_pk16")  # first-pass DP kernels (fp16 / int16 mode)
+DP = ("osw_sw_s16q", "osw_sw_s16", "osw_sw_pk16q", "osw_sw_pk16")  # first-pass DP kernels (fp16 / int16 mode)
 KERNELS = DP + ("osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
 
 
