@@ -46,7 +46,8 @@ def test_small_databases_all_group_shapes(hip_ctx, oracle, nseq):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("matrix,go,ge", [("blosum62", 10, 2), ("pam250", 14, 2), ("blosum45", 0, 0), ("pam30", 30, 5), ("blosum90", 3, 1)])
+@pytest.mark.parametrize("matrix,go,ge", [("blosum62", 10, 2), ("pam250", 14, 2), ("blosum45", 0, 0), ("pam30", 30, 5), ("blosum90", 3, 1),
+                                          ("blosum62", 200, 70), ("blosum62", 3, 60), ("blosum62", 0, 9), ("blosum62", 1000, 1000)])
 def test_matrices_and_gaps(hip_ctx, oracle, matrix, go, ge):
     qs = synth.make_queries([50, 129, 375], seed=5)
     L, R, O = random_db(200, seed=77, max_len=400, queries=qs, homologs=3)
