@@ -1,4 +1,5 @@
-"""Debug aid: full-size C2 search in two first-pass modes, report where they differ (run on the GPU box)."""
+"""Debug aid: full-size C2 search with int16 and with int32 cells, report where they differ (run on the GPU box;
+the int32 pass takes a few seconds)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
@@ -15,7 +16,7 @@ a, m, ad = pack_queries(qs)
 sm = submat.load("blosum62")
 ctx = capi.Context(1)
 res = {}
-for bits in (16, 11):
+for bits in (16, 32):
     ctx.set_scoring(sm, 10, 2, bits)
     ctx.set_queries(a, m, ad)
     out = np.zeros((len(qs), len(n) * 16), np.int32)
@@ -23,10 +24,10 @@ for bits in (16, 11):
     ctx.wait()
     res[bits] = out
     print(bits, "rerun items", ctx.kernel_stats()[2], "max", out.max())
-bad = np.argwhere(res[16] != res[11])
+bad = np.argwhere(res[16] != res[32])
 print("mismatches", len(bad))
 for q, s in bad[:20]:
-    print("  q", q, "m", m[q], "seq", s, "len", sl[s] if s < nseq else -1, "i16", res[16][q, s], "f16", res[11][q, s])
+    print("  q", q, "m", m[q], "seq", s, "len", sl[s] if s < nseq else -1, "i16", res[16][q, s], "i32", res[32][q, s])
 if len(bad):
     print("queries", sorted(set(bad[:, 0].tolist())))
     print("blocks", sorted(set((bad[:, 1] // 128).tolist()))[:40])
