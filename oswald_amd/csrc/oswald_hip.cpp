@@ -531,8 +531,8 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         r = d.counters.reserve((2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
         // Strip-boundary spill scratch: one region per resident wave and launch (two launches run side by side),
-        // allocated here because a multi-GB hipMalloc occasionally takes ~200 ms.  Every region starts with its
-        // zero page (never written afterwards) and its trash page.
+        // allocated here because a multi-GB hipMalloc occasionally takes ~200 ms.  Every region starts with a
+        // reserved page and its trash page.
         {
             const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
             d.bnd_stride = OSW_SCRATCH_ENTRIES;

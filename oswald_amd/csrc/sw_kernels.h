@@ -16,8 +16,8 @@
 #define OSW_SCRATCH_ENTRIES ((4096u + OSW_SCRATCH_PAD_COLS) * 32u) // a wave's spill columns ({H,F} entries, 1.07 MB): a 4096-column
                                                                    // block at 32 lanes per group (G = 2); longer blocks, or G = 1 beyond
                                                                    // 2012 columns, run at a geometry with fewer lanes per group
-// A wave's spill region: 64 entries that stay zero (the "row above" of a first round), 64 entries
-// that absorb the stores of steps / rounds that have nothing to spill, then the columns.
+// A wave's spill region: 64 reserved entries, 64 entries that absorb the stores of steps / rounds that
+// have nothing to spill, then the columns.  (The "row above" of a first round comes from top_pages.)
 #define OSW_SCRATCH_ZERO 0
 #define OSW_SCRATCH_TRASH 64
 #define OSW_SCRATCH_DATA 128
@@ -118,7 +118,7 @@ struct OswSearchArgs {
     uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves; column-frame kernels: (open, extend)
     uint32_t goe_fb, ge_fb;    // column-frame kernels: (open+extend, extend) for the plain cell
     int32_t goe, ge;
-    uint32_t debug_nospill;    // diagnostics: every round reads the zero page and stores to the trash page (WRONG scores; timing only)
+    uint32_t debug_nospill;    // diagnostics: every round reads the constant top row and stores to the trash page (WRONG scores; timing only)
     unsigned long long *wg_times; // diagnostics (or null): per workgroup {start, end of phase 1, end, end} in 100 MHz ticks
 };
 

@@ -119,7 +119,7 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // rounded.  Patterns from 0x7C00 (31744) on would be inf / NaN: a sequence whose
 // biased score reaches 31600 (true score 30576) is re-run in int32, and below
 // that threshold no sum can reach 31744 (|S| <= 128).  7.5 VOP3P instructions
-// per row like the fp16 cell, with fifteen times its ceiling.
+// per row (9 with two-operand maxima).
 //   floor (the value of "zero"): B in both halves; profile: the plain int16 one
 // ---------------------------------------------------------------------------
 #define OSW_I16B_BIAS 0x04000400u
