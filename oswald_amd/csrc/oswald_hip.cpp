@@ -233,19 +233,18 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
                                          (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
                                          ctx->extend_gap, (uint2 *)d.prof_alt.p, d.stream));
     }
-    {
-        // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
-        // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern)
-        const size_t entries = 128 + OSW_I16S_TABLE;
-        std::vector<uint32_t> pages(entries * 2, 0u);
-        for (size_t i = 64; i < 128; ++i) pages[2 * i] = pages[2 * i + 1] = 0x04000400u;
-        for (size_t k = 0; k < OSW_I16S_TABLE; ++k) {
-            const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
-            pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);
-        }
-        HIP_TRY(d.top_pages.reserve(pages.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(d.top_pages.p, pages.data(), pages.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
+    // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern).  Uploaded on the
+    // device's stream like everything else here (ordered behind a search still in flight); `pages` lives until the
+    // synchronisation at the end of this function.
+    std::vector<uint32_t> pages((128 + OSW_I16S_TABLE) * 2, 0u);
+    for (size_t i = 64; i < 128; ++i) pages[2 * i] = pages[2 * i + 1] = 0x04000400u;
+    for (size_t k = 0; k < OSW_I16S_TABLE; ++k) {
+        const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
+        pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);
     }
+    HIP_TRY(d.top_pages.reserve(pages.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(d.top_pages.p, pages.data(), pages.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     const uint32_t np = (uint32_t)ctx->pair_len.size();
     if (np > 0) {
         HIP_TRY(d.pair_q.reserve(2 * np * sizeof(uint32_t)));

@@ -905,6 +905,16 @@ static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint
     }
 }
 
+// Which blocks the column-frame cell may take (ArithI16S): the frame offset (columns + 2G + 2) * ge must
+// stay within OSW_I16S_FRAME_MAX, and -- whatever ge is, 0 included -- a first round indexes the floor table
+// BY COLUMN (entry G + column, up to two columns of prefetch and G - 1 drain steps past the block), so the
+// block must also fit the table's OSW_I16S_TABLE entries.  Everything else runs on the plain biased cell.
+static __device__ __forceinline__ bool osw_frame_cell_takes(uint32_t cols, uint32_t lg, uint32_t ge)
+{
+    const uint32_t span = cols + 2u * (1u << lg) + 2u;
+    return ge <= 64u && span + 2u <= OSW_I16S_TABLE && span * ge <= OSW_I16S_FRAME_MAX;
+}
+
 // ---------------------------------------------------------------------------
 // Main kernel: packed int16.
 // ---------------------------------------------------------------------------
@@ -953,7 +963,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest run on CF
-        const bool cf_only = C::kShifted && ((uint32_t)p.ge > 64u || (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX);
+        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             if (cf_only) {
                 const v2s score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_fb, p.ge_fb);
@@ -984,7 +994,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        const bool cf_only = C::kShifted && ((uint32_t)p.ge > 64u || (blk.ncols4 * 4u + 2u * (1u << lg) + 2u) * (uint32_t)p.ge > OSW_I16S_FRAME_MAX);
+        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             if (cf_only) {
                 const v2s score = run_item<CF, false>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_fb, p.ge_fb);

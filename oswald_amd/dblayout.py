@@ -43,6 +43,9 @@ def group_lengths(sorted_lengths, W: int, round_to: int = FPGA_BLOCK_WIDTH) -> n
     n = L[last]
     if round_to > 1:
         n = (n + round_to - 1) // round_to * round_to
+    if len(n) and int(n.max()) > 65535:
+        raise ValueError(f"a group of padded length {int(n.max())} does not fit the uint16 group lengths "
+                         f"(sequences are limited to {65535 // round_to * round_to} residues)")
     return n
 
 

@@ -58,8 +58,10 @@ std::vector<FastaRecord> read_fasta(const std::string &path)
                 throw std::runtime_error("OSWALD: input is not FASTA (first record has no '>' line).");
             }
             recs.back().residues += line;
-            if (recs.back().residues.size() > 65535)
-                throw std::runtime_error("OSWALD: sequence longer than 65535 residues: " + recs.back().title);
+            // 65520 = 28 * 2340: the group length (longest sequence rounded up to a multiple of 28,
+            // sequences.c:457-463) is stored as uint16 and would wrap for 65521..65535 (it does in the reference)
+            if (recs.back().residues.size() > kMaxSequenceLength)
+                throw std::runtime_error("OSWALD: sequence longer than " + std::to_string(kMaxSequenceLength) + " residues: " + recs.back().title);
         }
     }
     return recs;
@@ -164,6 +166,8 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
     for (uint64_t g = 0; g < G; ++g) {
         const uint64_t last = std::min(N, (g + 1) * W) - 1;
         const uint32_t l = len[last];
+        if (l > kMaxSequenceLength) // a .seq written by the reference may hold such a sequence; its padded length wraps there
+            throw std::runtime_error("OSWALD: database holds a sequence of " + std::to_string(l) + " residues (limit " + std::to_string(kMaxSequenceLength) + ")");
         n[g] = (uint16_t)((l + kFpgaBlockWidth - 1) / kFpgaBlockWidth * kFpgaBlockWidth);
     }
     std::vector<uint64_t> gdisp(G + 1, 0);

@@ -20,6 +20,7 @@ namespace oswald {
 
 constexpr int kDummy = 23;            // PREPROCESSED_DUMMY_ELEMENT, reference sequences.h:17
 constexpr int kFpgaBlockWidth = 28;   // reference arguments.h:24 (group lengths are padded to it)
+constexpr unsigned kMaxSequenceLength = 65520; // 28 * 2340: longest sequence whose padded group length still fits uint16
 constexpr int kFpgaVectorLength = 16; // reference arguments.h:23
 constexpr const char *kVersion = "1.0";
 

@@ -22,8 +22,14 @@ def cases(draw):
     qlens = [int(x) for x in rng.integers(1, draw(st.sampled_from([8, 40, 140, 420])) + 1, nq)]
     nseq = draw(st.integers(1, 280))
     max_len = draw(st.sampled_from([3, 30, 120, 500]))
+    ge = draw(st.integers(0, 12))
+    if ge <= 1 and draw(st.booleans()):
+        # small gap-extend penalties keep the column-frame cell's offset small on blocks of any length: draw blocks
+        # longer than its floor table too (a few sequences only: the scalar oracle has to follow)
+        max_len = draw(st.sampled_from([2000, 8440, 8470, 12000]))
+        nseq = min(nseq, 6)
     return dict(seed=seed, qlens=qlens, nseq=nseq, max_len=max_len,
-                matrix=draw(st.sampled_from(submat.NAMES)), go=draw(st.integers(0, 40)), ge=draw(st.integers(0, 12)),
+                matrix=draw(st.sampled_from(submat.NAMES)), go=draw(st.integers(0, 40)), ge=ge,
                 W=draw(st.sampled_from([16, 32, 64, 128])), lg=draw(st.sampled_from([-1, -1, 0, 1, 2, 3, 4, 5, 6])),
                 wg=draw(st.sampled_from([-1, -1, 0, 1])), pairs=draw(st.sampled_from([0, 1, 2])), bits=draw(st.sampled_from([0, 16, 16, 32])),
                 homolog=draw(st.booleans()))
@@ -37,8 +43,14 @@ def test_random_cases(hip_ctx, oracle, case):
     rng = np.random.default_rng(case["seed"])
     queries = [synth.random_residues(case["seed"] + 11 * i, 0, m) for i, m in enumerate(case["qlens"])]
     seqs = [rng.integers(0, 24, int(l)).astype(np.uint8) for l in rng.integers(1, case["max_len"] + 1, case["nseq"])]
+    if case["max_len"] >= 2000:
+        seqs[0] = rng.integers(0, 24, case["max_len"]).astype(np.uint8)   # one block of exactly the drawn length
     if case["homolog"]:
-        seqs[int(rng.integers(0, len(seqs)))] = queries[-1].copy()
+        k = int(rng.integers(0, len(seqs)))
+        if len(seqs[k]) > 2 * len(queries[-1]):
+            seqs[k][-len(queries[-1]):] = queries[-1]                     # at the far end of a long sequence
+        else:
+            seqs[k] = queries[-1].copy()
     L, R, O = db_from_sequences(seqs)
     b, n, disp, _, _ = layout(L, R, O, case["W"], round_to=int(rng.choice([1, 4, 28])))
     sm = submat.load(case["matrix"])

@@ -350,20 +350,27 @@ def test_pairing_is_invisible(hip_ctx, oracle, monkeypatch):
     np.testing.assert_array_equal(on, expect(oracle, qs, b, n, disp, 16, sm, 12, 3))
 
 
+@pytest.mark.parametrize("go,ge", [(10, 2), (0, 0), (5, 0), (3, 1)])
 @pytest.mark.parametrize("seq_len,qlen", [(9000, 300), (30000, 150)])
-def test_very_long_sequences_with_multi_round_queries(hip_ctx, oracle, seq_len, qlen):
+def test_very_long_sequences_with_multi_round_queries(hip_ctx, oracle, seq_len, qlen, go, ge):
     """Blocks longer than a wave's spill region holds at G = 1 (4096 columns): the planner must pick a
-    geometry with fewer lanes per group, and the boundary row still has to come back exactly."""
+    geometry with fewer lanes per group, and the boundary row still has to come back exactly.
+    Gap extend 0 and 1 keep the frame offset (columns x ge) small however long the block is, so these are
+    also the blocks that would overrun the column-frame cell's floor table (OSW_I16S_TABLE columns) if the
+    kernel did not send them to the plain biased cell: homologs sit past column 8 500."""
     q = synth.random_residues(5, 0, qlen)
     long_seq = synth.random_residues(6, 0, seq_len)
     hom = synth.mutate(q, 0.1, 3)[:qlen]
     long_seq[seq_len // 2:seq_len // 2 + len(hom)] = hom
-    seqs = [synth.random_residues(200 + i, 0, 40 + i) for i in range(20)] + [long_seq, synth.random_residues(7, 0, seq_len - 17)]
+    long_seq[8600:8600 + len(hom) - 20] = hom[20:]            # a second one just past the table's end
+    other = synth.random_residues(7, 0, seq_len - 17)
+    other[seq_len - 17 - len(hom):] = hom                     # and one that ends with the sequence
+    seqs = [synth.random_residues(200 + i, 0, 40 + i) for i in range(20)] + [long_seq, other]
     L, R, O = db_from_sequences(seqs)
     b, n, disp, _, _ = layout(L, R, O, 16)
     sm = submat.load("blosum62")
-    got = run_gpu(hip_ctx, [q, q[:77]], b, n, disp, 16, sm, 10, 2)
-    want = expect(oracle, [q, q[:77]], b, n, disp, 16, sm, 10, 2)
+    got = run_gpu(hip_ctx, [q, q[:77]], b, n, disp, 16, sm, go, ge)
+    want = expect(oracle, [q, q[:77]], b, n, disp, 16, sm, go, ge)
     np.testing.assert_array_equal(got, want)
     assert want.max() > 300
 

@@ -1,0 +1,229 @@
+// tools/oprate.hip -- per-opcode VALU issue cost on gfx950, in core-clock cycles per wave
+// instruction per SIMD, at 1 / 2 / 4 / 8 waves per SIMD.  The question it settles (VERDICT r1,
+// weak #7): do plain 32-bit VOP2 adds / subtracts issue faster than the packed 16-bit VOP3P
+// instructions of the DP cell?  If so the cell can do its carry-free adds and subtracts on the
+// packed pair with 32-bit instructions.
+//
+// Method: every workgroup (256 threads = one wave per SIMD) runs `iters` x 32 instructions of ONE
+// kind on 8 independent registers (dst = src0), brackets the loop with s_memtime (core clock) and
+// s_memrealtime (100 MHz) and writes both.  Dynamic LDS is sized so that exactly `wps` workgroups
+// fit a CU, i.e. wps waves share each SIMD.  The slowest workgroup ran loaded all the way; its
+// cycles / (iters * 32 * wps) is the loaded cost per instruction per SIMD.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/oprate tools/oprate.hip ; run: tools/oprate
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define OPS(X)                                                                                          \
+    X(0, "v_add_u32 %0, %0, %1", "v_add_u32 (VOP2)")                                                     \
+    X(1, "v_sub_u32 %0, %0, %1", "v_sub_u32 (VOP2)")                                                     \
+    X(2, "v_max_u32 %0, %0, %1", "v_max_u32 (VOP2)")                                                     \
+    X(3, "v_max_i32 %0, %0, %1", "v_max_i32 (VOP2)")                                                     \
+    X(4, "v_max3_i32 %0, %0, %1, %2", "v_max3_i32 (VOP3)")                                               \
+    X(5, "v_max3_u32 %0, %0, %1, %2", "v_max3_u32 (VOP3)")                                               \
+    X(6, "v_add3_u32 %0, %0, %1, %2", "v_add3_u32 (VOP3)")                                               \
+    X(7, "v_pk_sub_u16 %0, %0, %1 clamp", "v_pk_sub_u16 clamp (VOP3P)")                                  \
+    X(8, "v_pk_add_i16 %0, %0, %1 clamp", "v_pk_add_i16 clamp (VOP3P)")                                  \
+    X(9, "v_pk_add_u16 %0, %0, %1", "v_pk_add_u16 (VOP3P)")                                              \
+    X(10, "v_pk_max_i16 %0, %0, %1", "v_pk_max_i16 (VOP3P)")                                             \
+    X(11, "v_pk_max_u16 %0, %0, %1", "v_pk_max_u16 (VOP3P)")                                             \
+    X(12, "v_pk_maximum3_f16 %0, %0, %1, %2", "v_pk_maximum3_f16 (VOP3P)")                               \
+    X(13, "v_pk_add_f16 %0, %0, %1", "v_pk_add_f16 (VOP3P)")                                             \
+    X(14, "v_perm_b32 %0, %0, %1, %2", "v_perm_b32 (VOP3)")                                              \
+    X(15, "v_lshl_add_u32 %0, %0, 1, %1", "v_lshl_add_u32 (VOP3)")                                       \
+    X(16, "v_and_or_b32 %0, %0, %1, %2", "v_and_or_b32 (VOP3)")                                          \
+    X(17, "v_mov_b32 %0, %1", "v_mov_b32 (VOP1)")                                                        \
+    X(18, "v_cndmask_b32 %0, %0, %1, vcc", "v_cndmask_b32 (VOP2)")                                       \
+    X(19, "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_add_u32_sdwa") \
+    X(20, "v_max_u16 %0, %0, %1", "v_max_u16 (VOP2, low half)")                                          \
+    X(21, "v_add_f32 %0, %0, %1", "v_add_f32 (VOP2)")                                                    \
+    X(22, "v_fma_f32 %0, %0, %1, %2", "v_fma_f32 (VOP3)")                                                \
+    X(23, "v_max_f32 %0, %0, %1", "v_max_f32 (VOP2)")                                                    \
+    X(24, "v_max3_f32 %0, %0, %1, %2", "v_max3_f32 (VOP3)")                                              \
+    X(25, "v_med3_i32 %0, %0, %1, %2", "v_med3_i32 (VOP3)")                                              \
+    X(26, "v_add_u32 %0, %0, %3", "v_add_u32 with SGPR src (VOP2)")                                      \
+    X(27, "v_sub_u32 %0, %0, %3", "v_sub_u32 with SGPR src (VOP2)")                                      \
+    X(28, "v_pk_maximum3_f16 %0, %0, %1, %3", "v_pk_maximum3_f16 with SGPR src")                         \
+    X(29, "v_pk_sub_u16 %0, %0, %3 clamp", "v_pk_sub_u16 clamp with SGPR src")                           \
+    X(30, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32 DPP row_shr")          \
+    X(31, "v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf", "v_add_u32 DPP row_shr")      \
+    X(32, "v_pk_max_f16 %0, %0, %1", "v_pk_max_f16 (VOP3P)")                                             \
+    X(33, "v_max_f16 %0, %0, %1", "v_max_f16 (VOP2)")                                                    \
+    X(34, "v_xor_b32 %0, %0, %1", "v_xor_b32 (VOP2)")                                                    \
+    X(35, "v_pk_fma_f32 %0, %0, %1, %2", "v_pk_fma_f32 (VOP3P, 64-bit)")                                 \
+    X(36, "v_mad_u32_u16 %0, %0, %1, %2", "v_mad_u32_u16 (VOP3)")                                        \
+    X(37, "v_sub_u16 %0, %0, %1", "v_sub_u16 (VOP2, low half)")                                          \
+    X(38, "v_pk_min_u16 %0, %0, %1", "v_pk_min_u16 (VOP3P)")                                             \
+    X(39, "v_bfe_u32 %0, %0, %1, 8", "v_bfe_u32 (VOP3)")
+
+template <int OP>
+__global__ __launch_bounds__(256) void op_probe(unsigned long long *out, uint32_t c1, uint32_t c2, uint32_t s1, int iters)
+{
+    extern __shared__ uint32_t pad_lds[];
+    if (iters < 0) pad_lds[threadIdx.x] = c1;
+    s1 = __builtin_amdgcn_readfirstlane(s1);
+    if constexpr (OP == 35) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 x[8];
+        const f2 a = {1.0f, 1.0f}, b = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = f2{(float)threadIdx.x, (float)i};
+        const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+        }
+        const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        float acc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += x[i].x + x[i].y;
+        if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0 + (acc == 0.12345f); out[blockIdx.x * 2 + 1] = r1 - r0; }
+        return;
+    } else {
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = 0x3c003c00u + threadIdx.x + i;
+        const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#define X(N, ASM, NAME) if constexpr (OP == N) asm volatile(ASM : "+v"(x[i]) : "v"(c1), "v"(c2), "s"(s1) : "vcc");
+                    OPS(X)
+#undef X
+                }
+            }
+        }
+        const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc ^= x[i];
+        if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0 + (acc == 0x12345678u); out[blockIdx.x * 2 + 1] = r1 - r0; }
+    }
+}
+
+// Candidate cell rows, 4 rows per iteration on independent state (the real cell's dependency
+// distances), to see whether the per-opcode costs simply add.
+//   MIX 0: today's column-frame row (6 VOP3P + the 1/2 running maximum)
+//   MIX 1: the same row with the diagonal add, u = H - go and F - ge as 32-bit VOP2
+//   MIX 2: MIX 1 with gap penalties in SGPRs instead of VGPRs
+template <int MIX>
+__global__ __launch_bounds__(256) void mix_probe(unsigned long long *out, uint32_t go, uint32_t ge, uint32_t fl, uint32_t s, uint32_t sgo, uint32_t sge, int iters)
+{
+    extern __shared__ uint32_t pad_lds[];
+    if (iters < 0) pad_lds[threadIdx.x] = go;
+    sgo = __builtin_amdgcn_readfirstlane(sgo);
+    sge = __builtin_amdgcn_readfirstlane(sge);
+    uint32_t D[4], E[4], F = fl, x = fl, sc = fl, t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { D[i] = fl + threadIdx.x; E[i] = fl; }
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint32_t xn;
+                if constexpr (MIX == 0) {
+                    asm volatile("v_pk_add_i16 %[xn], %[Dn], %[s] clamp\n\t"
+                                 "v_pk_maximum3_f16 %[Dn], %[x], %[E], %[F]\n\t"
+                                 "v_pk_sub_u16 %[t], %[Dn], %[go] clamp\n\t"
+                                 "v_pk_maximum3_f16 %[E], %[E], %[t], %[fl]\n\t"
+                                 "v_pk_maximum3_f16 %[F], %[F], %[t], %[fl]\n\t"
+                                 "v_pk_sub_u16 %[F], %[F], %[ge] clamp"
+                                 : [xn] "=&v"(xn), [t] "=&v"(t), [E] "+v"(E[r]), [Dn] "+v"(D[(r + 1) & 3]), [F] "+v"(F)
+                                 : [x] "v"(x), [s] "v"(s), [go] "s"(sgo), [ge] "s"(sge), [fl] "v"(fl));
+                } else if constexpr (MIX == 1) {
+                    asm volatile("v_add_u32 %[xn], %[Dn], %[s]\n\t"
+                                 "v_pk_maximum3_f16 %[Dn], %[x], %[E], %[F]\n\t"
+                                 "v_sub_u32 %[t], %[Dn], %[go]\n\t"
+                                 "v_pk_maximum3_f16 %[E], %[E], %[t], %[fl]\n\t"
+                                 "v_pk_maximum3_f16 %[F], %[F], %[t], %[fl]\n\t"
+                                 "v_sub_u32 %[F], %[F], %[ge]"
+                                 : [xn] "=&v"(xn), [t] "=&v"(t), [E] "+v"(E[r]), [Dn] "+v"(D[(r + 1) & 3]), [F] "+v"(F)
+                                 : [x] "v"(x), [s] "v"(s), [go] "v"(go), [ge] "v"(ge), [fl] "v"(fl));
+                } else {
+                    asm volatile("v_add_u32 %[xn], %[Dn], %[s]\n\t"
+                                 "v_pk_maximum3_f16 %[Dn], %[x], %[E], %[F]\n\t"
+                                 "v_subrev_u32 %[t], %[go], %[Dn]\n\t"
+                                 "v_pk_maximum3_f16 %[E], %[E], %[t], %[fl]\n\t"
+                                 "v_pk_maximum3_f16 %[F], %[F], %[t], %[fl]\n\t"
+                                 "v_subrev_u32 %[F], %[ge], %[F]"
+                                 : [xn] "=&v"(xn), [t] "=&v"(t), [E] "+v"(E[r]), [Dn] "+v"(D[(r + 1) & 3]), [F] "+v"(F)
+                                 : [x] "v"(x), [s] "v"(s), [go] "s"(sgo), [ge] "s"(sge), [fl] "v"(fl));
+                }
+                if (r & 1) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(sc) : "v"(D[r]), "v"(D[(r + 1) & 3]));
+                x = xn;
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t acc = sc ^ F ^ x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc ^= D[i] ^ E[i];
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0 + (acc == 0x12345678u); out[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+struct Res { double mhz, cyc_slowest, cyc_avg; };
+
+template <class L>
+static Res run(L launch, int nb, unsigned long long *o, double per_wg_instr, int wps)
+{
+    launch();
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(nb * 2);
+    hipMemcpy(h.data(), o, nb * 16, hipMemcpyDeviceToHost);
+    double cyc = 0, ref = 0, cmax = 0;
+    for (int i = 0; i < nb; ++i) { cyc += (double)h[2 * i]; ref += (double)h[2 * i + 1]; cmax = std::max(cmax, (double)h[2 * i]); }
+    return {cyc / ref * 100.0, cmax / per_wg_instr / wps, cyc / nb / per_wg_instr / wps};
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    printf("device %s (%s), %d CUs; cycles = core clock (s_memtime) per wave instruction per SIMD, slowest workgroup [average]\n", p.name, p.gcnArchName, cus);
+    const int iters = 40000;
+    unsigned long long *o;
+    hipMalloc(&o, (size_t)cus * 8 * 16);
+    const int wpss[4] = {1, 2, 4, 8};
+#define X(N, ASM, NAME)                                                                                                 \
+    {                                                                                                                   \
+        printf("%-36s", NAME);                                                                                          \
+        for (int w = 0; w < 4; ++w) {                                                                                   \
+            const int wps = wpss[w], nb = cus * wps;                                                                    \
+            const size_t lds = (size_t)(160 * 1024 / wps) - 1024;                                                       \
+            hipFuncSetAttribute((const void *)op_probe<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            Res r = run([&] { hipLaunchKernelGGL(op_probe<N>, dim3(nb), dim3(256), lds, 0, o, 0x00030003u, 0x04000400u, 0x00020002u, iters); }, nb, o, (double)iters * 32, wps); \
+            printf("  w%d: %5.2f [%5.2f] @%4.0fMHz", wps, r.cyc_slowest, r.cyc_avg, r.mhz);                               \
+        }                                                                                                               \
+        printf("\n");                                                                                                   \
+        fflush(stdout);                                                                                                 \
+    }
+    OPS(X)
+#undef X
+    const char *mixn[3] = {"row: 6 VOP3P + 1/2 max3 (today)", "row: 3 VOP2 (vgpr) + 3.5 VOP3P", "row: 3 VOP2 (sgpr) + 3.5 VOP3P"};
+    for (int mix = 0; mix < 3; ++mix) {
+        printf("%-36s", mixn[mix]);
+        for (int w = 0; w < 4; ++w) {
+            const int wps = wpss[w], nb = cus * wps;
+            const size_t lds = (size_t)(160 * 1024 / wps) - 1024;
+            auto go = [&](auto kern) {
+                hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                return run([&] { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, 0, o, 0x000a000au, 0x00020002u, 0x04000400u, 0x00040004u, 0x000a000au, 0x00020002u, iters / 4); },
+                           nb, o, (double)(iters / 4) * 8, wps);
+            };
+            Res r = mix == 0 ? go(mix_probe<0>) : mix == 1 ? go(mix_probe<1>) : go(mix_probe<2>);
+            printf("  w%d: %5.2f [%5.2f] cyc/row", wps, r.cyc_slowest, r.cyc_avg);
+        }
+        printf("\n");
+    }
+    return 0;
+}
