@@ -4,17 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch: every query of the
-workload against the rank's resident database shard (DP kernels incl. the
-exact int32 re-run of saturated cells, on-device top-r) and, for N > 1, the
-gather of the per-GPU top-r lists over RCCL.  Inputs (re-tiled residues,
-query profile) are resident in HBM before the timed region starts.
+workload against the rank's resident part of the database (DP kernels incl. the
+exact int32 re-run of saturated cells, on-device top-r per chunk) and, for
+N > 1, the gather of the per-GPU top-r lists over RCCL.  Inputs (re-tiled
+residues, query profiles) are RESIDENT IN HBM before the timed region starts;
+the rate with the host buffers handed over inside the timed region (SURVEY 8d's
+region: upload + kernels + download) is reported next to it as
+`pcie_inclusive`, never as `value`.
 
-Workload at N = 1: BASELINE.json configs[1] -- 20 queries of length 100..1000
-(sum 11 000) against a 100k-sequence synthetic length-binned database
-(~36.5 M residues), BLOSUM62, gap 10/2, int16 cells (packed, exact below 22256;
-sequences above are re-run in int32).  For N > 1 every
-rank holds its own 100k-sequence shard (weak scaling; shards are chunk-sharded
-parts of an N x 100k-sequence database, no data-path collective).
+Workload
+  N = 1: BASELINE.json configs[1] (C2) -- 20 queries of length 100..1000 (sum
+         11 000) against a 100 000-sequence synthetic length-binned database
+         (~36.7 M residues), BLOSUM62, gap 10/2, int16 cells (packed, exact below
+         22256; sequences above are re-run in int32).
+  N > 1: BASELINE.json configs[3] (C4) -- the same queries against ONE
+         1 000 000-sequence database (~364.6 M residues), length-sorted once and
+         cut by the reference's rule (host/src/sequences.c:510-515: shards of
+         ceil(vD/ndev) padded residues; chunk c goes to device c mod ndev,
+         host/src/FPGAsearch.c:132-138).  Total work is fixed as N grows:
+         "scaling": "strong".  Database indices are positions in the globally
+         sorted database, so the merged top-10 is comparable across N
+         (tests/golden/bench_top_*.json holds the single-GPU result).
+  --nseq overrides the TOTAL number of database sequences for any N;
+  --weak restores round 1's mode (an independent --nseq database per GPU).
 
 GCUPS = sum(query lengths) x unpadded database residues / seconds / 1e9, the
 reference's definition (reference host/src/FPGAsearch.c:324).
@@ -22,8 +34,10 @@ reference's definition (reference host/src/FPGAsearch.c:324).
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,12 +50,13 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9                 # max clock (MI355X_MICROARCH.md)
 N_CU = 256
 SIMD_PER_CU = 4
-PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (tools/ubench.hip, measured 4.2-4.5)
+PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (profiles/r02_oprate_valu_issue.txt: 4.25)
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
 PK_OPS_PER_ROW = {16: (7.5, 6.5), 32: (24.0, 24.0)}
 DTYPE = {16: "int16", 32: "int32"}
 CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells"}
+KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/oswald_hip.cpp")
 
 
 def parse():
@@ -49,24 +64,35 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nseq", type=int, default=100000, help="database sequences per GPU")
+    ap.add_argument("--nseq", type=int, default=0, help="TOTAL database sequences (default: 100000 at --gpus 1 = C2, 1000000 at --gpus > 1 = C4); per GPU with --weak")
+    ap.add_argument("--weak", action="store_true", help="round-1 mode: every rank searches its own independent --nseq database")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
+    ap.add_argument("--max-chunk", type=int, default=134217728, help="chunk size limit in bytes (the reference's -k, default 128 MiB)")
     ap.add_argument("--cell-bits", type=int, default=16, choices=[16, 32],
                     help="cell arithmetic: 16 = packed int16 (the cells BASELINE.json names; the library's default), 32 = int32 only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
+    ap.add_argument("--write-top-golden", action="store_true", help="N = 1 only: write tests/golden/bench_top_<workload>_<nseq>.json")
     return ap.parse_args()
 
 
 def workload(name):
     if name == "c2":
-        return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="C2: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2")
+        return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="20 queries len 100-1000 x {nseq}-seq synthetic DB, BLOSUM62 10/2")
     if name == "c3":
-        return dict(qlens=None, matrix="pam250", go=14, ge=2, label="C3: 20 queries len 100-1000 x {nseq}-seq synthetic DB per GPU, PAM250 14/2")
+        return dict(qlens=None, matrix="pam250", go=14, ge=2, label="20 queries len 100-1000 x {nseq}-seq synthetic DB, PAM250 14/2")
     if name == "q1":
-        return dict(qlens=[375], matrix="blosum62", go=10, ge=2, label="Q1: 1 query len 375 (the C1 query) x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2")
-    return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="C5: 1 query len 5000 x {nseq}-seq synthetic DB per GPU, BLOSUM62 10/2")
+        return dict(qlens=[375], matrix="blosum62", go=10, ge=2, label="1 query len 375 (the C1 query) x {nseq}-seq synthetic DB, BLOSUM62 10/2")
+    return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="1 query len 5000 x {nseq}-seq synthetic DB, BLOSUM62 10/2")
+
+
+def source_digest():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -74,7 +100,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world == 1 and args.gpus > 1:
+        # started without a launcher: start the ranks ourselves (before anything touches the GPU) and leave with their code
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -105,24 +136,39 @@ def main():
     a_disp = np.concatenate([[0], np.cumsum(m[:-1], dtype=np.int64)]).astype(np.uint32)
     a = np.concatenate(queries)
     sum_m = int(m.astype(np.int64).sum())
+    nq = len(qlens)
 
-    # this rank's shard: generated, sorted by length, interleaved exactly like the
-    # reference's preprocessed + assembled database (W = 16, pad to x28)
+    # The database: a plan of the WHOLE database on every rank (lengths and planted homologs only), sorted by
+    # length once, cut into chunks by the reference's rule; every rank materialises and interleaves only the
+    # sequences of its own chunks, exactly like the reference's preprocessed + assembled database (W = 16,
+    # group lengths padded to x28).
     t0 = time.time()
-    L, R, O = synth.make_database(args.nseq, queries, seed=synth.SEED_DB + 1000003 * rank)
-    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
-    b, n, disp = dblayout.interleave(sl, sr, so, 16)
-    d_local = int(sl.astype(np.int64).sum())
-    t_gen = time.time() - t0
+    strong = not args.weak
+    nseq_total = args.nseq or (100000 if world == 1 or args.weak else 1000000)
+    if strong:
+        plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB, 12)
+        shard_world, shard_rank = world, rank
+    else:
+        plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB + 1000003 * rank, 12)
+        shard_world, shard_rank = 1, 0
+    shard = multigpu.ShardedDatabase(plan, 16, args.max_chunk, shard_world, shard_rank)
+    index_base = 0 if strong else rank * nseq_total      # weak mode: global index = shard base + sorted position
 
     ctx = capi.Context(1, [gpu])
     cell_bits = args.cell_bits
     ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
     ctx.set_queries(a, m, a_disp)
-    if b.size >= 2**32:
-        raise SystemExit("shard too large for one chunk")
-    chunk = ctx.chunk_upload(b, n, disp.astype(np.uint32), 16)
-    geom = ctx.chunk_geometry(chunk)
+    chunks = []          # resident chunks of this rank (+ their host arrays for the PCIe-inclusive leg)
+    d_local = 0
+    for k in range(len(shard.mine)):
+        c = shard.chunk(k)
+        if c["b"].size >= 2**32:
+            raise SystemExit("chunk too large; lower --max-chunk")
+        c["h"] = ctx.chunk_upload(c["b"], c["n"], c["disp"], 16)
+        chunks.append(c)
+        d_local += int(c["off"][-1])
+    t_gen = time.time() - t0
+    geoms = [ctx.chunk_geometry(c["h"]) for c in chunks]
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -131,10 +177,9 @@ def main():
         torch.cuda.synchronize(dev)
 
     def step():
-        ctx.chunk_search(chunk, None)
-        sc, ix = ctx.chunk_topr(chunk, args.nseq, args.top)   # syncs the library's stream
-        gix = ix.astype(np.int64) + rank * args.nseq          # global index = shard base + sorted position
-        return multigpu.gather_topr(sc, gix, args.top, dist, coll_dev if dist is not None else None)
+        return multigpu.rank_step(chunks, lambda c: ctx.chunk_search(c["h"], None),
+                                  lambda c: ctx.chunk_topr(c["h"], c["nseq"], args.top),   # syncs the library's stream
+                                  nq, args.top, index_base, dist, coll_dev if dist is not None else None)
 
     for _ in range(args.warmup):
         step()
@@ -162,82 +207,130 @@ def main():
     if rank == 0:
         cells_per_step = sum_m * d_total
         gcups = cells_per_step * args.steps / elapsed / 1e9
-        # roofline of the dominant kernel (osw_sw_pk16 + its int32 re-run, one event pair per step)
-        nq = len(qlens)
-        alg_bytes = nq * (geom["residue_bytes_per_query"] + 4 * args.nseq) + sum_m + 768
-        kern_s = kern_ms / max(1, kern_launches) / 1e3
+        # roofline of the dominant kernels (one event pair per chunk search = per launch group)
+        nlaunch = max(1, kern_launches)
+        alg_step = sum(nq * (g["residue_bytes_per_query"] + 4 * c["nseq"]) + sum_m + 768 for g, c in zip(geoms, chunks))
+        alg_bytes = alg_step * args.steps / nlaunch
+        kern_s = kern_ms / nlaunch / 1e3
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
-        kern_gcups = sum_m * d_local / kern_s / 1e9 if kern_s > 0 else 0.0
+        kern_gcups = sum_m * d_local * args.steps / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
         ops_row = PK_OPS_PER_ROW[cell_bits][1 if nq > 1 else 0]  # a multi-query search runs (mostly) as query pairs
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / ops_row / 1e9
         kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32"}[cell_bits]
-        traffic = measured_traffic(args.workload, args.nseq)
+        traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None)
+        cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1"}[args.workload]
+        shard_note = (f"one database sharded over {world} GPUs by the reference's chunk rule (chunk c -> GPU c mod {world}), "
+                      f"{'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}") if world > 1 and strong else \
+                     (f"independent {nseq_total}-sequence database per GPU x{world}, {'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}" if world > 1 else "single GPU")
         result = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": DTYPE[cell_bits], "data": "synthetic",
-            "config": {"workload": wl["label"].format(nseq=args.nseq) + ", " + CELL_LABEL[cell_bits], "queries": nq, "query_residues": sum_m, "db_sequences_per_gpu": args.nseq,
+            "config": {"workload": f"{cfg_name}: " + wl["label"].format(nseq=nseq_total) + ", " + CELL_LABEL[cell_bits] + "; database resident in HBM (re-tiled) before the timed region",
+                       "queries": nq, "query_residues": sum_m, "db_sequences_total": nseq_total * (1 if strong else world),
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
-                       "top": args.top, "sharding": f"db-shard x{world}, {'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}" if world > 1 else "single GPU"},
+                       "top": args.top, "sharding": shard_note, "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "launches_per_step": round(nlaunch / max(1, args.steps), 2),
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
                                   "instr_per_128_cells": ops_row,
                                   "note": "the DP is VALU-issue bound: instr_per_128_cells VALU instructions per wave per query row (query-pair cell for a multi-query search), one packed 16-bit instruction per 4 cycles per SIMD"}},
             # the north star's ">= 0.5 x HBM roofline" is only well posed under the reference's own traffic
             # model, 1 B of substitution score per cell streamed from device DRAM (sw.cl:57): 8 TB/s = 8000 GCUPS
             "reference_traffic_model": {"bytes_per_cell": 1.0, "roofline_gcups": HBM_PEAK_GBS, "frac": round(gcups / world / HBM_PEAK_GBS, 4)},
-            "rerun_items_int32": int(rerun), "work_items": int(ctx.chunk_geometry(chunk)["work_items"]), "max_log2_geometry": int(ctx.chunk_geometry(chunk)["max_log2_geometry"]), "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
+            "rerun_items_int32": int(rerun), "work_items": int(sum(ctx.chunk_geometry(c["h"])["work_items"] for c in chunks)),
+            "max_log2_geometry": int(max([ctx.chunk_geometry(c["h"])["max_log2_geometry"] for c in chunks] or [0])),
+            "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
             "setup_s": round(t_gen, 1),
         }
+        result["top_equals_single_gpu_golden"] = check_top_golden(args, nseq_total, strong, world, top)
         # not `value`: the same pass when the boundary hands over host buffers (H2D of the interleaved
-        # chunk + re-tile + search + D2H of the full int32 score table), the reference's timed region
-        out_full = np.zeros((nq, len(n) * 16), np.int32)
-        t0 = time.perf_counter()  # (rank 0's shard; the other ranks idle at the final barrier meanwhile)
-        h2 = ctx.chunk_upload(b, n, disp.astype(np.uint32), 16)
-        ctx.chunk_search(h2, out_full)
+        # chunks + re-tile + search + D2H of the full int32 score table), the reference's timed region
+        outs = [np.zeros((nq, len(c["n"]) * 16), np.int32) for c in chunks]
+        t0 = time.perf_counter()  # (rank 0's chunks; the other ranks idle at the final barrier meanwhile)
+        hs = []
+        for c, o in zip(chunks, outs):
+            h2 = ctx.chunk_upload(c["b"], c["n"], c["disp"], 16)
+            ctx.chunk_search(h2, o)
+            hs.append(h2)
         ctx.wait()
         t_pcie = time.perf_counter() - t0
-        ctx.chunk_release(h2)
+        for h2 in hs:
+            ctx.chunk_release(h2)
         result["pcie_inclusive"] = {"gcups": round(sum_m * d_local / t_pcie / 1e9, 1), "ms": round(t_pcie * 1e3, 2),
-                                    "what": "chunk_upload (H2D + re-tile) + search + D2H of all scores, pageable host memory"}
-        if args.cpu_seconds > 0 and world == 1:  # reported at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(args, a, m, a_disp, sl, sr, so, sm, wl, sum_m, ctx, chunk, n)
-    ctx.chunk_release(chunk)
+                                    "what": "SURVEY 8(d)'s timed region on rank 0's chunks: chunk_upload (H2D + re-tile) + search + D2H of all scores, pageable host memory"}
+        if args.cpu_seconds > 0 and world == 1 and chunks:  # reported at N = 1 only
+            result["cpu_baseline"] = cpu_baseline(args, a, m, a_disp, chunks[0], outs[0], sm, wl, sum_m)
+    for c in chunks:
+        ctx.chunk_release(c["h"])
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+        if result.get("top_equals_single_gpu_golden") is False:
+            raise SystemExit("bench.py: the merged top list differs from the single-GPU golden result (tests/golden/bench_top_*.json)")
+
+
+def golden_path(args, nseq_total):
+    return os.path.join(ROOT, "tests", "golden", f"bench_top_{args.workload}_{nseq_total}.json")
+
+
+def check_top_golden(args, nseq_total, strong, world, top):
+    """The merged top-r list (scores and positions in the globally sorted database) against the list a
+    single GPU produced for the same workload (written with --write-top-golden at N = 1): True / False,
+    or None when no golden exists for this workload (or in --weak mode, where the database differs)."""
+    if not strong or top is None:
+        return None
+    sc, ix = top
+    path = golden_path(args, nseq_total)
+    if args.write_top_golden and world == 1:
+        with open(path, "w") as f:
+            json.dump({"workload": args.workload, "nseq": nseq_total, "top": args.top, "scores": sc.tolist(), "index": ix.tolist()}, f)
+        return True
+    try:
+        with open(path) as f:
+            g = json.load(f)
+    except (OSError, ValueError):
+        return None
+    r = min(args.top, g["top"])
+    return bool(np.array_equal(np.array(g["scores"])[:, :r], sc[:, :r]) and np.array_equal(np.array(g["index"])[:, :r], ix[:, :r]))
 
 
 def measured_traffic(workload_name, nseq):
-    """HBM bytes per launch of the DP kernel from rocprofv3 PMC passes
-    (FETCH_SIZE / WRITE_SIZE, separate runs, see tools/profile_gpu.sh and
-    DESIGN.md for the unit and the gfx950 correction), if a summary for this
-    exact workload has been committed under profiles/; else None."""
+    """HBM bytes per launch of the DP kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+    runs, see tools/profile_gpu.sh and DESIGN.md for the unit and the gfx950 correction) committed under
+    profiles/ for this exact workload -- and for THIS kernel source: the summary carries a digest of the
+    kernel sources it was measured on; a stale one is not reported."""
+    if nseq is None:
+        return None, "PMC passes are single-GPU runs"
     path = os.path.join(ROOT, "profiles", f"traffic_{workload_name}_{nseq}.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return t.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
-        return None
+        return None, "no PMC summary committed for this workload"
+    if t.get("source_digest") != source_digest():
+        print(f"bench.py: {path} was measured on other kernel sources (digest {t.get('source_digest')} != {source_digest()}); "
+              "traffic not reported -- re-run tools/profile_gpu.sh", file=sys.stderr, flush=True)
+        return None, "stale: PMC summary was measured on other kernel sources"
+    return t.get("hbm_bytes_per_launch"), f"rocprofv3 FETCH_SIZE+WRITE_SIZE, {os.path.relpath(path, ROOT)}"
 
 
-def cpu_baseline(args, a, m, a_disp, sl, sr, so, sm, wl, sum_m, ctx, chunk, n_gpu):
+def cpu_baseline(args, a, m, a_disp, chunk, gpu_scores, sm, wl, sum_m):
     """The oracle's SIMD port of the reference host path (SSE4.1/AVX2
     int8->int16->int32, OpenMP over groups) timed on this box's host cores on a
-    bounded sample: every k-th W-lane group of the sorted shard, all queries.
+    bounded sample: every k-th W-lane group of rank 0's first chunk, all queries.
     Its scores are also compared with the GPU's for the sampled sequences."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     from oswald_amd import dblayout
     W = args.cpu_lanes
     threads = pyoracle.max_threads()
+    sl, sr, so = chunk["ls"], chunk["res"], chunk["off"]
     nseq = len(sl)
     ngroups = (nseq + W - 1) // W
     # calibrate on a few groups, then size the sample for ~cpu_seconds
@@ -250,7 +343,7 @@ def cpu_baseline(args, a, m, a_disp, sl, sr, so, sm, wl, sum_m, ctx, chunk, n_gp
         np.cumsum(lens, out=off[1:])
         idx = np.repeat(so[seqs] - off[:-1], lens) + np.arange(int(off[-1]))
         res = sr[idx]
-        bb, nn, dd = dblayout.interleave(lens.astype(np.uint16), res, off, W, round_to=1)
+        bb, nn, dd = dblayout.interleave(lens, res, off, W, round_to=1)
         return seqs, int(lens.sum()), bb, nn, dd.astype(np.uint32)
     seqs, dres, bb, nn, dd = sample(max(1, ngroups // 64))
     t0 = time.perf_counter()
@@ -263,13 +356,10 @@ def cpu_baseline(args, a, m, a_disp, sl, sr, so, sm, wl, sum_m, ctx, chunk, n_gp
     t0 = time.perf_counter()
     sc_cpu, stage = pyoracle.search_chunk_simd(a, m, a_disp, bb, nn, dd, W, sm, wl["go"], wl["ge"], 256, threads)
     t = time.perf_counter() - t0
-    # parity of the sampled sequences against the GPU score table
-    out = np.zeros((len(m), len(n_gpu) * 16), np.int32)
-    ctx.chunk_search(chunk, out)
-    ctx.wait()
-    equal = bool(np.array_equal(out[:, seqs], sc_cpu[:, :len(seqs)]))
+    # parity of the sampled sequences against the GPU score table (downloaded by the PCIe-inclusive leg)
+    equal = bool(np.array_equal(gpu_scores[:, seqs], sc_cpu[:, :len(seqs)]))
     return {"value": round(sum_m * dres / t / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
-            "sample": f"every {stride}-th {W}-lane group of the sorted shard ({len(seqs)} sequences, {dres} residues) x all {len(m)} queries, "
+            "sample": f"every {stride}-th {W}-lane group of rank 0's first chunk ({len(seqs)} sequences, {dres} residues) x all {len(m)} queries, "
                       f"{'AVX2' if W == 32 else 'SSE4.1'} int8->int16->int32 port, block 256, {t:.1f} s",
             "gpu_scores_equal_on_sample": equal,
             "cells_by_precision": {"int8": int(stage[0]), "int16": int(stage[1]), "int32": int(stage[2])}}

@@ -117,10 +117,29 @@ def topr_reference_order(scores: np.ndarray, r: int):
 
 
 def merge_topr(parts, r: int):
-    """Merge per-shard (scores, global_index) top lists with the same rule."""
+    """Merge per-shard (scores, global_index) top lists with the same rule; index < 0 = empty slot.
+    Returns (scores int32, global index int64)."""
     sc = np.concatenate([p[0] for p in parts])
     ix = np.concatenate([p[1] for p in parts]).astype(np.int64)
     keep = ix >= 0
     sc, ix = sc[keep], ix[keep]
     order = np.lexsort((-ix, -sc.astype(np.int64)))[:r]
-    return sc[order].astype(np.int32), ix[order].astype(np.uint32)
+    return sc[order].astype(np.int32), ix[order]
+
+
+def merge_topr_rows(scores: np.ndarray, index: np.ndarray, r: int):
+    """merge_topr for all queries at once: scores / index [nq][K] candidates (index < 0 = empty slot) ->
+    ([nq][r] int32, [nq][r] int64), empty slots (-1, -1).  The order "descending score, ties by descending
+    index" is the descending order of the key score << 32 | index (scores >= 0, index < 2^32)."""
+    scores = np.asarray(scores)
+    index = np.asarray(index, dtype=np.int64)
+    valid = index >= 0
+    key = np.where(valid, (((scores.astype(np.uint64) << np.uint64(32)) | index.astype(np.uint64)) << np.uint64(1)) | np.uint64(1), np.uint64(0))
+    key = np.sort(key, axis=1)[:, ::-1][:, :r]
+    if key.shape[1] < r:
+        key = np.concatenate([key, np.zeros((key.shape[0], r - key.shape[1]), np.uint64)], axis=1)
+    have = (key & np.uint64(1)) != 0
+    body = key >> np.uint64(1)
+    out_s = np.where(have, (body >> np.uint64(32)).astype(np.int64), -1).astype(np.int32)
+    out_i = np.where(have, (body & np.uint64(0xFFFFFFFF)).astype(np.int64), -1)
+    return out_s, out_i

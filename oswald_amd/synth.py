@@ -32,30 +32,77 @@ _RR = {
 }
 
 
+def _mix(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
 def splitmix64(seed: int, start: int, count: int) -> np.ndarray:
     """Values start..start+count-1 of the SplitMix64 stream seeded with `seed`."""
     with np.errstate(over="ignore"):
         k = np.arange(start + 1, start + count + 1, dtype=np.uint64)
-        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + k * _GAMMA
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        return z ^ (z >> np.uint64(31))
+        return _mix(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + k * _GAMMA)
 
 
-def _residue_table() -> tuple[np.ndarray, np.ndarray]:
-    codes = np.array([ALPHABET.index(c) for c in _RR], dtype=np.uint8)
-    p = np.array(list(_RR.values()), dtype=np.float64)
-    cum = np.cumsum(p / p.sum())
-    thresholds = np.minimum((cum * 2.0**32).astype(np.uint64), np.uint64(2**32 - 1))
-    thresholds[-1] = np.uint64(2**32 - 1)
-    return codes, thresholds
+def splitmix64_at(seed: int, positions: np.ndarray) -> np.ndarray:
+    """The same stream at arbitrary positions (it is counter based): value k = mix(seed + (k+1)*gamma)."""
+    with np.errstate(over="ignore"):
+        k = np.asarray(positions).astype(np.uint64) + np.uint64(1)
+        return _mix(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + k * _GAMMA)
+
+
+_RESIDUE_TABLE = None
+
+
+def _residue_table():
+    """(codes, thresholds, lut, lut_exact): residue k is drawn when the 32-bit variate u falls into
+    (thresholds[k-1], thresholds[k]] (= codes[searchsorted(thresholds, u, 'left')]).  lut maps the top 16
+    bits of u to that code wherever no threshold lies inside the 16-bit bucket (lut_exact)."""
+    global _RESIDUE_TABLE
+    if _RESIDUE_TABLE is None:
+        codes = np.array([ALPHABET.index(c) for c in _RR], dtype=np.uint8)
+        p = np.array(list(_RR.values()), dtype=np.float64)
+        cum = np.cumsum(p / p.sum())
+        thresholds = np.minimum((cum * 2.0**32).astype(np.uint64), np.uint64(2**32 - 1))
+        thresholds[-1] = np.uint64(2**32 - 1)
+        lo = np.arange(65536, dtype=np.uint64) << np.uint64(16)
+        k_lo = np.searchsorted(thresholds, lo, side="left").clip(0, len(codes) - 1)
+        k_hi = np.searchsorted(thresholds, lo + np.uint64(65535), side="left").clip(0, len(codes) - 1)
+        _RESIDUE_TABLE = (codes, thresholds, codes[k_lo], k_lo == k_hi)
+    return _RESIDUE_TABLE
+
+
+def _residues_from_variates(z: np.ndarray) -> np.ndarray:
+    codes, thr, lut, exact = _residue_table()
+    u = z >> np.uint64(32)
+    top = (u >> np.uint64(16)).astype(np.intp)
+    out = lut[top]
+    amb = np.flatnonzero(~exact[top])           # the few buckets a threshold cuts through
+    if len(amb):
+        out[amb] = codes[np.searchsorted(thr, u[amb], side="left").clip(0, len(codes) - 1)]
+    return out
+
+
+_BLOCK = 1 << 20  # variates per pass: temporaries stay cache-sized
 
 
 def random_residues(seed: int, start: int, count: int) -> np.ndarray:
     """`count` residue codes (uint8, 0..22) drawn with Robinson-Robinson frequencies."""
-    codes, thr = _residue_table()
-    u = splitmix64(seed, start, count) >> np.uint64(32)
-    return codes[np.searchsorted(thr, u, side="left").clip(0, len(codes) - 1)]
+    out = np.empty(count, dtype=np.uint8)
+    for b0 in range(0, count, _BLOCK):
+        nb = min(_BLOCK, count - b0)
+        out[b0:b0 + nb] = _residues_from_variates(splitmix64(seed, start + b0, nb))
+    return out
+
+
+def random_residues_at(seed: int, positions: np.ndarray) -> np.ndarray:
+    """random_residues at arbitrary stream positions."""
+    positions = np.asarray(positions)
+    out = np.empty(len(positions), dtype=np.uint8)
+    for b0 in range(0, len(positions), _BLOCK):
+        out[b0:b0 + _BLOCK] = _residues_from_variates(splitmix64_at(seed, positions[b0:b0 + _BLOCK]))
+    return out
 
 
 def random_lengths(seed: int, count: int) -> np.ndarray:
@@ -106,6 +153,53 @@ def mutate(seq: np.ndarray, rate: float, seed: int) -> np.ndarray:
     return out.astype(np.uint8)
 
 
+class DatabasePlan:
+    """Everything about a synthetic database except its residues: lengths, offsets into the residue
+    stream and the planted homologs.  Cheap (no per-residue work), so every rank of a sharded search
+    can hold the plan of the whole database and materialise only the sequences of its own shard."""
+
+    def __init__(self, nseq, queries, seed, homologs_per_query):
+        self.nseq, self.seed = nseq, seed
+        lengths = random_lengths(seed, nseq).astype(np.int64)
+        self.planted = {}
+        if queries is not None and nseq > 0:
+            ranks = splitmix64(seed ^ 0x9A17ED, 0, len(queries) * homologs_per_query)
+            k = 0
+            for qi, q in enumerate(queries):
+                for h in range(homologs_per_query):
+                    idx = int(ranks[k] % np.uint64(nseq))
+                    while idx in self.planted:
+                        idx = (idx + 1) % nseq
+                    mut = mutate(np.asarray(q, dtype=np.uint8), 0.05 * (h + 1), seed + 7919 * (qi * homologs_per_query + h + 1))
+                    if len(mut) > 65520:
+                        mut = mut[:65520]
+                    self.planted[idx] = mut
+                    lengths[idx] = len(mut)
+                    k += 1
+        self.lengths = lengths
+        self.offsets = np.zeros(nseq + 1, dtype=np.int64)
+        np.cumsum(lengths, out=self.offsets[1:])
+
+    def residues_of(self, seq_ids) -> np.ndarray:
+        """Residues of the given sequences (generation-order ids), concatenated in the order given."""
+        ids = np.asarray(seq_ids, dtype=np.int64)
+        ls = self.lengths[ids]
+        out_off = np.zeros(len(ids) + 1, dtype=np.int64)
+        np.cumsum(ls, out=out_off[1:])
+        out = np.empty(int(out_off[-1]), dtype=np.uint8)
+        # in slabs of sequences so that the position arrays stay small
+        step = 4096
+        for s0 in range(0, len(ids), step):
+            s1 = min(len(ids), s0 + step)
+            l = ls[s0:s1]
+            tot = int(out_off[s1] - out_off[s0])
+            pos = np.repeat(self.offsets[ids[s0:s1]] - (out_off[s0:s1] - out_off[s0]), l) + np.arange(tot, dtype=np.int64)
+            out[out_off[s0]:out_off[s1]] = random_residues_at(self.seed, pos)
+        for k in np.flatnonzero(np.isin(ids, np.fromiter(self.planted.keys(), dtype=np.int64, count=len(self.planted)))) if self.planted else ():
+            out[out_off[k]:out_off[k + 1]] = self.planted[int(ids[k])]
+        return out
+
+
 def make_database(nseq: int, queries=None, seed: int = SEED_DB, homologs_per_query: int = 12):
     """Synthetic database: list-free representation (lengths, flat residues).
 
@@ -114,28 +208,11 @@ def make_database(nseq: int, queries=None, seed: int = SEED_DB, homologs_per_que
     given, `homologs_per_query` mutated copies of each query (substitution rate
     5 %, 10 %, ... ) replace PRNG-chosen sequences.
     """
-    lengths = random_lengths(seed, nseq).astype(np.int64)
-    planted = {}
-    if queries is not None and nseq > 0:
-        ranks = splitmix64(seed ^ 0x9A17ED, 0, len(queries) * homologs_per_query)
-        k = 0
-        for qi, q in enumerate(queries):
-            for h in range(homologs_per_query):
-                idx = int(ranks[k] % np.uint64(nseq))
-                while idx in planted:
-                    idx = (idx + 1) % nseq
-                mut = mutate(np.asarray(q, dtype=np.uint8), 0.05 * (h + 1), seed + 7919 * (qi * homologs_per_query + h + 1))
-                if len(mut) > 65535:
-                    mut = mut[:65535]
-                planted[idx] = mut
-                lengths[idx] = len(mut)
-                k += 1
-    offsets = np.zeros(nseq + 1, dtype=np.int64)
-    np.cumsum(lengths, out=offsets[1:])
-    residues = random_residues(seed, 0, int(offsets[-1]))
-    for idx, mut in planted.items():
-        residues[offsets[idx]:offsets[idx + 1]] = mut
-    return lengths.astype(np.uint16), residues, offsets
+    plan = DatabasePlan(nseq, queries, seed, homologs_per_query)
+    residues = random_residues(seed, 0, int(plan.offsets[-1]))
+    for idx, mut in plan.planted.items():
+        residues[plan.offsets[idx]:plan.offsets[idx + 1]] = mut
+    return plan.lengths.astype(np.uint16), residues, plan.offsets
 
 
 def to_letters(codes: np.ndarray) -> str:

@@ -25,8 +25,8 @@ def test_bench_line_schema(first_pass):
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"] == "GCUPS" and d["unit"] == "GCUPS" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and "resident in HBM" in d["config"]["workload"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k

@@ -1,11 +1,17 @@
-"""BASELINE.json configs[1] at full size on the GPU (20 queries x 100 000
-sequences, ~36.7 M residues), checked through size-independent properties and
-against the CPU port on a sample: idempotence, chunking invariance, device
-top-r == top-r of the downloaded table, planted homologs on top, score bounds."""
+"""Every GPU configuration of BASELINE.json at its full size, through the C ABI:
+C2 (20 queries x 100 000 sequences, BLOSUM62 10/2), C3 (the same database,
+PAM250 14/2), C5 (one 5000-residue query x the same 100 000 sequences) and the
+C4 database (1 000 000 sequences, ~364.6 M residues) on one GPU, chunked by the
+reference's -k rule like the command-line tool does.  Checked through
+size-independent properties -- idempotence, chunking invariance, device top-r
+== top-r of the downloaded table, planted homologs on top, score bounds -- and
+bit for bit against the CPU port (AVX2 int8->int16->int32) on every k-th
+32-lane group INCLUDING the last groups, which hold the longest sequences (the
+expensive tail: widest wave geometries, workgroup items)."""
 import numpy as np
 import pytest
 
-from oswald_amd import dblayout, submat, synth
+from oswald_amd import dblayout, multigpu, submat, synth
 
 from helpers import pack_queries
 
@@ -13,22 +19,52 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def c2():
+def db100k():
     qs = synth.make_queries(synth.default_query_lengths())
     L, R, O = synth.make_database(100000, qs)
     order, sl, sr, so = dblayout.sort_by_length(L, R, O)
-    return qs, sl, sr, so
-
-
-def test_c2_full_size_properties(hip_ctx, oracle, c2):
-    qs, sl, sr, so = c2
-    nseq = len(sl)
     b, n, disp = dblayout.interleave(sl, sr, so, 16)
+    return qs, sl, sr, so, b, n, disp.astype(np.uint32)
+
+
+def sample_groups(nseq, W, stride, tail):
+    """Every stride-th W-lane group plus the last `tail` groups -> sequence indices."""
+    ng = (nseq + W - 1) // W
+    groups = np.unique(np.concatenate([np.arange(0, ng, stride), np.arange(max(0, ng - tail), ng)]))
+    seqs = (groups[:, None] * W + np.arange(W)[None, :]).reshape(-1)
+    return seqs[seqs < nseq]
+
+
+def cpu_port_scores(oracle, a, m, ad, sl, sr, so, seqs, sm, go, ge, W=32):
+    lens = np.asarray(sl)[seqs].astype(np.int64)
+    off = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    idx = np.repeat(np.asarray(so)[seqs] - off[:-1], lens) + np.arange(int(off[-1]))
+    bb, nn, dd = dblayout.interleave(lens, np.asarray(sr)[idx], off, W, round_to=1)
+    cpu, _ = oracle.search_chunk_simd(a, m, ad, bb, nn, dd.astype(np.uint32), W, sm, go, ge)
+    return cpu[:, :len(seqs)]
+
+
+def check_properties(t, sc, ix, nseq, m, sl, sm):
+    for q in range(t.shape[0]):
+        ws, wi = dblayout.topr_reference_order(t[q, :nseq], sc.shape[1])
+        np.testing.assert_array_equal(sc[q], ws)
+        np.testing.assert_array_equal(ix[q], wi)
+    # bounds: 0 <= score <= best possible score of the shorter partner; padding lanes are 0
+    assert (t >= 0).all() and (t[:, nseq:] == 0).all()
+    diag = int(sm[np.arange(23), np.arange(23)].max())
+    assert (t[:, :nseq] <= diag * np.minimum(m[:, None].astype(np.int64), np.asarray(sl)[None, :nseq].astype(np.int64))).all()
+    assert (np.diff(sc.astype(np.int64), axis=1) <= 0).all()
+
+
+def test_c2_full_size_properties(hip_ctx, oracle, db100k):
+    qs, sl, sr, so, b, n, disp = db100k
+    nseq = len(sl)
     a, m, ad = pack_queries(qs)
     sm = submat.load("blosum62")
     hip_ctx.set_scoring(sm, 10, 2)
     hip_ctx.set_queries(a, m, ad)
-    h = hip_ctx.chunk_upload(b, n, disp.astype(np.uint32), 16)
+    h = hip_ctx.chunk_upload(b, n, disp, 16)
     t1 = np.zeros((len(qs), len(n) * 16), np.int32)
     t2 = np.zeros_like(t1)
     hip_ctx.chunk_search(h, t1)
@@ -38,29 +74,11 @@ def test_c2_full_size_properties(hip_ctx, oracle, c2):
     np.testing.assert_array_equal(t1, t2)                      # idempotent, no stale state between launches
     sc, ix = hip_ctx.chunk_topr(h, nseq, 10)
     hip_ctx.chunk_release(h)
-    for q in range(len(qs)):
-        ws, wi = dblayout.topr_reference_order(t1[q, :nseq], 10)
-        np.testing.assert_array_equal(sc[q], ws)
-        np.testing.assert_array_equal(ix[q], wi)
-    # bounds: 0 <= score <= best possible score of the shorter partner; padding lanes are 0
-    assert (t1 >= 0).all() and (t1[:, nseq:] == 0).all()
-    diag = sm[np.arange(23), np.arange(23)].max()
-    assert (t1[:, :nseq] <= diag * np.minimum(m[:, None].astype(np.int64), sl[None, :].astype(np.int64))).all()
+    check_properties(t1, sc, ix, nseq, m, sl, sm)
     # the 12 planted copies of every query dominate its top-10 (well beyond the int8 range)
     assert (sc[:, 0] > 127).all() and (sc[:, 9] > 60).all()
-    assert (np.diff(sc.astype(np.int64), axis=1) <= 0).all()
-    # CPU port (AVX2, int8->int16->int32) on every 40th 32-lane group
-    W = 32
-    groups = np.arange(0, (nseq + W - 1) // W, 40)
-    seqs = (groups[:, None] * W + np.arange(W)[None, :]).reshape(-1)
-    seqs = seqs[seqs < nseq]
-    lens = sl[seqs].astype(np.int64)
-    off = np.zeros(len(seqs) + 1, np.int64)
-    np.cumsum(lens, out=off[1:])
-    idx = np.repeat(so[seqs] - off[:-1], lens) + np.arange(int(off[-1]))
-    bb, nn, dd = dblayout.interleave(lens.astype(np.uint16), sr[idx], off, W, round_to=1)
-    cpu, _ = oracle.search_chunk_simd(a, m, ad, bb, nn, dd.astype(np.uint32), W, sm, 10, 2)
-    np.testing.assert_array_equal(t1[:, seqs], cpu[:, :len(seqs)])
+    seqs = sample_groups(nseq, 32, 40, 8)
+    np.testing.assert_array_equal(t1[:, seqs], cpu_port_scores(oracle, a, m, ad, sl, sr, so, seqs, sm, 10, 2))
     # chunked the reference's way (8 MiB chunks) == one chunk
     plan = dblayout.chunk_plan(n, 16, 8 << 20, 1)
     assert len(plan) >= 4
@@ -74,28 +92,107 @@ def test_c2_full_size_properties(hip_ctx, oracle, c2):
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), t1)
 
 
-def test_c5_long_query_full_size_sample(hip_ctx, oracle, c2):
-    """BASELINE configs[4] shape: one query of 5000 residues against the same
-    database; the planted 5 % copy scores far beyond int8, rounds spill to HBM."""
-    _, sl, sr, so = c2
+def test_c3_pam250_full_size(hip_ctx, oracle, db100k):
+    """BASELINE configs[2]: the same queries and database with PAM250, gap 14/2 (matrix / gap configurability).
+    The library's narrowest cells are the packed int16 ones (no packed 8-bit maximum on gfx950, DESIGN.md);
+    their escalation to int32 gives the reference's exact scores."""
+    qs, sl, sr, so, b, n, disp = db100k
+    nseq = len(sl)
+    a, m, ad = pack_queries(qs)
+    sm = submat.load("pam250")
+    hip_ctx.set_scoring(sm, 14, 2)
+    hip_ctx.set_queries(a, m, ad)
+    h = hip_ctx.chunk_upload(b, n, disp, 16)
+    t1 = np.zeros((len(qs), len(n) * 16), np.int32)
+    hip_ctx.chunk_search(h, t1)
+    hip_ctx.wait()
+    sc, ix = hip_ctx.chunk_topr(h, nseq, 10)
+    hip_ctx.chunk_release(h)
+    check_properties(t1, sc, ix, nseq, m, sl, sm)
+    assert (sc[:, 0] > 127).all()
+    seqs = sample_groups(nseq, 32, 40, 8)
+    np.testing.assert_array_equal(t1[:, seqs], cpu_port_scores(oracle, a, m, ad, sl, sr, so, seqs, sm, 14, 2))
+
+
+def test_c5_long_query_full_size(hip_ctx, oracle, db100k):
+    """BASELINE configs[4]: one query of 5000 residues against all 100 000 sequences plus a planted 5 % copy of the
+    query (score far beyond int16: exact int32 re-run); rounds spill their boundary rows to HBM, the longest
+    blocks run as workgroup items at wide geometries."""
+    _, sl, sr, so, _, _, _ = db100k
     q = synth.make_queries([5000])[0]
-    nseq = 20000                                           # the 20 000 shortest + a planted copy
-    seqs_len = sl[:nseq].astype(np.int64)
-    res = sr[: int(so[nseq])]
     mut = synth.mutate(q, 0.05, 123)
-    lens = np.concatenate([seqs_len, [len(mut)]])
+    # the planted copy is the longest sequence: it sorts last
+    lens = np.concatenate([sl.astype(np.int64), [len(mut)]])
     off = np.zeros(len(lens) + 1, np.int64)
     np.cumsum(lens, out=off[1:])
-    allres = np.concatenate([res, mut])
-    b, n, disp = dblayout.interleave(lens.astype(np.uint16), allres, off, 16)
+    allres = np.concatenate([sr, mut])
+    nseq = len(lens)
+    b, n, disp = dblayout.interleave(lens, allres, off, 16)
     a, m, ad = pack_queries([q])
     sm = submat.load("blosum62")
     hip_ctx.set_scoring(sm, 10, 2)
     hip_ctx.set_queries(a, m, ad)
-    out = np.zeros((1, len(n) * 16), np.int32)
-    hip_ctx.search_chunk_async(b, n, disp.astype(np.uint32), out, 16)
+    h = hip_ctx.chunk_upload(b, n, disp.astype(np.uint32), 16)
+    t1 = np.zeros((1, len(n) * 16), np.int32)
+    t2 = np.zeros_like(t1)
+    hip_ctx.chunk_search(h, t1)
     hip_ctx.wait()
-    assert out[0, nseq] == oracle.sw_scalar(q, mut, sm, 10, 2) and out[0, nseq] > 20000
-    pick = np.arange(0, nseq, 97)
-    for s in pick[:60]:
-        assert out[0, s] == oracle.sw_scalar(q, allres[off[s]:off[s + 1]], sm, 10, 2)
+    _, _, rerun = hip_ctx.kernel_stats()
+    hip_ctx.chunk_search(h, t2)
+    hip_ctx.wait()
+    np.testing.assert_array_equal(t1, t2)
+    sc, ix = hip_ctx.chunk_topr(h, nseq, 10)
+    hip_ctx.chunk_release(h)
+    check_properties(t1, sc, ix, nseq, m, lens, sm)
+    assert t1[0, nseq - 1] == oracle.sw_scalar(q, mut, sm, 10, 2) and t1[0, nseq - 1] > 22256 and rerun >= 1
+    assert ix[0, 0] == nseq - 1
+    seqs = sample_groups(nseq, 32, 25, 12)
+    np.testing.assert_array_equal(t1[:, seqs], cpu_port_scores(oracle, a, m, ad, lens, allres, off, seqs, sm, 10, 2))
+
+
+def test_c4_database_on_one_gpu_chunked(hip_ctx, oracle):
+    """BASELINE configs[3]'s database (1 000 000 sequences) on ONE GPU, cut into 128 MiB chunks by the reference's
+    rule (sequences.c:505-541, the -k default) and searched chunk after chunk like `oswald -O search` does;
+    per-chunk device top-r merged to the global top-10 (positions in the globally sorted database)."""
+    qs = synth.make_queries(synth.default_query_lengths())
+    plan = synth.DatabasePlan(1000000, qs, synth.SEED_DB, 12)
+    shard = multigpu.ShardedDatabase(plan, 16, 134217728, 1, 0)
+    assert len(shard.mine) >= 3
+    a, m, ad = pack_queries(qs)
+    sm = submat.load("blosum62")
+    hip_ctx.set_scoring(sm, 10, 2)
+    hip_ctx.set_queries(a, m, ad)
+    parts, best = [], None
+    for k in range(len(shard.mine)):
+        c = shard.chunk(k)
+        h = hip_ctx.chunk_upload(c["b"], c["n"], c["disp"], 16)
+        t = np.zeros((len(qs), len(c["n"]) * 16), np.int32)
+        hip_ctx.chunk_search(h, t)
+        hip_ctx.wait()
+        sc, ix = hip_ctx.chunk_topr(h, c["nseq"], 10)
+        if k == len(shard.mine) - 1:       # the chunk with the longest sequences once more: idempotent
+            t2 = np.zeros_like(t)
+            hip_ctx.chunk_search(h, t2)
+            hip_ctx.wait()
+            np.testing.assert_array_equal(t, t2)
+        hip_ctx.chunk_release(h)
+        check_properties(t, sc, ix, c["nseq"], m, c["ls"], sm)
+        seqs = sample_groups(c["nseq"], 32, 150, 6)
+        np.testing.assert_array_equal(t[:, seqs], cpu_port_scores(oracle, a, m, ad, c["ls"], c["res"], c["off"], seqs, sm, 10, 2))
+        parts.append((sc, multigpu.global_index(ix, c["s0"])))
+        whole = (t[:, :c["nseq"]], c["s0"])
+        # running global top-10 from the full tables, the slow way
+        for q in range(len(qs)):
+            ws, wi = dblayout.topr_reference_order(whole[0][q], 10)
+            cur = (ws, wi.astype(np.int64) + whole[1])
+            if best is None:
+                best = [None] * len(qs)
+            best[q] = cur if best[q] is None else dblayout.merge_topr([best[q], cur], 10)
+        del t
+    gs, gi = multigpu.merge_local(parts, 10)
+    for q in range(len(qs)):
+        np.testing.assert_array_equal(gs[q], best[q][0])
+        np.testing.assert_array_equal(gi[q], best[q][1])
+    # the planted 5 % copies are on top, and their sorted positions hold sequences of about the query's length
+    assert (gs[:, 0] > 300).all()
+    assert (np.abs(shard.sorted_lengths[gi[:, 0]] - m.astype(np.int64)) <= 5).all()

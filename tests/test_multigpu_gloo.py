@@ -8,6 +8,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -27,53 +28,90 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, r, ret):
+QLENS, NSEQ, DBSEED = [60, 35, 90], 900, 21
+
+
+def _worker(rank, world, port, r, max_chunk, ret):
+    """bench.py's N > 1 code path (multigpu.ShardedDatabase + multigpu.rank_step) with the CPU oracle standing in
+    for the GPU search of a chunk and gloo for RCCL."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    qs = synth.make_queries([60, 35, 90], seed=5)
-    L, R, O = synth.make_database(900, qs, seed=21, homologs_per_query=5)
-    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
-    n_all = dblayout.group_lengths(sl, 16)
+    qs = synth.make_queries(QLENS, seed=5)
+    plan = synth.DatabasePlan(NSEQ, qs, DBSEED, 5)
+    shard = multigpu.ShardedDatabase(plan, 16, max_chunk, world, rank)
+    chunks = [shard.chunk(k) for k in range(len(shard.mine))]
     a, m, ad = pack_queries(qs)
     sm = submat.load("blosum62")
-    mine = multigpu.rank_chunks(n_all, 16, 134217728, world, rank)
-    best_s = np.full((3, r), -1, np.int32)
-    best_i = np.full((3, r), -1, np.int64)
-    for g0, g1 in mine:
-        b, n, disp = dblayout.interleave(sl, sr, so, 16, g_begin=g0, g_end=g1)
-        sc = pyoracle.search_chunk_scalar(a, m, ad, b, n, disp.astype(np.uint32), 16, sm, 10, 2, threads=2)
-        nvalid = min(900, g1 * 16) - g0 * 16
-        for q in range(3):
-            s_, i_ = dblayout.topr_reference_order(sc[q, :nvalid], r)
-            s2, i2 = dblayout.merge_topr([(best_s[q], best_i[q]), (s_, i_.astype(np.int64) + g0 * 16)], r)
-            best_s[q, :len(s2)], best_i[q, :len(i2)] = s2, i2
-    out_s, out_i = multigpu.gather_topr(best_s, best_i, r, dist)
+    table = {}
+
+    def launch(c):
+        table[c["s0"]] = pyoracle.search_chunk_scalar(a, m, ad, c["b"], c["n"], c["disp"], 16, sm, 10, 2, threads=2)
+
+    def collect(c):
+        sc = np.full((len(qs), r), -1, np.int32)
+        ix = np.full((len(qs), r), 0xFFFFFFFF, np.uint32)      # what oswald_hip_chunk_topr returns for empty slots
+        for q in range(len(qs)):
+            s_, i_ = dblayout.topr_reference_order(table[c["s0"]][q, :c["nseq"]], r)
+            sc[q, :len(s_)], ix[q, :len(i_)] = s_, i_
+        return sc, ix
+
+    out_s, out_i = multigpu.rank_step(chunks, launch, collect, len(qs), r, 0, dist)
     if rank == 0:
-        ret["scores"], ret["index"], ret["chunks"] = out_s, out_i, mine
+        ret["scores"], ret["index"] = out_s, out_i
+    ret[f"chunks{rank}"] = [(c["g0"], c["g1"]) for c in chunks]
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_merge(oracle):
-    world, r = 2, 12
+@pytest.mark.parametrize("world,max_chunk,r", [(2, 134217728, 12), (4, 134217728, 12), (4, 60000, 10), (3, 90000, 1000)])
+def test_ranks_shard_and_merge(oracle, world, max_chunk, r):
+    """world ranks over gloo == one process over the whole database: same top-r scores AND the same
+    positions in the globally sorted database (r = 1000 > sequences per chunk: empty slots on the way)."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), r, ret), nprocs=world, join=True)
-    qs = synth.make_queries([60, 35, 90], seed=5)
-    L, R, O = synth.make_database(900, qs, seed=21, homologs_per_query=5)
+    mp.spawn(_worker, args=(world, _free_port(), r, max_chunk, ret), nprocs=world, join=True)
+    qs = synth.make_queries(QLENS, seed=5)
+    L, R, O = synth.make_database(NSEQ, qs, seed=DBSEED, homologs_per_query=5)
     order, sl, sr, so = dblayout.sort_by_length(L, R, O)
     b, n, disp = dblayout.interleave(sl, sr, so, 16)
     a, m, ad = pack_queries(qs)
     whole = oracle.search_chunk_scalar(a, m, ad, b, n, disp.astype(np.uint32), 16, submat.load("blosum62"), 10, 2)
     for q in range(3):
-        ws, wi = dblayout.topr_reference_order(whole[q, :900], r)
-        np.testing.assert_array_equal(ret["scores"][q], ws)
-        np.testing.assert_array_equal(ret["index"][q], wi)
-    assert len(ret["chunks"]) >= 1
+        ws, wi = dblayout.topr_reference_order(whole[q, :NSEQ], r)
+        np.testing.assert_array_equal(ret["scores"][q, :len(ws)], ws)
+        np.testing.assert_array_equal(ret["index"][q, :len(wi)], wi)
+        assert (ret["index"][q, len(wi):] == -1).all()
+    allc = sorted(c for k in range(world) for c in ret[f"chunks{k}"])
+    assert allc[0][0] == 0 and allc[-1][1] == len(n) and all(allc[i][1] == allc[i + 1][0] for i in range(len(allc) - 1))
+    if max_chunk < 134217728:
+        assert len(allc) > world   # several chunks per rank, dealt round-robin
+
+
+def test_sharded_database_equals_whole():
+    """ShardedDatabase materialises only a rank's sequences; together the ranks hold exactly the sorted database."""
+    qs = synth.make_queries([50, 200], seed=9)
+    plan = synth.DatabasePlan(3000, qs, 77, 4)
+    L, R, O = synth.make_database(3000, qs, seed=77, homologs_per_query=4)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
+    got = {}
+    for rank in range(3):
+        sh = multigpu.ShardedDatabase(plan, 16, 300000, 3, rank)
+        for k in range(len(sh.mine)):
+            c = sh.chunk(k)
+            got[c["g0"]] = c
+    pos = 0
+    for g0 in sorted(got):
+        c = got[g0]
+        assert c["s0"] == g0 * 16
+        np.testing.assert_array_equal(c["n"], nfull[c["g0"]:c["g1"]])
+        np.testing.assert_array_equal(c["b"], bfull[pos:pos + c["b"].size])
+        pos += c["b"].size
+    assert pos == bfull.size
 
 
 def test_rank_chunks_cover_database_once():

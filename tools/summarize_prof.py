@@ -2,9 +2,20 @@
 """tools/summarize_prof.py -- condense rocprofv3 CSV output of tools/profile_gpu.sh
 into the small files committed under profiles/ (kernel stats, PMC per-launch
 averages, HBM traffic per launch of the DP kernel)."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 
 out, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/oswald_hip.cpp")  # = bench.py
+
+
+def source_digest():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
 DP = ("osw_sw_s16q", "osw_sw_s16", "osw_sw_pk16q", "osw_sw_pk16")  # first-pass DP kernels (fp16 / int16 mode)
 KERNELS = DP + ("osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
 
@@ -97,6 +108,11 @@ try:
                           "fetch_factor": kf, "write_factor": kw,
                           "hbm_bytes_per_launch": int((kf * fs + kw * ws) * 1024),
                           "correction": "bytes = KiB * 1024 * factor; factor = 1 GiB / counter value of a 1-GiB stream of 8-B entries accessed as 2 dwords per lane (the DP kernels' spill access)"}
+    # what bench.py reads for roofline.traffic: tied to the kernel sources it was measured on
+    t = dict(summary["traffic"], workload=wl, nseq=int(nseq), source_digest=source_digest(),
+             source=f"tools/profile_gpu.sh {wl} {nseq} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), int16 cells (bench.py default)")
+    with open(os.path.join(out, f"traffic_{wl}_{nseq}.json"), "w") as f:
+        json.dump(t, f, indent=1)
 except KeyError:
     pass
 print(json.dumps(summary, indent=1))
