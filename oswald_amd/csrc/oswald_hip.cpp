@@ -256,12 +256,12 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
         HIP_TRY(hipMemcpyAsync(d.pair_len.p, ctx->pair_len.data(), np * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(osw_launch_build_pair_profile((const uint2 *)(alt ? d.prof_alt.p : d.prof.p), (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                               (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
-                                              ctx->pair_max_rowblocks, (uint4 *)d.prof_pair.p, d.stream));
+                                              ctx->pair_max_rowblocks, alt /* column-frame pair cell: 32-bit integer sums */, (uint4 *)d.prof_pair.p, d.stream));
         if (alt) { // plain int16 pair profile for the items the first-pass cell hands to the plain cell
             HIP_TRY(d.prof_pair_i16.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096));
             HIP_TRY(osw_launch_build_pair_profile((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                                   (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
-                                                  ctx->pair_max_rowblocks, (uint4 *)d.prof_pair_i16.p, d.stream));
+                                                  ctx->pair_max_rowblocks, false, (uint4 *)d.prof_pair_i16.p, d.stream));
         }
     }
     HIP_TRY(hipStreamSynchronize(d.stream)); // host vectors may change after return

@@ -189,60 +189,75 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 //   x, Dn, E, F, sc as above; u_ in go_ slot: gap open; fl1: the floor operand
 // ---------------------------------------------------------------------------
 #define OSW_I16S_FRAME_MAX 8192u
-#define OSW_I16S_ROW_EVEN(FREG, x, xn, Er, Dn, s_next, ge, go, fl1)                          \
+// The three adds / subtracts of a row exist in two spellings.  VOP3P packed 16-bit (saturating), and plain
+// 32-bit VOP2 on the packed pair: gfx950 issues v_add_u32 / v_sub_u32 in ~2 cycles against ~4 for any VOP3P
+// instruction (profiles/r02_oprate_valu_issue.txt; in the cell's mix a row goes from 27.7 to 25.3 cycles,
+// profiles/r02_oprate2_valu_mix.txt).  The 32-bit forms are exact whenever no borrow / carry crosses the
+// halves: every H, E, F pattern is >= 1024 >= go, ge (the kernel checks go <= 1024; ge <= 64 anyway), and
+// the diagonal add takes a profile whose (S_lo, S_hi) pairs are stored as the 32-bit INTEGER S_lo + 65536 * S_hi
+// (query-pair profile, osw_build_pair_profile), so that the sum is right in both halves although S_lo may be
+// negative; the sequence-pair cell assembles its score pairs with v_perm_b32 and keeps the packed add.
+#define OSW_ADD_PK "v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp"
+#define OSW_ADD_32 "v_add_u32 %[xn_], %[Dn_], %[sn_]"
+#define OSW_SUBU_PK(H) "v_pk_sub_u16 %[t], " H ", %[go_] clamp"
+#define OSW_SUBU_32(H) "v_subrev_u32 %[t], %[go_], " H
+#define OSW_SUBF_PK(F) "v_pk_sub_u16 " F ", " F ", %[ge_] clamp"
+#define OSW_SUBF_32(F) "v_subrev_u32 " F ", %[ge_], " F
+
+#define OSW_I16S_ROW_EVEN(ADD, SUBU, SUBF, FREG, x, xn, Er, Dn, s_next, ge, go, fl1)         \
     do {                                                                                     \
         v2s t_;                                                                              \
-        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+        asm volatile(ADD "\n\t"                                                              \
                      "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_sub_u16 %[t], %[Dn_], %[go_] clamp\n\t"                           \
+                     SUBU("%[Dn_]") "\n\t"                                                   \
                      "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
                      "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     SUBF(FREG)                                                              \
                      : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn)         \
                      : [x_] "v"(x), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
                      : OSW_INFLIGHT);                                                        \
     } while (0)
 
-#define OSW_I16S_ROW_ODD(FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1)                   \
+#define OSW_I16S_ROW_ODD(ADD, SUBU, SUBF, FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1)  \
     do {                                                                                     \
         v2s t_;                                                                              \
-        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+        asm volatile(ADD "\n\t"                                                              \
                      "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_sub_u16 %[t], %[Dn_], %[go_] clamp\n\t"                           \
+                     SUBU("%[Dn_]") "\n\t"                                                   \
                      "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[Dn_]\n\t"                  \
                      "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
                      "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     SUBF(FREG)                                                              \
                      : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
                      : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
                      : OSW_INFLIGHT);                                                        \
     } while (0)
 
 // first odd row of a column: starts the column maximum (sc is written, not read)
-#define OSW_I16S_ROW_ODD1(FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1)                  \
+#define OSW_I16S_ROW_ODD1(ADD, SUBU, SUBF, FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1) \
     do {                                                                                     \
         v2s t_;                                                                              \
-        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
+        asm volatile(ADD "\n\t"                                                              \
                      "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_sub_u16 %[t], %[Dn_], %[go_] clamp\n\t"                           \
+                     SUBU("%[Dn_]") "\n\t"                                                   \
                      "v_pk_maximum3_f16 %[sc_], %[Dp_], %[Dn_], %[Dn_]\n\t"                  \
                      "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
                      "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     SUBF(FREG)                                                              \
                      : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "=&v"(sc) \
                      : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
                      : OSW_INFLIGHT);                                                        \
     } while (0)
 
-#define OSW_I16S_ROW_LAST(FREG, x, Er, hl, Dp, sc, ge, go, fl1)                              \
+#define OSW_I16S_ROW_LAST(SUBU, SUBF, FREG, x, Er, hl, Dp, sc, ge, go, fl1)                  \
     do {                                                                                     \
         v2s t_;                                                                              \
         asm volatile("v_pk_maximum3_f16 %[hl_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_sub_u16 %[t], %[hl_], %[go_] clamp\n\t"                           \
+                     SUBU("%[hl_]") "\n\t"                                                   \
                      "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[hl_]\n\t"                  \
                      "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
                      "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp"                         \
+                     SUBF(FREG)                                                              \
                      : [hl_] "=&v"(hl), [t] "=&v"(t_), [E_] "+v"(Er), [sc_] "+v"(sc)         \
                      : [x_] "v"(x), [Dp_] "v"(Dp), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
                      : OSW_INFLIGHT);                                                        \
@@ -276,6 +291,9 @@ struct ArithI16B {
 
 // `goe` carries the gap OPEN penalty for this cell, `aux` the floor of the next column's frame, and the rows
 // accumulate the COLUMN maximum (in the column's frame) into `sc`; sw_round_fast turns it into a true score.
+// INTSUM: the profile stores its score pairs as 32-bit integer sums (see OSW_ADD_32): the diagonal add is a
+// v_add_u32 too; otherwise only the two subtracts are.
+template <bool INTSUM>
 struct ArithI16S {
     static constexpr int kCeiling = 22256; // true score from which a sequence is re-run in int32 (31600 - 1024 - 8192 - 128)
     static constexpr uint32_t kFloor = OSW_I16B_BIAS;
@@ -284,17 +302,27 @@ struct ArithI16S {
     static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t go, v2s fl1)
     {
         v2s xn;
-        if constexpr (ODD && FIRST) OSW_I16S_ROW_ODD1(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
-        else if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
-        else OSW_I16S_ROW_EVEN(OSW_VF, x, xn, Er, Dn, s_next, ge, go, fl1);
+        if constexpr (INTSUM) {
+            if constexpr (ODD && FIRST) OSW_I16S_ROW_ODD1(OSW_ADD_32, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
+            else if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_ADD_32, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
+            else OSW_I16S_ROW_EVEN(OSW_ADD_32, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, s_next, ge, go, fl1);
+        } else {
+            if constexpr (ODD && FIRST) OSW_I16S_ROW_ODD1(OSW_ADD_PK, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
+            else if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_ADD_PK, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
+            else OSW_I16S_ROW_EVEN(OSW_ADD_PK, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, s_next, ge, go, fl1);
+        }
         x = xn;
     }
     template <int P>
     static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t ge, uint32_t go, v2s fl1)
     {
-        OSW_I16S_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, ge, go, fl1);
+        OSW_I16S_ROW_LAST(OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, Er, hl, Dp, sc, ge, go, fl1);
     }
-    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0) { return __builtin_elementwise_add_sat(top_prev, s0); }
+    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0)
+    {
+        if constexpr (INTSUM) return as_v2s(as_u32(top_prev) + as_u32(s0));
+        else return __builtin_elementwise_add_sat(top_prev, s0);
+    }
     static __device__ __forceinline__ int to_int(short bits) { return (int)(uint16_t)bits; } // the running score is a true one
     static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 22256u; }
 };
@@ -486,8 +514,8 @@ struct CellQueryPair {
 
 typedef CellSeqPair<ArithI16B> CellPK16B;
 typedef CellQueryPair<ArithI16B> CellPK16BQ;
-typedef CellSeqPair<ArithI16S> CellPK16S;
-typedef CellQueryPair<ArithI16S> CellPK16SQ;
+typedef CellSeqPair<ArithI16S<false>> CellPK16S;
+typedef CellQueryPair<ArithI16S<true>> CellPK16SQ;
 
 // Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.
 // Compiler-scheduled throughout (rare path: re-run of saturated lanes).
@@ -905,14 +933,15 @@ static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint
     }
 }
 
-// Which blocks the column-frame cell may take (ArithI16S): the frame offset (columns + 2G + 2) * ge must
+// Which blocks the column-frame cell may take (ArithI16S; p.goe_pk holds the gap OPEN penalty there): the frame offset (columns + 2G + 2) * ge must
 // stay within OSW_I16S_FRAME_MAX, and -- whatever ge is, 0 included -- a first round indexes the floor table
 // BY COLUMN (entry G + column, up to two columns of prefetch and G - 1 drain steps past the block), so the
 // block must also fit the table's OSW_I16S_TABLE entries.  Everything else runs on the plain biased cell.
-static __device__ __forceinline__ bool osw_frame_cell_takes(uint32_t cols, uint32_t lg, uint32_t ge)
+// go <= 1024: the cell subtracts the gap penalties with 32-bit instructions on the packed pair (OSW_SUBU_32).
+static __device__ __forceinline__ bool osw_frame_cell_takes(uint32_t cols, uint32_t lg, uint32_t ge, uint32_t go)
 {
     const uint32_t span = cols + 2u * (1u << lg) + 2u;
-    return ge <= 64u && span + 2u <= OSW_I16S_TABLE && span * ge <= OSW_I16S_FRAME_MAX;
+    return ge <= 64u && go <= 1024u && span + 2u <= OSW_I16S_TABLE && span * ge <= OSW_I16S_FRAME_MAX;
 }
 
 // ---------------------------------------------------------------------------
@@ -963,7 +992,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest run on CF
-        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge);
+        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge, p.goe_pk & 0xffffu);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             if (cf_only) {
                 const v2s score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_fb, p.ge_fb);
@@ -994,7 +1023,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
-        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge);
+        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge, p.goe_pk & 0xffffu);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             if (cf_only) {
                 const v2s score = run_item<CF, false>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_fb, p.ge_fb);
@@ -1164,7 +1193,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_
 extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile(const uint2 *__restrict__ prof, const uint32_t *__restrict__ prof_off,
                                                                           const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ pair_q,
                                                                           const uint32_t *__restrict__ pair_off, const uint16_t *__restrict__ pair_len,
-                                                                          uint32_t npairs, uint4 *__restrict__ prof_pair)
+                                                                          uint32_t npairs, uint32_t intsum, uint4 *__restrict__ prof_pair)
 {
     const uint32_t pr = blockIdx.y;
     if (pr >= npairs) return;
@@ -1175,11 +1204,16 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile(const u
         const uint32_t rb = e >> 5, code = e & 31;
         const uint2 A = rb < na ? prof[(size_t)(prof_off[qa] + rb) * 32 + code] : make_uint2(0, 0);
         const uint2 Bv = rb < nb ? prof[(size_t)(prof_off[qb] + rb) * 32 + code] : make_uint2(0, 0);
+        // (S_A, S_B) as two int16 halves -- or, intsum, as the 32-bit integer S_A + 65536 * S_B, which a plain
+        // 32-bit add turns into the right sums in both halves of a non-negative packed pair (OSW_ADD_32)
+        auto pack = [&](uint32_t a16, uint32_t b16) {
+            return intsum ? (uint32_t)((int32_t)(int16_t)a16 + (int32_t)(int16_t)b16 * 65536) : (a16 & 0xffffu) | (b16 << 16);
+        };
         uint4 o;
-        o.x = (A.x & 0xffffu) | (Bv.x << 16);
-        o.y = (A.x >> 16) | (Bv.x & 0xffff0000u);
-        o.z = (A.y & 0xffffu) | (Bv.y << 16);
-        o.w = (A.y >> 16) | (Bv.y & 0xffff0000u);
+        o.x = pack(A.x & 0xffffu, Bv.x & 0xffffu);
+        o.y = pack(A.x >> 16, Bv.x >> 16);
+        o.z = pack(A.y & 0xffffu, Bv.y & 0xffffu);
+        o.w = pack(A.y >> 16, Bv.y >> 16);
         prof_pair[(size_t)(pair_off[pr] + rb) * 32 + code] = o;
     }
 }
@@ -1287,12 +1321,12 @@ hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 
 hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
-                                         uint4 *prof_pair, hipStream_t s)
+                                         bool intsum, uint4 *prof_pair, hipStream_t s)
 {
     if (npairs == 0) return hipSuccess;
     uint32_t gx = (max_rowblocks * 32 + 255) / 256;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(osw_build_pair_profile, dim3(gx, npairs), dim3(256), 0, s, prof, prof_off, qlen, pair_q, pair_off, pair_len, npairs, prof_pair);
+    hipLaunchKernelGGL(osw_build_pair_profile, dim3(gx, npairs), dim3(256), 0, s, prof, prof_off, qlen, pair_q, pair_off, pair_len, npairs, intsum ? 1u : 0u, prof_pair);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -116,7 +116,7 @@ def test_c3_pam250_full_size(hip_ctx, oracle, db100k):
 
 def test_c5_long_query_full_size(hip_ctx, oracle, db100k):
     """BASELINE configs[4]: one query of 5000 residues against all 100 000 sequences plus a planted 5 % copy of the
-    query (score far beyond int16: exact int32 re-run); rounds spill their boundary rows to HBM, the longest
+    query (score beyond the column-frame ceiling); rounds spill their boundary rows to HBM, the longest
     blocks run as workgroup items at wide geometries."""
     _, sl, sr, so, _, _, _ = db100k
     q = synth.make_queries([5000])[0]
@@ -137,14 +137,14 @@ def test_c5_long_query_full_size(hip_ctx, oracle, db100k):
     t2 = np.zeros_like(t1)
     hip_ctx.chunk_search(h, t1)
     hip_ctx.wait()
-    _, _, rerun = hip_ctx.kernel_stats()
     hip_ctx.chunk_search(h, t2)
     hip_ctx.wait()
     np.testing.assert_array_equal(t1, t2)
     sc, ix = hip_ctx.chunk_topr(h, nseq, 10)
     hip_ctx.chunk_release(h)
     check_properties(t1, sc, ix, nseq, m, lens, sm)
-    assert t1[0, nseq - 1] == oracle.sw_scalar(q, mut, sm, 10, 2) and t1[0, nseq - 1] > 22256 and rerun >= 1
+    # (beyond the column-frame cell's ceiling; its 5004-column block runs on the plain biased cell, exact below 30576)
+    assert t1[0, nseq - 1] == oracle.sw_scalar(q, mut, sm, 10, 2) and t1[0, nseq - 1] > 22256
     assert ix[0, 0] == nseq - 1
     seqs = sample_groups(nseq, 32, 25, 12)
     np.testing.assert_array_equal(t1[:, seqs], cpu_port_scores(oracle, a, m, ad, lens, allres, off, seqs, sm, 10, 2))
