@@ -96,6 +96,20 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
 int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                             const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int *chunk);
 
+/* The same, without waiting for the device: returns once the copies and the re-tile kernel are queued on the
+ * device's stream.  b / n / disp must stay valid until the chunk has been searched (oswald_hip_chunk_search
+ * finishes the upload first) or oswald_hip_wait() has returned.  With several devices this is what lets their
+ * uploads overlap: queue all of them, then search each (the reference's four clEnqueueWriteBuffer per device
+ * are asynchronous too and share one clFinish per device, FPGAsearch.c:180-198). */
+int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
+                                  const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int *chunk);
+
+/* Optional: allocate the device-side work space (per-wave spill scratch of the long-query rounds) for databases
+ * whose longest sequence has max_sequence_length residues, on device dev (dev < 0: all).  Without it the first
+ * upload allocates what its chunk needs.  Stands where the reference sizes its device buffers for the largest
+ * chunk before the timed region starts (FPGAsearch.c:85-96). */
+int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length);
+
 /* All queries against a resident chunk, asynchronously on the device's stream.
  * If scores_out != NULL the int32 scores [nq][ngroups*W] are copied there
  * (valid after oswald_hip_wait).  Replaces the per-query clSetKernelArg +

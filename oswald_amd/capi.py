@@ -20,7 +20,7 @@ SYMBOLS = (
     "oswald_hip_abi_version", "oswald_hip_last_error", "oswald_hip_device_count", "oswald_hip_init", "oswald_hip_finalize",
     "oswald_hip_info", "oswald_hip_set_scoring", "oswald_hip_set_queries", "oswald_hip_chunk_upload", "oswald_hip_chunk_search",
     "oswald_hip_chunk_release", "oswald_hip_search_chunk_async", "oswald_hip_wait", "oswald_hip_chunk_topr",
-    "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry",
+    "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry", "oswald_hip_chunk_upload_async", "oswald_hip_reserve",
 )
 
 
@@ -50,6 +50,8 @@ def load():
     lib.oswald_hip_set_scoring.argtypes = [vp, vp, i32, i32, i32]
     lib.oswald_hip_set_queries.argtypes = [vp, vp, u64, vp, vp, u32]
     lib.oswald_hip_chunk_upload.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, C.POINTER(i32)]
+    lib.oswald_hip_chunk_upload_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, C.POINTER(i32)]
+    lib.oswald_hip_reserve.argtypes = [vp, i32, u32]
     lib.oswald_hip_chunk_search.argtypes = [vp, i32, i32, vp]
     lib.oswald_hip_chunk_release.argtypes = [vp, i32, i32]
     lib.oswald_hip_search_chunk_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, vp]
@@ -123,13 +125,21 @@ class Context:
         _chk(self.lib.oswald_hip_set_queries(self.h, _ptr(a), a.size, _ptr(m), _ptr(a_disp), m.size))
         self.nq = int(m.size)
 
-    def chunk_upload(self, b, n, disp, lane_width: int = 16, dev: int = 0) -> int:
+    def chunk_upload(self, b, n, disp, lane_width: int = 16, dev: int = 0, wait: bool = True) -> int:
+        """wait=False: oswald_hip_chunk_upload_async (the arrays are kept alive until wait())."""
         b = np.ascontiguousarray(b, dtype=np.uint8)
         n = np.ascontiguousarray(n, dtype=np.uint16)
         disp = np.ascontiguousarray(disp, dtype=np.uint32)
         h = C.c_int(-1)
-        _chk(self.lib.oswald_hip_chunk_upload(self.h, dev, _ptr(b), b.size, _ptr(n), _ptr(disp), n.size, lane_width, C.byref(h)))
+        if wait:
+            _chk(self.lib.oswald_hip_chunk_upload(self.h, dev, _ptr(b), b.size, _ptr(n), _ptr(disp), n.size, lane_width, C.byref(h)))
+        else:
+            self._keep += [b, n, disp]
+            _chk(self.lib.oswald_hip_chunk_upload_async(self.h, dev, _ptr(b), b.size, _ptr(n), _ptr(disp), n.size, lane_width, C.byref(h)))
         return h.value
+
+    def reserve(self, max_sequence_length: int, dev: int = -1):
+        _chk(self.lib.oswald_hip_reserve(self.h, dev, max_sequence_length))
 
     def chunk_search(self, chunk: int, out: np.ndarray | None = None, dev: int = 0):
         """Asynchronous; `out` (int32 [nq][ngroups*W]) is valid after wait()."""

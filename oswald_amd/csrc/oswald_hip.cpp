@@ -92,6 +92,7 @@ struct Chunk {
     int items_bits = 0;                 // cell width it was planned for
     uint32_t max_lg = 0;                // widest geometry in the item list
     bool searched = false;
+    bool upload_pending = false;        // uploaded with _async: the device's stream has not been synchronised since
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -423,16 +424,49 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     const double fair = planned / nwaves;
     const bool no_prio = getenv("OSWALD_HIP_NO_PRIO") != nullptr;
     auto prio_of = [&](double cost) { return no_prio ? 0u : cost > fair / 2 ? 3u : cost > fair / 4 ? 2u : cost > fair / 8 ? 1u : 0u; };
+    // Phase 1 of a launch is ONE queue of workgroup entries, heaviest first (longest-processing-time order): a
+    // workgroup item (four sub-blocks of one item on the four waves, shared profile slice), or a QUAD of four
+    // independent wave items of similar cost -- the wave items that are heavy compared with a wave's fair share of
+    // the launch.  (They used to wait in the wave queue until every workgroup item was done: a wave item worth 0.7
+    // of the fair share that starts at 60 % of the launch defines its end.)  Phase 2, the per-wave queue, keeps
+    // the light wave items that fill the tail.  An entry is four item slots, one per wave; slot.y bit 31 marks a
+    // workgroup item, slot.y == OSW_ITEM_NONE an empty slot of the last quad.
+    const double quad_frac = getenv("OSWALD_HIP_QUAD_FRAC") ? atof(getenv("OSWALD_HIP_QUAD_FRAC")) : 0.5; // measured: 0.25 costs C2 6 % (waves in step), 1.0 loses the gain on C5
+    struct Entry { double cost; uint2 slot[4]; };
     std::vector<uint2> flat[2];
+    uint32_t n_entries[2] = {0, 0}, n_wave[2] = {0, 0}, n_quads[2] = {0, 0};
     for (int kd = 0; kd < 2; ++kd) {
-        flat[kd].reserve(its[kd].size() + its_wg[kd].size());
-        for (const It &i : its_wg[kd]) flat[kd].push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
-        for (const It &i : its[kd]) flat[kd].push_back(make_uint2(i.x | (prio_of(i.cost) << 30), i.b));
+        std::vector<Entry> ent;
+        ent.reserve(its_wg[kd].size() + its[kd].size() / 4 + 1);
+        for (const It &i : its_wg[kd]) {
+            Entry e;
+            e.cost = i.cost;
+            for (uint32_t w = 0; w < 4; ++w) e.slot[w] = make_uint2((i.x + (w << 16)) | (prio_of(i.cost) << 30), i.b | OSW_ITEM_WG_FLAG);
+            ent.push_back(e);
+        }
+        size_t heavy = 0;
+        while (!i32 && heavy < its[kd].size() && its[kd][heavy].cost >= quad_frac * fair) ++heavy;
+        for (size_t k = 0; k < heavy; k += 4) {
+            Entry e;
+            e.cost = its[kd][k].cost;
+            for (uint32_t w = 0; w < 4; ++w) {
+                if (k + w < heavy) { const It &i = its[kd][k + w]; e.slot[w] = make_uint2(i.x | (prio_of(i.cost) << 30), i.b); }
+                else e.slot[w] = make_uint2(0u, OSW_ITEM_NONE);
+            }
+            ent.push_back(e);
+            n_quads[kd]++;
+        }
+        std::stable_sort(ent.begin(), ent.end(), [](const Entry &x, const Entry &y) { return x.cost > y.cost; });
+        flat[kd].reserve(ent.size() * 4 + its[kd].size() - heavy);
+        for (const Entry &e : ent) for (uint32_t w = 0; w < 4; ++w) flat[kd].push_back(e.slot[w]);
+        for (size_t k = heavy; k < its[kd].size(); ++k) flat[kd].push_back(make_uint2(its[kd][k].x | (prio_of(its[kd][k].cost) << 30), its[kd][k].b));
+        n_entries[kd] = (uint32_t)ent.size();
+        n_wave[kd] = (uint32_t)(its[kd].size() - heavy);
     }
-    c.nitems_wg = (uint32_t)its_wg[0].size();
-    c.nitems = (uint32_t)its[0].size();
-    c.nitems_q_wg = (uint32_t)its_wg[1].size();
-    c.nitems_q = (uint32_t)its[1].size();
+    c.nitems_wg = n_entries[0];
+    c.nitems = n_wave[0];
+    c.nitems_q_wg = n_entries[1];
+    c.nitems_q = n_wave[1];
     if (getenv("OSWALD_HIP_DEBUG")) {
         fprintf(stderr, "[oswald_hip] plan: %zu single queries, %zu query pairs, total %.3g slots, %.0f waves, target %.3g, max lg %u\n",
                 i32 ? (size_t)ctx->nq : ctx->singles.size(), i32 ? (size_t)0 : ctx->pair_len.size(), total, nwaves, target, c.max_lg);
@@ -440,8 +474,8 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             double sw = 0, sg = 0;
             for (const It &i : its[kd]) sw += i.cost;
             for (const It &i : its_wg[kd]) sg += i.cost * 4;
-            fprintf(stderr, "[oswald_hip]   %s: wave items %zu (sum %.3g, max %.3g), workgroup items %zu (sum %.3g, max %.3g)\n", kd ? "pairs  " : "singles",
-                    its[kd].size(), sw, its[kd].empty() ? 0.0 : its[kd][0].cost, its_wg[kd].size(), sg, its_wg[kd].empty() ? 0.0 : its_wg[kd][0].cost);
+            fprintf(stderr, "[oswald_hip]   %s: wave items %zu (sum %.3g, max %.3g; %u quads in phase 1, %u in the wave queue), workgroup items %zu (sum %.3g, max %.3g), fair share %.3g\n", kd ? "pairs  " : "singles",
+                    its[kd].size(), sw, its[kd].empty() ? 0.0 : its[kd][0].cost, n_quads[kd], n_wave[kd], its_wg[kd].size(), sg, its_wg[kd].empty() ? 0.0 : its_wg[kd][0].cost, fair);
             uint32_t hist[2][8] = {{0}};
             for (const It &i : its[kd]) hist[0][OSW_ITEM_LG(i.x)]++;
             for (const It &i : its_wg[kd]) hist[1][OSW_ITEM_LG(i.x)]++;
@@ -470,6 +504,37 @@ void release_registered(Device &d)
 {
     for (void *p : d.registered) (void)hipHostUnregister(p);
     d.registered.clear();
+}
+
+// Strip-boundary spill scratch: one region per resident wave and launch (two launches run side by side), every region
+// a reserved page, a trash page and (columns + pad) x 32 {H,F} entries: the boundary row of the longest block at
+// two lane groups (the planner runs longer blocks, or G = 1 beyond half of it, at a geometry with fewer lanes per
+// group).  Sized from the longest sequence the device is asked to hold (at most 4096 columns' worth) and grown when
+// a later chunk needs more; a multi-GB hipMalloc occasionally takes ~200 ms, which is why oswald_hip_reserve exists.
+int ensure_scratch(Device &d, uint32_t max_cols)
+{
+    const uint64_t cols = std::min<uint64_t>(std::max<uint64_t>(max_cols, 1024), 4096);
+    const uint64_t stride = (cols + OSW_SCRATCH_PAD_COLS) * 32u;
+    if (stride <= d.bnd_stride && d.bnd.p) return 0;
+    HIP_TRY(hipStreamSynchronize(d.stream)); // nothing may still be spilling into the old regions
+    HIP_TRY(hipStreamSynchronize(d.stream2));
+    const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
+    d.bnd.release();
+    d.bnd_stride = 0;
+    HIP_TRY(d.bnd.reserve(2 * slots * (stride + OSW_SCRATCH_DATA) * sizeof(uint2)));
+    HIP_TRY(hipMemset2DAsync(d.bnd.p, (stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream));
+    d.bnd_stride = stride;
+    for (Chunk &c : d.chunks) c.items_version = ~0ull; // the plans were made for the old region size
+    return 0;
+}
+
+// An upload queued with oswald_hip_chunk_upload_async has landed once the device's stream is drained.
+int finish_upload(Device &d, Chunk &c)
+{
+    if (!c.upload_pending) return 0;
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    for (Chunk &k : d.chunks) k.upload_pending = false; // one stream: everything queued before is done too
+    return 0;
 }
 
 void drain_events(Device &d)
@@ -529,17 +594,6 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         d.grid = (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu;
         r = d.counters.reserve((2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
-        // Strip-boundary spill scratch: one region per resident wave and launch (two launches run side by side),
-        // allocated here because a multi-GB hipMalloc occasionally takes ~200 ms.  Every region starts with a
-        // reserved page and its trash page.
-        {
-            const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
-            d.bnd_stride = OSW_SCRATCH_ENTRIES;
-            r = d.bnd.reserve(2 * slots * (d.bnd_stride + OSW_SCRATCH_DATA) * sizeof(uint2));
-            if (r == hipSuccess)
-                r = hipMemset2DAsync(d.bnd.p, (d.bnd_stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream);
-            if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: spill scratch: %s", d.id, hipGetErrorString(r)); }
-        }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
         // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
         // copy of a process takes ~10 ms, later ones run at ~20 GB/s) and the first launch of every kernel.
@@ -656,8 +710,8 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
     return 0;
 }
 
-int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
-                            uint32_t ngroups, uint32_t W, int *chunk)
+static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
+                             uint32_t ngroups, uint32_t W, int *chunk, bool async)
 {
     if (int r = check_dev(ctx, dev)) return r;
     if (!chunk) return fail(OSWALD_HIP_EINVAL, "chunk out-pointer is null");
@@ -669,7 +723,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     Device &d = ctx->dev[dev];
     HIP_TRY(hipSetDevice(d.id));
     int slot = -1;
-    for (size_t i = 0; i < d.chunks.size(); ++i) if (!d.chunks[i].live) { slot = (int)i; break; }
+    for (size_t i = 0; i < d.chunks.size(); ++i) if (!d.chunks[i].live && !d.chunks[i].upload_pending) { slot = (int)i; break; }
     if (slot < 0) { d.chunks.emplace_back(); slot = (int)d.chunks.size() - 1; }
     Chunk &c = d.chunks[slot];
     PhaseTimer pt;
@@ -696,6 +750,7 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
         off += (uint64_t)nc4 + OSW_TILED_PAD_GROUPS; // + the all-dummy groups the kernels prefetch / drain through
     }
     c.total_col4 = off;
+    if (int r = ensure_scratch(d, c.max_ncols4 * 4)) return r;
     HIP_TRY(c.tiled.reserve((off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2)));
     HIP_TRY(c.blocks.reserve(c.nblocks * sizeof(OswBlock) + 16));
     HIP_TRY(c.sub_cols_buf.reserve((size_t)c.nblocks * 128 * sizeof(uint16_t) + 16));
@@ -715,12 +770,41 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
     if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("upload: H2D + re-tile"); }
     c.sub_cols.assign((size_t)c.nblocks * 128, 0);
     if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols.data(), c.sub_cols_dev(), c.sub_cols.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, d.stream));
-    HIP_TRY(hipStreamSynchronize(d.stream)); // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
-    pt.lap("upload: sync");
     c.items_version = ~0ull;
     c.searched = false;
     c.live = true;
+    c.upload_pending = true;
     *chunk = slot;
+    if (!async) {
+        if (int r = finish_upload(d, c)) return r; // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
+        pt.lap("upload: sync");
+    }
+    return 0;
+}
+
+int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
+                            uint32_t ngroups, uint32_t W, int *chunk)
+{
+    return chunk_upload_impl(ctx, dev, b, vD, n, disp, ngroups, W, chunk, false);
+}
+
+int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
+                                  uint32_t ngroups, uint32_t W, int *chunk)
+{
+    return chunk_upload_impl(ctx, dev, b, vD, n, disp, ngroups, W, chunk, true);
+}
+
+int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length)
+{
+    if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
+    if (dev >= (int)ctx->dev.size()) return fail(OSWALD_HIP_ENODEV, "device index %d out of range", dev);
+    for (int i = 0; i < (int)ctx->dev.size(); ++i) {
+        if (dev >= 0 && i != dev) continue;
+        Device &d = ctx->dev[i];
+        HIP_TRY(hipSetDevice(d.id));
+        if (int r = ensure_scratch(d, max_sequence_length + 28)) return r; // + the padding of the group lengths
+        HIP_TRY(hipStreamSynchronize(d.stream));
+    }
     return 0;
 }
 
@@ -732,6 +816,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
     PhaseTimer pt;
+    if (int r = finish_upload(d, c)) return r; // the planner reads the chunk's live extents
     if (int r = sync_queries(ctx, d)) return r;
     pt.lap("search: queries + profiles");
     if (int r = build_items(ctx, d, c)) return r;
@@ -890,6 +975,7 @@ int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
     if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
     HIP_TRY(hipSetDevice(d.id));
     HIP_TRY(hipStreamSynchronize(d.stream));
+    d.chunks[chunk].upload_pending = false;
     d.chunks[chunk].live = false; // buffers are kept for the next upload into this slot
     return 0;
 }
@@ -974,6 +1060,7 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
     HIP_TRY(hipStreamSynchronize(d.stream));
+    c.upload_pending = false;
     std::vector<OswBlock> blocks(c.nblocks);
     if (c.nblocks) HIP_TRY(hipMemcpy(blocks.data(), c.blocks.p, c.nblocks * sizeof(OswBlock), hipMemcpyDeviceToHost));
     uint64_t alloc = 0, live = 0;
@@ -982,7 +1069,7 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
     out6[1] = alloc;
     out6[2] = live;
     out6[3] = live * 64 * sizeof(uint2);
-    out6[4] = c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg;
+    out6[4] = c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg; // wave-level work items (a phase-1 entry is four)
     out6[5] = c.max_lg;
     return 0;
 }

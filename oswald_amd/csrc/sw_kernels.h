@@ -11,11 +11,12 @@
 #define OSW_RMAX32 16        // query rows per strip, int32 kernel
 #define OSW_LDS_ROWS16 128   // profile rows a wave keeps in LDS per round (8 KB), packed int16 kernel
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
+#define OSW_LDS_SKEW8 128    // extra 8-byte units per wave region: group g's slice sits g entries (<= 16 B) further on, G <= 64
 #define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
 #define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64), kept zero
-#define OSW_SCRATCH_ENTRIES ((4096u + OSW_SCRATCH_PAD_COLS) * 32u) // a wave's spill columns ({H,F} entries, 1.07 MB): a 4096-column
-                                                                   // block at 32 lanes per group (G = 2); longer blocks, or G = 1 beyond
-                                                                   // 2012 columns, run at a geometry with fewer lanes per group
+// (a wave's spill region holds (columns + OSW_SCRATCH_PAD_COLS) x 32 {H,F} entries, sized from the longest sequence by
+// oswald_hip.cpp::ensure_scratch: the boundary row of the longest block at two lane groups; longer blocks, or G = 1
+// beyond half of it, run at a geometry with fewer lanes per group)
 // A wave's spill region: 64 reserved entries, 64 entries that absorb the stores of steps / rounds that
 // have nothing to spill, then the columns.  (The "row above" of a first round comes from top_pages.)
 #define OSW_SCRATCH_ZERO 0
@@ -35,6 +36,8 @@
 #define OSW_ITEM_LG(x) (((x) >> 24) & 0xfu)
 #define OSW_ITEM_HALVES(x) (((x) >> 28) & 3u)
 #define OSW_ITEM_PRIO(x) (((x) >> 30) & 3u)
+#define OSW_ITEM_WG_FLAG 0x80000000u  // in y of a phase-1 slot: workgroup item (shared profile slice, waves in step)
+#define OSW_ITEM_NONE 0x7fffffffu     // y of an empty slot
 
 // Strip plan of a query of m rows at geometry G: every lane group owns
 // T = ceil4(ceil4(m) / G) rows, cut into `rounds` strips whose heights are
@@ -96,7 +99,9 @@ struct OswSearchArgs {
     const uint16_t *tiled;     // [col][64 lanes] {8*residue of seq 2l, 8*residue of seq 2l+1}
     const OswBlock *blocks;
     const uint16_t *sub_cols;  // [block][128]: live columns of sub-block sigma at geometry G, at (G-1) + sigma
-    const uint2 *items;        // work queue, heaviest first: nitems_wg workgroup items, then nitems wave items
+    const uint2 *items;        // work queues, heaviest first: nitems_wg phase-1 entries of four slots (one per wave of the
+                               // workgroup: the four sub-blocks of a workgroup item, or a quad of independent heavy
+                               // wave items), then nitems wave items
     uint32_t nitems;
     uint32_t nitems_wg;
     uint32_t two_ended_waves;  // wave items: eat the queue from both ends (see osw_sw_pk16) or heaviest-first only

@@ -338,6 +338,7 @@ struct CellSeqPair {
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16;
     static constexpr int kRowBytes = 64; // profile bytes per query row: 32 codes x int16
+    typedef uint2 Entry;                 // one code, 4 rows
     static __device__ __forceinline__ T zero() { return as_v2s(A::kFloor); } // the value that stands for 0
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
@@ -450,6 +451,7 @@ struct CellQueryPair {
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
     static constexpr int kRowBytes = 128; // 32 codes x 2 queries x int16
+    typedef uint4 Entry;                  // one code, 4 rows x 2 queries
     static __device__ __forceinline__ T zero() { return as_v2s(A::kFloor); } // the value that stands for 0
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
@@ -528,6 +530,7 @@ struct CellI32 {
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
     static constexpr int kRowBytes = 64;
+    typedef uint2 Entry;
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
@@ -788,41 +791,45 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
 #undef OSW_ROUND_CASE
 }
 
-// Copy the round's profile slice (nrb row-blocks of 256 B from row-block rb0;
-// row-blocks at or past rb_end are beyond the query and read as zero scores)
-// into the wave's LDS region.  Only this wave touches the region; LDS
-// operations of one wave execute in order, the wave barriers only pin the
-// compiler's order.
-static __device__ __forceinline__ void load_profile_round(const uint4 *prof_q, uint32_t rb0, uint32_t nrb, uint32_t rb_end,
-                                                          uint32_t rb16 /* uint4 per row-block */, uint2 *lds_wave, int lane)
+// Copy the round's profile slice into LDS: G lane groups x rbg row-blocks (4 rows x 32 codes) each, taken
+// from row-block rb0 of the query's profile on (row-blocks at or past rb_end are beyond the query and read as
+// zero scores).  Group g's part starts g ENTRIES later than a dense layout would put it (one entry = the
+// scores of one residue code for 4 rows: 8 B, 16 B for query pairs): lanes of different groups that look up
+// the same code -- all lanes past the end of their sequence read the dummy code -- would otherwise hit the same
+// LDS banks at different addresses (a G-way conflict); shifted by one entry per group they hit neighbouring
+// banks.  E = uint2 / uint4 (the entry); tid / nthr: the threads that copy (a wave, or the whole workgroup).
+template <class E>
+static __device__ __forceinline__ void fill_profile_slice(const E *prof_q, uint32_t rb0, uint32_t rbg, uint32_t G, uint32_t rb_end, E *dst,
+                                                          uint32_t tid, uint32_t nthr)
 {
-    __builtin_amdgcn_wave_barrier();
-    const uint4 *src = prof_q + (size_t)rb0 * rb16;
-    uint4 *dst = (uint4 *)lds_wave;
-    const uint32_t n16 = nrb * rb16;
-    const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * rb16 : 0;
-    for (uint32_t i = lane; i < n16; i += 64) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    const uint32_t per_group = rbg * 32u; // entries
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t rbs = rb0 + g * rbg; // first row-block of the group
+        const uint32_t valid = rb_end > rbs ? ((rb_end - rbs) < rbg ? (rb_end - rbs) : rbg) * 32u : 0u;
+        const E *src = prof_q + (size_t)rbs * 32u;
+        E *d = dst + (size_t)g * (per_group + 1u);
+        for (uint32_t e = tid; e < per_group; e += nthr) d[e] = e < valid ? src[e] : E{};
+    }
 }
 
 // One work item: all rounds of (query q, block B, sub-block sigma) at geometry G.
 // Returns the lane's best score (valid in the lanes of group 0 after the
 // cross-group reduction).
-//   WG = false: the wave works alone; its profile slice lives in its private
+//   wg = false: the wave works alone; its profile slice lives in its private
 //               LDS region (kLdsRows rows).
-//   WG = true : the four waves of the workgroup run four sub-blocks of the same
+//   wg = true : the four waves of the workgroup run four sub-blocks of the same
 //               (query, block, G) item in step; they share ONE profile slice in
 //               the workgroup's whole LDS (4 x kLdsRows rows), which allows
 //               4x taller rounds for heavy items.  The only synchronisation
 //               is a pair of workgroup barriers around the slice reload.
-template <class C, bool WG>
+// (wg is a run-time, workgroup-uniform flag: both kinds run the same round code.)
+template <class C>
 static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, const uint2 *prof, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
-                                                         uint32_t lg, int lane, int half, uint2 *lds_region, uint2 *bnd_wave,
+                                                         uint32_t lg, int lane, int half, bool wg, uint2 *lds_region, uint2 *bnd_wave,
                                                          typename C::GapT goe, typename C::GapT ge)
 {
     typedef typename C::T T;
-    constexpr uint32_t kLds = WG ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
+    const uint32_t kLds = wg ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
     const uint32_t G = 1u << lg, gl = 64u >> lg;
     const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
     // the item's extent: the longest sequence of its sub-block
@@ -830,8 +837,8 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
     uint2 *bnd = (uint2 *)osw_uniform64((uint64_t)bnd_wave);
     const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
-    constexpr uint32_t rb16 = C::kRowBytes * 4 / 16; // uint4 per row-block of 4 rows
-    const uint4 *prof_q = (const uint4 *)prof + (size_t)p.prof_off[q] * rb16;
+    typedef typename C::Entry Entry; // the profile scores of one residue code for 4 rows
+    const Entry *prof_q = (const Entry *)prof + (size_t)p.prof_off[q] * 32u;
     if (plan.rounds > 1) {
         // the scratch columns the prefetch and the drain steps read past the block's last one are the
         // row above of dummy columns: "zero" in the cell's representation (other items have written here)
@@ -846,21 +853,22 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     if constexpr (C::kShifted) score = C::from_bits(0u); // the column-frame cell keeps a true (unbiased) running score
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
-        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, nrb = G * R / 4, rb_end = plan.m4 / 4;
-        if constexpr (WG) {
+        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
+        if (wg) {
             __syncthreads(); // every wave is done with the previous slice
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
-            const uint4 *src = prof_q + (size_t)rb0 * rb16;
-            uint4 *dst = (uint4 *)lds_region;
-            const uint32_t n16 = nrb * rb16;
-            const uint32_t v16 = rb_end > rb0 ? ((rb_end - rb0) < nrb ? (rb_end - rb0) : nrb) * rb16 : 0;
-            for (uint32_t i = tid; i < n16; i += OSW_WG_THREADS) dst[i] = i < v16 ? src[i] : make_uint4(0, 0, 0, 0);
+            fill_profile_slice<Entry>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
             __syncthreads();
         } else {
-            load_profile_round(prof_q, rb0, nrb, rb_end, rb16, lds_region, lane);
+            // only this wave touches its region; LDS operations of one wave execute in order, the wave barriers
+            // only pin the compiler's order
+            __builtin_amdgcn_wave_barrier();
+            fill_profile_slice<Entry>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * R * C::kRowBytes);
+        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
         sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, p.top_pages, rho == 0 || p.debug_nospill, rho + 1 == plan.rounds || p.debug_nospill, G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
@@ -951,7 +959,7 @@ static __device__ __forceinline__ bool osw_frame_cell_takes(uint32_t cols, uint3
 template <class C, class CF, bool PAIR>
 static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 {
-    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8];
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8 + OSW_LDS_SKEW8]; // + one entry per lane group (fill_profile_slice)
     __shared__ uint32_t wg_item;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -976,61 +984,54 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     const bool heavy_end = wg_item == 0;
     __syncthreads();
 
-    // phase 1: heavy items, the workgroup's four waves on four sub-blocks of one item
+    // Phase 1: workgroup entries, heaviest first -- the workgroup's four waves on four sub-blocks of one item
+    // (shared profile slice, rounds in step), or on a quad of four independent heavy wave items.  Phase 2: every
+    // wave on its own, light wave items.  One loop, so that the (large, fully unrolled) round code exists once.
+    const uint2 *wave_items = p.items + (size_t)p.nitems_wg * 4;
+    bool phase1 = true;
     for (;;) {
-        if (threadIdx.x == 0) {
-            uint32_t t = atomicAdd(&p.counters[OSW_CTR_WORK_WG], 1u);
-            if (t < p.nitems_wg) t = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT_WG], 1u) : p.nitems_wg - 1 - atomicAdd(&p.counters[OSW_CTR_BACK_WG], 1u);
-            wg_item = t;
+        uint2 item;
+        bool shared = false;
+        if (phase1) {
+            if (threadIdx.x == 0) {
+                uint32_t t = atomicAdd(&p.counters[OSW_CTR_WORK_WG], 1u);
+                if (t < p.nitems_wg) t = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT_WG], 1u) : p.nitems_wg - 1 - atomicAdd(&p.counters[OSW_CTR_BACK_WG], 1u);
+                wg_item = t;
+            }
+            __syncthreads();
+            const uint32_t it = wg_item;
+            __syncthreads();
+            if (it >= p.nitems_wg) { // all four waves see this together
+                phase1 = false;
+                if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+                continue;
+            }
+            item = p.items[(size_t)it * 4 + wv];
+            shared = (item.y & OSW_ITEM_WG_FLAG) != 0; // the same for the four slots of an entry
+            if (!shared && item.y == OSW_ITEM_NONE) continue;
+        } else {
+            uint32_t it = 0;
+            if (lane == 0) {
+                it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
+                if (it < p.nitems && p.two_ended_waves) it = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT], 1u) : p.nitems - 1 - atomicAdd(&p.counters[OSW_CTR_BACK], 1u);
+            }
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= p.nitems) break;
+            item = wave_items[it];
         }
-        __syncthreads();
-        const uint32_t it = wg_item;
-        __syncthreads();
-        if (it >= p.nitems_wg) break;
-        const uint2 item = p.items[it];
-        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x) + wv, lg = OSW_ITEM_LG(item.x), B = item.y;
+        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y & ~OSW_ITEM_WG_FLAG;
         const OswBlock blk = p.blocks[B];
         set_wave_prio(OSW_ITEM_PRIO(item.x));
+        uint2 *lds_region = shared ? &lds_prof[0][0] : lds_prof[wv];
         // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest run on CF
         const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge, p.goe_pk & 0xffffu);
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             if (cf_only) {
-                const v2s score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_fb, p.ge_fb);
+                const v2s score = run_item<CF>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
             } else {
-                const v2s score = run_item<C, true>(p, p.prof, q, B, blk, sigma, lg, lane, half, &lds_prof[0][0], bnd_wave, p.goe_pk, p.ge_pk);
-                if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
-                else pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
-            }
-        }
-        set_wave_prio(0);
-    }
-
-    if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-
-    // phase 2: every wave on its own
-    const uint2 *items = p.items + p.nitems_wg;
-    for (;;) {
-        uint32_t it = 0;
-        if (lane == 0) {
-            it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
-            if (it < p.nitems && p.two_ended_waves) it = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT], 1u) : p.nitems - 1 - atomicAdd(&p.counters[OSW_CTR_BACK], 1u);
-        }
-        it = __builtin_amdgcn_readfirstlane(it);
-        if (it >= p.nitems) break;
-        const uint2 item = items[it];
-        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
-        const OswBlock blk = p.blocks[B];
-        set_wave_prio(OSW_ITEM_PRIO(item.x));
-        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge, p.goe_pk & 0xffffu);
-        for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
-            if (cf_only) {
-                const v2s score = run_item<CF, false>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_fb, p.ge_fb);
-                if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
-                else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
-            } else {
-                const v2s score = run_item<C, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_prof[wv], bnd_wave, p.goe_pk, p.ge_pk);
+                const v2s score = run_item<C>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
                 if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
             }
@@ -1058,7 +1059,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_s16q(OswS
 // ---------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearchArgs p)
 {
-    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS32 * 8];
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
@@ -1066,7 +1067,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
     uint2 *lds_wave = lds_prof[wv];
     // the queue length was produced by the previous kernel on this stream
     const uint32_t nitems = p.force_all ? p.nitems : p.counters_ovf[0];
-    const uint2 *items = p.force_all ? p.items + p.nitems_wg : p.ovf_items;
+    const uint2 *items = p.force_all ? p.items + (size_t)p.nitems_wg * 4 : p.ovf_items;
 
     for (;;) {
         uint32_t it = 0;
@@ -1080,7 +1081,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
         const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
-            const int score = run_item<CellI32, false>(p, p.prof, q, B, blk, sigma, lg, lane, half, lds_wave, bnd_wave, p.goe, p.ge);
+            const int score = run_item<CellI32>(p, p.prof, q, B, blk, sigma, lg, lane, half, false, lds_wave, bnd_wave, p.goe, p.ge);
             if ((uint32_t)lane < gl)
                 p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }

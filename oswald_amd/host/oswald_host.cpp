@@ -10,6 +10,11 @@
 #include <numeric>
 #include <stdexcept>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace oswald {
 
 #include "submat_tables.inc"
@@ -113,6 +118,7 @@ PreprocessStats preprocess_db(const std::string &input_filename, const std::stri
             f.write(buf.data(), (std::streamsize)buf.size());
         }
     }
+    write_group_cache(out_filename);
     return st;
 }
 
@@ -132,36 +138,67 @@ Queries load_query_sequences(const std::string &queries_filename)
     return q;
 }
 
-Database assemble_multiple_chunks_db(const std::string &sequences_filename, int W, uint64_t max_buffer_size, unsigned num_devices)
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t bytes = 0;
+    ~MappedFile() { if (p) munmap((void *)p, bytes); }
+    static std::shared_ptr<MappedFile> open(const std::string &path)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return nullptr;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return nullptr; }
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return nullptr;
+        (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+        auto r = std::make_shared<MappedFile>();
+        r->p = (const uint8_t *)m;
+        r->bytes = (size_t)st.st_size;
+        return r;
+    }
+};
+
+namespace {
+
+uint32_t crc32_of(const uint8_t *p, size_t n)
 {
-    Database db;
-    {
-        FILE *f = fopen((sequences_filename + ".info").c_str(), "r");
-        if (!f) throw std::runtime_error("OSWALD: An error occurred while opening info file.");
-        long a = 0, b = 0;
-        int c = 0;
-        if (fscanf(f, "%ld %ld %d", &a, &b, &c) != 3) { fclose(f); throw std::runtime_error("OSWALD: malformed info file."); }
-        fclose(f);
-        db.sequences_count = (uint64_t)a;
-        db.D = (uint64_t)b;
-        db.max_title_length = c;
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
     }
-    std::vector<uint16_t> len(db.sequences_count);
-    std::vector<uint8_t> s(db.D);
-    {
-        std::ifstream f(sequences_filename + ".seq", std::ios::binary);
-        if (!f) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
-        f.read((char *)len.data(), (std::streamsize)(len.size() * sizeof(uint16_t)));
-        f.read((char *)s.data(), (std::streamsize)s.size());
-        if (!f) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
-    }
-    if (db.sequences_count == 0) return db;
-    db.sequences_db_max_length = len.back();
-    const uint64_t N = db.sequences_count, G = (N + W - 1) / W;
-    db.vect_sequences_count = G;
-    std::vector<uint64_t> seq_off(N + 1, 0);
-    for (uint64_t i = 0; i < N; ++i) seq_off[i + 1] = seq_off[i] + len[i];
-    // group length = longest (= last) sequence of the group, rounded up to a multiple of 28
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+struct DbInfo { uint64_t count = 0, D = 0; int max_title_length = 0; };
+
+DbInfo read_info(const std::string &sequences_filename)
+{
+    FILE *f = fopen((sequences_filename + ".info").c_str(), "r");
+    if (!f) throw std::runtime_error("OSWALD: An error occurred while opening info file.");
+    long a = 0, b = 0;
+    int c = 0;
+    if (fscanf(f, "%ld %ld %d", &a, &b, &c) != 3) { fclose(f); throw std::runtime_error("OSWALD: malformed info file."); }
+    fclose(f);
+    DbInfo r;
+    r.count = (uint64_t)a;
+    r.D = (uint64_t)b;
+    r.max_title_length = c;
+    return r;
+}
+
+// padded group lengths: the longest (= last) sequence of the group, rounded up to a multiple of 28
+std::vector<uint16_t> group_lengths(const std::vector<uint16_t> &len, int W)
+{
+    const uint64_t N = len.size(), G = (N + W - 1) / W;
     std::vector<uint16_t> n(G);
     for (uint64_t g = 0; g < G; ++g) {
         const uint64_t last = std::min(N, (g + 1) * W) - 1;
@@ -170,9 +207,136 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
             throw std::runtime_error("OSWALD: database holds a sequence of " + std::to_string(l) + " residues (limit " + std::to_string(kMaxSequenceLength) + ")");
         n[g] = (uint16_t)((l + kFpgaBlockWidth - 1) / kFpgaBlockWidth * kFpgaBlockWidth);
     }
+    return n;
+}
+
+// groups [g0, g1) interleaved into dst (pre-filled with the dummy residue): dst[gdisp[g] - gdisp[g0] + col*W + lane]
+void interleave_groups(const std::vector<uint16_t> &len, const uint8_t *residues, const std::vector<uint64_t> &seq_off,
+                       const std::vector<uint64_t> &gdisp, int W, uint64_t g0, uint64_t g1, uint8_t *dst)
+{
+    const uint64_t N = len.size();
+#pragma omp parallel for schedule(dynamic, 64)
+    for (uint64_t g = g0; g < g1; ++g) {
+        uint8_t *d = dst + (gdisp[g] - gdisp[g0]);
+        for (int lane = 0; lane < W; ++lane) {
+            const uint64_t sidx = g * W + lane;
+            if (sidx >= N) break;
+            const uint8_t *src = residues + seq_off[sidx];
+            for (uint32_t col = 0; col < len[sidx]; ++col) d[(uint64_t)col * W + lane] = src[col];
+        }
+    }
+}
+
+size_t cache_payload_offset(uint64_t groups) { return (sizeof(GroupCacheHeader) + groups * sizeof(uint16_t) + 63) / 64 * 64; }
+
+} // namespace
+
+void write_group_cache(const std::string &sequences_filename)
+{
+    const int W = kFpgaVectorLength;
+    const DbInfo info = read_info(sequences_filename);
+    std::vector<uint16_t> len(info.count);
+    std::vector<uint8_t> s(info.D);
+    uint64_t seq_bytes = 0;
+    {
+        std::ifstream f(sequences_filename + ".seq", std::ios::binary);
+        if (!f) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
+        f.read((char *)len.data(), (std::streamsize)(len.size() * sizeof(uint16_t)));
+        f.read((char *)s.data(), (std::streamsize)s.size());
+        if (!f) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
+        seq_bytes = len.size() * sizeof(uint16_t) + s.size();
+    }
+    const std::vector<uint16_t> n = group_lengths(len, W);
+    const uint64_t N = info.count, G = n.size();
+    std::vector<uint64_t> seq_off(N + 1, 0), gdisp(G + 1, 0);
+    for (uint64_t i = 0; i < N; ++i) seq_off[i + 1] = seq_off[i] + len[i];
+    for (uint64_t g = 0; g < G; ++g) gdisp[g + 1] = gdisp[g] + (uint64_t)n[g] * W;
+    GroupCacheHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "OSWG16\0\0", 8);
+    h.version = 1;
+    h.vector_length = (uint32_t)W;
+    h.sequences_count = N;
+    h.D = info.D;
+    h.groups = G;
+    h.vD = gdisp[G];
+    h.seq_file_bytes = seq_bytes;
+    h.lengths_crc32 = crc32_of((const uint8_t *)len.data(), len.size() * sizeof(uint16_t));
+    const std::string tmp = sequences_filename + ".g16.tmp";
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) throw std::runtime_error("OSWALD: An error occurred while opening the group cache file.");
+        f.write((const char *)&h, sizeof h);
+        f.write((const char *)n.data(), (std::streamsize)(n.size() * sizeof(uint16_t)));
+        const std::vector<char> zeros(64, 0);
+        f.write(zeros.data(), (std::streamsize)(cache_payload_offset(G) - sizeof h - n.size() * sizeof(uint16_t)));
+        // in slabs of groups, so that the padded copy never exists in memory as a whole
+        const uint64_t slab = 4096;
+        std::vector<uint8_t> buf;
+        for (uint64_t g0 = 0; g0 < G; g0 += slab) {
+            const uint64_t g1 = std::min(G, g0 + slab);
+            buf.assign(gdisp[g1] - gdisp[g0], (uint8_t)kDummy);
+            interleave_groups(len, s.data(), seq_off, gdisp, W, g0, g1, buf.data());
+            f.write((const char *)buf.data(), (std::streamsize)buf.size());
+        }
+        if (!f) throw std::runtime_error("OSWALD: An error occurred while writing the group cache file.");
+    }
+    if (rename(tmp.c_str(), (sequences_filename + ".g16").c_str()) != 0)
+        throw std::runtime_error("OSWALD: An error occurred while renaming the group cache file.");
+}
+
+Database assemble_multiple_chunks_db(const std::string &sequences_filename, int W, uint64_t max_buffer_size, unsigned num_devices)
+{
+    Database db;
+    const DbInfo info = read_info(sequences_filename);
+    db.sequences_count = info.count;
+    db.D = info.D;
+    db.max_title_length = info.max_title_length;
+    std::vector<uint16_t> len(db.sequences_count);
+    std::ifstream fseq(sequences_filename + ".seq", std::ios::binary);
+    if (!fseq) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
+    fseq.read((char *)len.data(), (std::streamsize)(len.size() * sizeof(uint16_t)));
+    if (!fseq) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
+    if (db.sequences_count == 0) return db;
+    db.sequences_db_max_length = len.back();
+    const uint64_t N = db.sequences_count, G = (N + W - 1) / W;
+    db.vect_sequences_count = G;
+    const std::vector<uint16_t> n = group_lengths(len, W);
     std::vector<uint64_t> gdisp(G + 1, 0);
     for (uint64_t g = 0; g < G; ++g) gdisp[g + 1] = gdisp[g] + (uint64_t)n[g] * W;
     db.vD = gdisp[G];
+
+    // the group cache, if it belongs to this database (OSWALD_NO_GROUP_CACHE=1: ignore it)
+    const uint8_t *cached_b = nullptr;
+    if (W == kFpgaVectorLength && !getenv("OSWALD_NO_GROUP_CACHE")) {
+        std::shared_ptr<MappedFile> mf = MappedFile::open(sequences_filename + ".g16");
+        if (mf && mf->bytes >= sizeof(GroupCacheHeader)) {
+            GroupCacheHeader h;
+            memcpy(&h, mf->p, sizeof h);
+            struct stat st;
+            const bool seq_ok = stat((sequences_filename + ".seq").c_str(), &st) == 0 && (uint64_t)st.st_size == h.seq_file_bytes;
+            const bool ok = !memcmp(h.magic, "OSWG16\0\0", 8) && h.version == 1 && h.vector_length == (uint32_t)W && h.sequences_count == N &&
+                            h.D == db.D && h.groups == G && h.vD == db.vD && seq_ok && mf->bytes == cache_payload_offset(G) + db.vD &&
+                            h.lengths_crc32 == crc32_of((const uint8_t *)len.data(), len.size() * sizeof(uint16_t)) &&
+                            !memcmp(mf->p + sizeof h, n.data(), n.size() * sizeof(uint16_t));
+            if (ok) {
+                db.cache = mf;
+                cached_b = mf->p + cache_payload_offset(G);
+            } else {
+                fprintf(stderr, "OSWALD: %s.g16 does not match the database; interleaving from %s.seq (re-run -O preprocess to refresh it).\n",
+                        sequences_filename.c_str(), sequences_filename.c_str());
+            }
+        }
+    }
+    std::vector<uint8_t> s;
+    std::vector<uint64_t> seq_off;
+    if (!cached_b) {
+        s.resize(db.D);
+        fseq.read((char *)s.data(), (std::streamsize)s.size());
+        if (!fseq) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
+        seq_off.assign(N + 1, 0);
+        for (uint64_t i = 0; i < N; ++i) seq_off[i + 1] = seq_off[i] + len[i];
+    }
     // chunk plan: a single device fills chunks up to max_buffer_size; several devices aim at
     // ceil(vD/ndev) (divided again by ndev until it fits) and close a chunk just after passing it
     uint64_t buffer_size = max_buffer_size;
@@ -201,20 +365,17 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
             c.disp[k] = (uint32_t)(gdisp[start + k] - gdisp[start]);
         }
         const uint64_t bytes = gdisp[start + j] - gdisp[start];
-        c.b.assign(bytes, (uint8_t)kDummy);
-        for (uint64_t k = 0; k < j; ++k) {
-            const uint64_t g = start + k;
-            uint8_t *dst = c.b.data() + c.disp[k];
-            for (int lane = 0; lane < W; ++lane) {
-                const uint64_t sidx = g * W + lane;
-                if (sidx >= N) break;
-                const uint8_t *src = s.data() + seq_off[sidx];
-                for (uint32_t col = 0; col < len[sidx]; ++col) dst[(uint64_t)col * W + lane] = src[col];
-            }
+        c.b_size = bytes;
+        if (cached_b) {
+            c.b = cached_b + gdisp[start];
+        } else {
+            c.owned.assign(bytes, (uint8_t)kDummy);
+            interleave_groups(len, s.data(), seq_off, gdisp, W, start, start + j, c.owned.data());
         }
         db.max_chunk_vD = std::max(db.max_chunk_vD, bytes);
         db.chunks.push_back(std::move(c));
     }
+    for (Chunk &c : db.chunks) if (!cached_b) c.b = c.owned.data(); // (after the moves: the vectors' buffers are stable now)
     return db;
 }
 
@@ -228,6 +389,34 @@ std::vector<std::string> load_database_headers(const std::string &sequences_file
     while (h.size() < sequences_count && std::getline(f, line)) h.push_back(line);
     h.resize(sequences_count);
     return h;
+}
+
+std::vector<std::string> load_database_headers_at(const std::string &sequences_filename, const std::vector<uint64_t> &indices)
+{
+    std::shared_ptr<MappedFile> mf = MappedFile::open(sequences_filename + ".desc");
+    if (!mf) {
+        // an empty description file maps to nothing; a missing one is an error like in load_database_headers
+        std::ifstream f(sequences_filename + ".desc", std::ios::binary);
+        if (!f) throw std::runtime_error("OSWALD: An error occurred while opening sequence description file.");
+        return std::vector<std::string>(indices.size());
+    }
+    std::vector<size_t> by_line(indices.size());
+    std::iota(by_line.begin(), by_line.end(), 0);
+    std::sort(by_line.begin(), by_line.end(), [&](size_t x, size_t y) { return indices[x] < indices[y]; });
+    std::vector<std::string> out(indices.size());
+    const char *p = (const char *)mf->p, *end = p + mf->bytes;
+    uint64_t line = 0;
+    for (size_t k : by_line) {
+        while (line < indices[k] && p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            p = nl ? nl + 1 : end;
+            ++line;
+        }
+        if (p >= end) break;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        out[k].assign(p, nl ? nl : end);
+    }
+    return out;
 }
 
 void top_scores(const int32_t *scores, uint64_t n, uint64_t r, std::vector<int32_t> &out_scores, std::vector<uint64_t> &out_index)
@@ -288,8 +477,14 @@ int oswald_host_assemble(const char *dbname, int W, uint64_t max_chunk, unsigned
 }
 uint64_t oswald_host_chunk_groups(unsigned c) { return g_db.chunks[c].n.size(); }
 uint64_t oswald_host_chunk_accum(unsigned c) { return g_db.chunks[c].accum; }
-uint64_t oswald_host_chunk_vD(unsigned c) { return g_db.chunks[c].b.size(); }
-const uint8_t *oswald_host_chunk_b(unsigned c) { return g_db.chunks[c].b.data(); }
+uint64_t oswald_host_chunk_vD(unsigned c) { return g_db.chunks[c].b_size; }
+const uint8_t *oswald_host_chunk_b(unsigned c) { return g_db.chunks[c].b; }
+int oswald_host_db_from_cache(void) { return g_db.cache ? 1 : 0; }
+int oswald_host_write_group_cache(const char *dbname)
+{
+    try { oswald::write_group_cache(dbname); return 0; }
+    catch (const std::exception &e) { g_host_err = e.what(); return -1; }
+}
 const uint16_t *oswald_host_chunk_n(unsigned c) { return g_db.chunks[c].n.data(); }
 const uint16_t *oswald_host_chunk_nbb(unsigned c) { return g_db.chunks[c].nbb.data(); }
 const uint32_t *oswald_host_chunk_disp(unsigned c) { return g_db.chunks[c].disp.data(); }
@@ -301,6 +496,11 @@ int oswald_host_load_headers(const char *dbname, uint64_t count)
     catch (const std::exception &e) { g_host_err = e.what(); return -1; }
 }
 const char *oswald_host_header(uint64_t i) { return g_headers[i].c_str(); }
+int oswald_host_load_headers_at(const char *dbname, const uint64_t *indices, uint64_t count)
+{
+    try { g_headers = oswald::load_database_headers_at(dbname, std::vector<uint64_t>(indices, indices + count)); return 0; }
+    catch (const std::exception &e) { g_host_err = e.what(); return -1; }
+}
 
 void oswald_host_top_scores(const int32_t *scores, uint64_t n, uint64_t r, int32_t *out_scores, uint64_t *out_index)
 {

@@ -13,6 +13,7 @@
 #define OSWALD_HOST_H
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -41,8 +42,28 @@ std::vector<FastaRecord> read_fasta(const std::string &path);
 std::vector<size_t> length_order(const std::vector<FastaRecord> &recs);
 
 struct PreprocessStats { uint64_t sequences = 0, residues = 0; int max_title_length = 0; };
-// Writes <out>.desc, <out>.info, <out>.seq.
+// Writes <out>.desc, <out>.info, <out>.seq (the reference's three files, byte for byte) and, next to them,
+// <out>.g16: the group cache (see GroupCacheHeader) that lets `-O search` skip the interleave.
 PreprocessStats preprocess_db(const std::string &input_filename, const std::string &out_filename, int n_procs);
+
+// <db>.g16 -- the database already in the layout assemble_multiple_chunks_db() builds in memory: groups of
+// 16 length-sorted sequences interleaved column by column and padded with the dummy residue to the group
+// length (reference host/src/sequences.c:457-498).  The layout does not depend on the chunk plan (a chunk is a
+// run of whole groups), so a search maps the file and hands slices of it to the device, whatever -k / -f say.
+// <db>.seq stays the canonical database; the cache is used only if it matches it (count, D, size of the .seq
+// file, CRC-32 of its length table), else it is ignored and the groups are interleaved from <db>.seq.
+struct GroupCacheHeader {
+    char magic[8];          // "OSWG16\0\0"
+    uint32_t version;       // 1
+    uint32_t vector_length; // 16
+    uint64_t sequences_count, D, groups, vD;
+    uint64_t seq_file_bytes;
+    uint32_t lengths_crc32; // of the uint16 length table of <db>.seq
+    uint32_t reserved;
+};                          // followed by uint16 n[groups], zero padding to a multiple of 64 B, then uint8 b[vD]
+static_assert(sizeof(GroupCacheHeader) == 64, "on-disk header");
+// Writes <db>.g16 from <db>.info / <db>.seq (also usable on a database preprocessed by the reference).
+void write_group_cache(const std::string &sequences_filename);
 
 struct Queries {
     std::vector<uint8_t> a;           // all queries back to back, preprocessed codes
@@ -53,8 +74,12 @@ struct Queries {
 };
 Queries load_query_sequences(const std::string &queries_filename);
 
+struct MappedFile;                // read-only mapping of <db>.g16, shared by the chunks that point into it
+
 struct Chunk {
-    std::vector<uint8_t> b;       // interleaved groups, b[disp[g] + j*W + lane]
+    const uint8_t *b = nullptr;   // interleaved groups, b[disp[g] + j*W + lane]: points into `owned` or into the mapped cache
+    uint64_t b_size = 0;
+    std::vector<uint8_t> owned;
     std::vector<uint16_t> n;      // padded group lengths
     std::vector<uint16_t> nbb;    // n / 28 (kept for interface parity, unused by the GPU path)
     std::vector<uint32_t> disp;   // byte offset of each group in b
@@ -66,11 +91,15 @@ struct Database {
     uint16_t sequences_db_max_length = 0;
     int max_title_length = 0;
     std::vector<Chunk> chunks;
+    std::shared_ptr<MappedFile> cache; // set when the chunks point into <db>.g16
 };
 Database assemble_multiple_chunks_db(const std::string &sequences_filename, int vector_length, uint64_t max_buffer_size,
                                      unsigned num_devices);
 
 std::vector<std::string> load_database_headers(const std::string &sequences_filename, uint64_t sequences_count);
+// The titles of the given sequences only (any order, duplicates allowed): one pass over the mapped file instead of
+// one std::string per database sequence.  Lines the file does not have come back empty, like above.
+std::vector<std::string> load_database_headers_at(const std::string &sequences_filename, const std::vector<uint64_t> &indices);
 
 // The r best entries of scores[0..n) in the order the reference's sort_scores
 // leaves them: descending score, ties by descending index.

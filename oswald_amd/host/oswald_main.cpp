@@ -205,6 +205,7 @@ int do_search(Options &o)
     // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80)
     oswald_hip_ctx *ctx = nullptr;
     check(oswald_hip_init((int)o.num_devices, nullptr, &ctx), "device bring-up");
+    check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space"); // buffers sized before the clock starts, FPGAsearch.c:85-96
     lap("device bring-up");
     const double tick = dwalltime();
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
@@ -215,15 +216,21 @@ int do_search(Options &o)
     std::vector<uint32_t> ti_dev;
     for (size_t k = 0; k < db.chunks.size(); k += o.num_devices) {
         const size_t active = std::min<size_t>(o.num_devices, db.chunks.size() - k);
+        // uploads of the round's chunks are queued on all devices first (they overlap), then every device is
+        // given its search
+        if (device_top)
+            for (size_t d = 0; d < active; ++d) {
+                const oswald::Chunk &c = db.chunks[k + d];
+                check(oswald_hip_chunk_upload_async(ctx, (int)d, c.b, c.b_size, c.n.data(), c.disp.data(), (uint32_t)c.n.size(), (uint32_t)W,
+                                                    &handle[d]), "chunk upload");
+            }
         for (size_t d = 0; d < active; ++d) {
             const oswald::Chunk &c = db.chunks[k + d];
             if (device_top) {
-                check(oswald_hip_chunk_upload(ctx, (int)d, c.b.data(), c.b.size(), c.n.data(), c.disp.data(), (uint32_t)c.n.size(), (uint32_t)W,
-                                              &handle[d]), "chunk upload");
                 check(oswald_hip_chunk_search(ctx, (int)d, handle[d], nullptr), "chunk search");
             } else {
                 tmp[d].resize(nq * c.n.size() * W);
-                check(oswald_hip_search_chunk_async(ctx, (int)d, c.b.data(), c.b.size(), c.n.data(), c.disp.data(), (uint32_t)c.n.size(),
+                check(oswald_hip_search_chunk_async(ctx, (int)d, c.b, c.b_size, c.n.data(), c.disp.data(), (uint32_t)c.n.size(),
                                                     (uint32_t)W, tmp[d].data()), "chunk search");
             }
         }
@@ -251,11 +258,14 @@ int do_search(Options &o)
     oswald_hip_finalize(ctx);
     lap("device release");
 
-    const std::vector<std::string> headers = oswald::load_database_headers(o.db, db.sequences_count);
-    lap("load headers");
-    std::vector<int32_t> ts;
-    std::vector<uint64_t> ti;
+    // top lists of all queries first, then only the titles the report prints (the reference loads every title,
+    // sequences.c:1096-1127; a 1 M-sequence database has 1 M of them for 10 lines per query)
+    std::vector<std::vector<int32_t>> top_s(nq);
+    std::vector<std::vector<uint64_t>> top_i(nq);
+    std::vector<uint64_t> wanted;
     for (uint64_t i = 0; i < nq; ++i) {
+        std::vector<int32_t> &ts = top_s[i];
+        std::vector<uint64_t> &ti = top_i[i];
         if (device_top) {
             // merge of the chunks' lists: descending score, ties by descending database index
             auto &cd = cand[i];
@@ -269,16 +279,23 @@ int do_search(Options &o)
         } else {
             oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, ts, ti);
         }
+        wanted.insert(wanted.end(), ti.begin(), ti.end());
+    }
+    lap("top scores");
+    const std::vector<std::string> headers = oswald::load_database_headers_at(o.db, wanted);
+    lap("load headers");
+    size_t hpos = 0;
+    for (uint64_t i = 0; i < nq; ++i) {
         printf("\nQuery no.\t\t\t%d\n", (int)i + 1);
         printf("Query description: \t\t%s\n", q.titles[i].c_str() + 1);
         printf("Query length:\t\t\t%d residues\n", q.m[i]);
         printf("\nScore\tSequence description\n");
-        for (size_t j = 0; j < ts.size(); ++j) {
-            const std::string &h = headers[ti[j]];
-            printf("%d\t%s\n", ts[j], h.empty() ? "" : h.c_str() + 1);
+        for (size_t j = 0; j < top_s[i].size(); ++j) {
+            const std::string &h = headers[hpos++];
+            printf("%d\t%s\n", top_s[i][j], h.empty() ? "" : h.c_str() + 1);
         }
     }
-    lap("top scores + report");
+    lap("report");
     printf("\nSearch date:\t\t\t%s", ctime(&current_time));
     printf("Search time:\t\t\t%lf seconds\n", workTime);
     printf("Search speed:\t\t\t%.2lf GCUPS\n", (double)(q.Q * db.D) / (workTime * 1000000000));
@@ -289,7 +306,9 @@ int do_search(Options &o)
     printf("FPGA vector length:\t\t%d\n", oswald::kFpgaVectorLength);
     printf("FPGA block width:\t\t%d\n", oswald::kFpgaBlockWidth);
     printf("Max. chunk size in FPGA:\t%ld bytes\n", (long)o.max_chunk_size);
-    printf("Accelerator:\t\t\t%u x AMD Instinct GPU via HIP (the \"FPGA\" lines above describe the input layout)\n", o.num_devices);
+    // (not part of the reference's report, FPGAsearch.c:327-331: only on request)
+    if (getenv("OSWALD_REPORT_ACCELERATOR"))
+        printf("Accelerator:\t\t\t%u x AMD Instinct GPU via HIP (the \"FPGA\" lines above describe the input layout)\n", o.num_devices);
     return 0;
 }
 

@@ -73,6 +73,24 @@ def assemble(dbname, W=16, max_chunk=134217728, ndev=1):
     return r
 
 
+def from_cache():
+    """Did the last assemble() take its chunks from <db>.g16?"""
+    return bool(load().oswald_host_db_from_cache())
+
+
+def write_group_cache(dbname):
+    if load().oswald_host_write_group_cache(dbname.encode()):
+        raise RuntimeError(load().oswald_host_last_error().decode())
+
+
+def headers_at(dbname, indices):
+    lib = load()
+    ix = np.ascontiguousarray(indices, np.uint64)
+    if lib.oswald_host_load_headers_at(dbname.encode(), ix.ctypes.data_as(C.c_void_p), C.c_uint64(ix.size)):
+        raise RuntimeError(lib.oswald_host_last_error().decode())
+    return [lib.oswald_host_header(i) for i in range(ix.size)]
+
+
 def headers(dbname, count):
     lib = load()
     if lib.oswald_host_load_headers(dbname.encode(), C.c_uint64(count)):

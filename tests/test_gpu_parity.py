@@ -407,6 +407,48 @@ def test_two_devices_in_one_context(oracle):
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), want)
 
 
+def test_async_uploads_and_reserved_work_space(oracle):
+    """oswald_hip_chunk_upload_async on two context devices (uploads queued on both before either search), work
+    space reserved up front for the longest sequence and grown when a later chunk holds a longer one."""
+    from oswald_amd import capi
+    qs = synth.make_queries([700, 64, 1500], seed=91)
+    L, R, O = random_db(600, seed=92, max_len=500, queries=qs[:2], homologs=2)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
+    plan = dblayout.chunk_plan(nfull, 16, 60000, 2)
+    assert len(plan) >= 4
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = expect(oracle, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
+    with capi.Context(2, [0, 0]) as ctx:
+        ctx.reserve(500)
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        parts = [None] * len(plan)
+        for k in range(0, len(plan), 2):
+            live = []
+            for d in range(min(2, len(plan) - k)):
+                g0, g1 = plan[k + d]
+                b, n, disp = dblayout.interleave(sl, sr, so, 16, g_begin=g0, g_end=g1)
+                live.append((k + d, d, ctx.chunk_upload(b, n, disp.astype(np.uint32), 16, dev=d, wait=False), np.full((len(qs), len(n) * 16), -3, np.int32)))
+            for idx, d, h, out in live:
+                ctx.chunk_search(h, out, dev=d)
+            ctx.wait()
+            for idx, d, h, out in live:
+                parts[idx] = out
+                ctx.chunk_release(h, dev=d)
+        np.testing.assert_array_equal(np.concatenate(parts, axis=1), want)
+        # a chunk with a much longer sequence than reserved for: the work space grows (multi-round query: it is used)
+        long_seq = synth.random_residues(93, 0, 5000)
+        long_seq[2500:2500 + 700] = qs[0]
+        L2, R2, O2 = db_from_sequences([long_seq, synth.random_residues(94, 0, 4000)] + [synth.random_residues(95 + i, 0, 90) for i in range(20)])
+        b2, n2, d2, _, _ = layout(L2, R2, O2, 16)
+        out2 = np.zeros((len(qs), len(n2) * 16), np.int32)
+        ctx.search_chunk_async(b2, n2, d2, out2, 16, dev=0)
+        ctx.wait()
+        np.testing.assert_array_equal(out2, expect(oracle, qs, b2, n2, d2, 16, sm, 10, 2))
+
+
 def test_scores_around_the_int16_ceiling(hip_ctx, oracle):
     """The packed-int16 cell is exact below 30576 (its values carry a bias of 1024 and must stay below the fp16
     inf/NaN patterns, see ArithI16B); sequences at or above it are re-run in int32.  Self-alignments scoring just

@@ -122,6 +122,60 @@ def test_chunk_assembly_matches_reference(tmp_path):
             np.testing.assert_array_equal(pb, c["b"])
 
 
+def test_group_cache_equals_interleave(tmp_path, monkeypatch):
+    """<db>.g16: written by preprocess; a search that maps it gets exactly the chunks the
+    interleave from <db>.seq builds (the layout pinned against the reference above), for any -k / -f; a cache
+    that does not belong to the database is ignored."""
+    db, _ = _make_db(tmp_path, 1000, 7)
+    assert os.path.exists(db + ".g16")
+    for max_chunk, ndev in ((134217728, 1), (200000, 1), (134217728, 4), (120000, 3)):
+        monkeypatch.delenv("OSWALD_NO_GROUP_CACHE", raising=False)
+        cached = hostlib.assemble(db, 16, max_chunk, ndev)
+        assert hostlib.from_cache()
+        monkeypatch.setenv("OSWALD_NO_GROUP_CACHE", "1")
+        plain = hostlib.assemble(db, 16, max_chunk, ndev)
+        assert not hostlib.from_cache()
+        assert cached["chunk_count"] == plain["chunk_count"] and cached["vD"] == plain["vD"]
+        for a, b in zip(cached["chunks"], plain["chunks"]):
+            assert a["accum"] == b["accum"]
+            for k in ("n", "nbb", "disp", "b"):
+                np.testing.assert_array_equal(a[k], b[k])
+    monkeypatch.delenv("OSWALD_NO_GROUP_CACHE", raising=False)
+    # a cache left over from another database: same name, other content
+    (tmp_path / "other").mkdir()
+    db2, _ = _make_db(tmp_path / "other", 1000, 8)
+    os.replace(db2 + ".g16", db + ".g16")
+    stale = hostlib.assemble(db, 16, 134217728, 1)
+    assert not hostlib.from_cache()
+    np.testing.assert_array_equal(stale["chunks"][0]["b"], plain_first(db))
+    # rebuilt from the .seq / .info pair alone (e.g. a database preprocessed by the reference)
+    hostlib.write_group_cache(db)
+    again = hostlib.assemble(db, 16, 134217728, 1)
+    assert hostlib.from_cache()
+    np.testing.assert_array_equal(again["chunks"][0]["b"], stale["chunks"][0]["b"])
+    # truncated cache file
+    with open(db + ".g16", "r+b") as f:
+        f.truncate(os.path.getsize(db + ".g16") - 5)
+    hostlib.assemble(db, 16, 134217728, 1)
+    assert not hostlib.from_cache()
+
+
+def plain_first(db):
+    os.environ["OSWALD_NO_GROUP_CACHE"] = "1"
+    try:
+        return hostlib.assemble(db, 16, 134217728, 1)["chunks"][0]["b"]
+    finally:
+        del os.environ["OSWALD_NO_GROUP_CACHE"]
+
+
+def test_headers_at_equals_full_load(tmp_path):
+    db, _ = _make_db(tmp_path, 300, 11)
+    full = hostlib.headers(db, 300)
+    idx = [299, 0, 17, 17, 150, 298, 1]
+    assert hostlib.headers_at(db, idx) == [full[i] for i in idx]
+    assert hostlib.headers_at(db, [5000, 3]) == [b"", full[3]]     # past the end of the file: empty, like the full load
+
+
 def test_headers_roundtrip(tmp_path):
     meta = json.load(open(os.path.join(GOLD, "layout.json")))
     db, _ = _make_db(tmp_path, 17, meta["n17/k128M_f1"]["seed"])
