@@ -53,9 +53,10 @@ SIMD_PER_CU = 4
 PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (profiles/r02_oprate_valu_issue.txt: 4.25)
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
-PK_OPS_PER_ROW = {16: (7.5, 6.5), 32: (24.0, 24.0)}
-DTYPE = {16: "int16", 32: "int32"}
-CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells"}
+PK_OPS_PER_ROW = {16: (7.5, 6.5), 32: (24.0, 24.0), 8: (26.5, 26.5)}  # 8: ~53 SWAR instructions per 2 x 2 tile row = 256 cells
+DTYPE = {16: "int16", 32: "int32", 8: "int8"}
+CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells",
+              8: "int8 cells (four 7-bit SWAR cells per register) with int16 re-run of what leaves their range, int32 above"}
 KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/oswald_hip.cpp")
 
 
@@ -69,8 +70,9 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--max-chunk", type=int, default=134217728, help="chunk size limit in bytes (the reference's -k, default 128 MiB)")
-    ap.add_argument("--cell-bits", type=int, default=16, choices=[16, 32],
-                    help="cell arithmetic: 16 = packed int16 (the cells BASELINE.json names; the library's default), 32 = int32 only")
+    ap.add_argument("--cell-bits", type=int, default=16, choices=[8, 16, 32],
+                    help="cell arithmetic: 16 = packed int16 (the cells BASELINE.json configs[1] names; the library's default), 32 = int32 only, "
+                         "8 = SWAR 8-bit first pass with int16 re-run (configs[2])")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
     ap.add_argument("--write-top-golden", action="store_true", help="N = 1 only: write tests/golden/bench_top_<workload>_<nseq>.json")
@@ -216,7 +218,7 @@ def main():
         kern_gcups = sum_m * d_local * args.steps / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
         ops_row = PK_OPS_PER_ROW[cell_bits][1 if nq > 1 else 0]  # a multi-query search runs (mostly) as query pairs
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / ops_row / 1e9
-        kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32"}[cell_bits]
+        kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
         traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None)
         cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1"}[args.workload]
         shard_note = (f"one database sharded over {world} GPUs by the reference's chunk rule (chunk c -> GPU c mod {world}), "
@@ -240,7 +242,7 @@ def main():
             # the north star's ">= 0.5 x HBM roofline" is only well posed under the reference's own traffic
             # model, 1 B of substitution score per cell streamed from device DRAM (sw.cl:57): 8 TB/s = 8000 GCUPS
             "reference_traffic_model": {"bytes_per_cell": 1.0, "roofline_gcups": HBM_PEAK_GBS, "frac": round(gcups / world / HBM_PEAK_GBS, 4)},
-            "rerun_items_int32": int(rerun), "work_items": int(sum(ctx.chunk_geometry(c["h"])["work_items"] for c in chunks)),
+            "rerun_items_int32": int(rerun), "rerun_items_int16": int(ctx.rerun_counts()[0]), "work_items": int(sum(ctx.chunk_geometry(c["h"])["work_items"] for c in chunks)),
             "max_log2_geometry": int(max([ctx.chunk_geometry(c["h"])["max_log2_geometry"] for c in chunks] or [0])),
             "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
             "setup_s": round(t_gen, 1),

@@ -74,11 +74,16 @@ int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen);
  * (host/src/submat.c); open_gap / extend_gap as on the command line (a gap of
  * length L costs open + L*extend).  Replaces the static kernel arguments 3 and
  * 4 of FPGAsearch.c:101-109 and the score-profile build of :143-177 (done on
- * the device here).  cell_bits selects the cell arithmetic: 16 (packed int16,
- * the default; also selected by 0: exact below 22256) or 32 (plain int32).
- * Results are exact in both modes: a sequence whose score reaches the ceiling
- * of the int16 cell is re-run in int32 on the device (the reference escalates
- * int8 -> int16 -> int32 on the host, HybridSearch.c:1670-1680,:1774-1784). */
+ * the device here).  cell_bits selects the cell arithmetic of the first pass:
+ * 16 (packed int16, the default; also selected by 0: exact below 22256), 32
+ * (plain int32) or 8 (four 7-bit cells per register, the reference's int8
+ * first pass sw.cl:60-78; slower than 16 on this GPU, which has no packed
+ * 8-bit maximum).  Results are exact in every mode: what leaves the range of
+ * the 8-bit cells is re-run in int16, what reaches the ceiling of the int16
+ * cells in int32, on the device (the reference escalates int8 -> int16 ->
+ * int32 on the host, HybridSearch.c:1670-1680,:1774-1784).  With cell_bits 8
+ * a matrix whose entries span more than 127, or a gap penalty above 127,
+ * makes the search run on the int16 cells alone. */
 int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_gap, int extend_gap, int cell_bits);
 
 /* Query set: residues of all queries back to back (codes 0..23), lengths m[],
@@ -143,6 +148,12 @@ int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nval
 int oswald_hip_set_profiling(oswald_hip_ctx *ctx, int enable);
 int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, uint64_t *dp_launches,
                             uint64_t *rerun_items, int reset);
+
+/* Escalations of the most recent search on `dev`: out[0] = work items the 8-bit
+ * pass queued for the int16 re-run, out[1] = sequences the int16 cells queued
+ * for the int32 re-run (the reference's two overflow tests,
+ * HybridSearch.c:1670-1680, :1774-1784). */
+int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2);
 
 /* Geometry of a resident chunk as the kernels see it (for roofline accounting):
  * out[0] = wave blocks, out[1] = stored 4-column groups, out[2] = 4-column

@@ -20,7 +20,7 @@ SYMBOLS = (
     "oswald_hip_abi_version", "oswald_hip_last_error", "oswald_hip_device_count", "oswald_hip_init", "oswald_hip_finalize",
     "oswald_hip_info", "oswald_hip_set_scoring", "oswald_hip_set_queries", "oswald_hip_chunk_upload", "oswald_hip_chunk_search",
     "oswald_hip_chunk_release", "oswald_hip_search_chunk_async", "oswald_hip_wait", "oswald_hip_chunk_topr",
-    "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry", "oswald_hip_chunk_upload_async", "oswald_hip_reserve",
+    "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry", "oswald_hip_chunk_upload_async", "oswald_hip_reserve", "oswald_hip_rerun_counts",
 )
 
 
@@ -52,6 +52,7 @@ def load():
     lib.oswald_hip_chunk_upload.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, C.POINTER(i32)]
     lib.oswald_hip_chunk_upload_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, C.POINTER(i32)]
     lib.oswald_hip_reserve.argtypes = [vp, i32, u32]
+    lib.oswald_hip_rerun_counts.argtypes = [vp, i32, C.POINTER(u64)]
     lib.oswald_hip_chunk_search.argtypes = [vp, i32, i32, vp]
     lib.oswald_hip_chunk_release.argtypes = [vp, i32, i32]
     lib.oswald_hip_search_chunk_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, vp]
@@ -176,6 +177,12 @@ class Context:
         ms, n, re = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         _chk(self.lib.oswald_hip_kernel_stats(self.h, dev, C.byref(ms), C.byref(n), C.byref(re), 1 if reset else 0))
         return ms.value, n.value, re.value
+
+    def rerun_counts(self, dev: int = 0):
+        """(items the 8-bit pass sent to the int16 re-run, sequences the int16 cells sent to the int32 re-run)."""
+        out = (C.c_uint64 * 2)()
+        _chk(self.lib.oswald_hip_rerun_counts(self.h, dev, out))
+        return int(out[0]), int(out[1])
 
     def chunk_geometry(self, chunk: int, dev: int = 0):
         out = (C.c_uint64 * 6)()

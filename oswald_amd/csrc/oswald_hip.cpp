@@ -82,7 +82,7 @@ struct Chunk {
     uint32_t score_stride = 0;   // nblocks*128
     uint32_t max_ncols4 = 0;     // largest stored extent of a block
     uint64_t total_col4 = 0;     // stored 4-column groups incl. the pad group per block
-    DevBuf tiled, blocks, sub_cols_buf, items, items_q, scores, ovf;
+    DevBuf tiled, blocks, sub_cols_buf, items, items_q, scores, ovf, ovf8;
     const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     std::vector<uint16_t> sub_cols;     // host copy of the live extents (see osw_block_extent), for the planner
@@ -105,7 +105,7 @@ struct Device {
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
-    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages;
+    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
     std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
@@ -145,6 +145,18 @@ namespace {
 // OSWALD_HIP_NO_FRAME=1 (test hook) runs the plain cell only
 bool first_pass_is_frame(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 16 && !getenv("OSWALD_HIP_NO_FRAME"); }
 
+// cell_bits 8: the SWAR 8-bit first pass (CellQ8) runs the query PAIRS; what leaves its 7-bit range is re-run by the
+// plain packed-int16 kernel, what reaches that one's ceiling by the int32 kernel.  It needs every profile entry
+// S + bias, with bias = -min S, and both gap penalties to be 7-bit values; otherwise the search runs on the int16
+// cells alone (the reference's int8 kernels wrap in that case, HybridSearch.c:1520).
+int bias8_of(const oswald_hip_ctx *ctx)
+{
+    int mn = 0, mx = 0;
+    for (int i = 0; i < 24 * 32; ++i) { mn = std::min<int>(mn, ctx->submat[i]); mx = std::max<int>(mx, ctx->submat[i]); }
+    return (mx - mn <= 127 && ctx->open_gap <= 127 && ctx->extend_gap <= 127) ? -mn : -1;
+}
+bool first_pass_is_q8(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 8 && bias8_of(ctx) >= 0; }
+
 // Pair up queries of similar length (sorted by length, neighbours): a pair costs 7.5 instructions per row of
 // the LONGER query for one sequence, two singles 8.5 per row for two sequences, so pairing pays when the
 // shorter one is longer than ~0.8 of the longer one.
@@ -159,6 +171,7 @@ void plan_pairs(oswald_hip_ctx *ctx)
     ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
     int mode = 1;
     if (const char *e = getenv("OSWALD_HIP_PAIRS")) mode = atoi(e);
+    if (first_pass_is_q8(ctx)) mode = 2; // the 8-bit cell works on query pairs only: pair every neighbour (a leftover query runs in int16)
     const double margin = getenv("OSWALD_HIP_PAIR_MARGIN") ? atof(getenv("OSWALD_HIP_PAIR_MARGIN")) : 1.03;
     std::vector<uint32_t> order(nq);
     for (uint32_t q = 0; q < nq; ++q) order[q] = q;
@@ -258,6 +271,12 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
         HIP_TRY(osw_launch_build_pair_profile((const uint2 *)(alt ? d.prof_alt.p : d.prof.p), (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                               (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
                                               ctx->pair_max_rowblocks, alt /* column-frame pair cell: 32-bit integer sums */, (uint4 *)d.prof_pair.p, d.stream));
+        if (first_pass_is_q8(ctx)) {
+            HIP_TRY(d.prof_pair8.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint2) + 4096));
+            HIP_TRY(osw_launch_build_pair_profile8((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
+                                                   (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
+                                                   ctx->pair_max_rowblocks, bias8_of(ctx), (uint2 *)d.prof_pair8.p, d.stream));
+        }
         if (alt) { // plain int16 pair profile for the items the first-pass cell hands to the plain cell
             HIP_TRY(d.prof_pair_i16.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096));
             HIP_TRY(osw_launch_build_pair_profile((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
@@ -282,13 +301,14 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
 // column step and round).  Heaviest first within each class.
 int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
 {
-    if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0;
-    const bool i32 = ctx->cell_bits == 32;
+    if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0; // (a change of scoring that changes the 8-bit eligibility bumps queries_version)
+    const bool i32 = ctx->cell_bits == 32, q8 = first_pass_is_q8(ctx);
     struct Kind { uint32_t rmax, ldsr; double row_cost, passes; };
     const Kind kinds[2] = {
         {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16,
          i32 ? 24.0 : first_pass_is_frame(ctx) ? 7.5 : 8.5, 1.0},
-        {OSW_RMAX16, OSW_LDS_ROWS16 / 2, first_pass_is_frame(ctx) ? 6.5 : 7.5, 2.0}};
+        q8 ? Kind{OSW_RMAX8, OSW_LDS_ROWS8, 50.0, 1.0} // SWAR 8-bit pairs: ~50 instructions per row of a 2 x 2 tile, one pass, wave items only
+           : Kind{OSW_RMAX16, OSW_LDS_ROWS16 / 2, first_pass_is_frame(ctx) ? 6.5 : 7.5, 2.0}};
     struct Entity { uint32_t m, id, kind; };
     std::vector<Entity> ents;
     if (i32) {
@@ -330,7 +350,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     for (uint32_t k = 0; k < ne; ++k) {
         const Kind &kd = kinds[ents[k].kind];
         lgmax[k] = lg_limit(ents[k], false, 8);
-        lgmax_wg[k] = i32 ? 0 : lg_limit(ents[k], true, 4);
+        lgmax_wg[k] = (i32 || (q8 && ents[k].kind == 1)) ? 0 : lg_limit(ents[k], true, 4);
         const uint32_t m4 = std::max(4u, (ents[k].m + 3u) & ~3u);
         // widest geometries that still run full-height strips (G * rmax rows fit the LDS slice)
         uint32_t full_wave = 0, full_wg = 0;
@@ -391,12 +411,12 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
                     if (ck < best_cost) { best_cost = ck; cwg = w; clg = g2; }
                 };
                 if (!wg) for (uint32_t g2 = lg + 1; g2 <= lgmax[k]; ++g2) consider(false, g2);
-                if (!i32) for (uint32_t g2 = std::max(2u, wg ? lg + 1 : 2u); g2 <= lgmax_wg[k]; ++g2) consider(true, g2);
+                if (!i32 && !(q8 && e.kind == 1)) for (uint32_t g2 = std::max(2u, wg ? lg + 1 : 2u); g2 <= lgmax_wg[k]; ++g2) consider(true, g2);
                 if (best_fit_work >= 0) { wg = fwg; lg = flg; } else { wg = cwg; lg = clg; }
             }
             if (force_lg >= 0) { lg = (uint32_t)force_lg; wg = false; }
             if (force_wg == 1) { wg = true; if (lg < 2) lg = 2; }
-            if (force_wg == 0) wg = false;
+            if (force_wg == 0 || (q8 && e.kind == 1)) wg = false; // (the 8-bit kernel has no workgroup phase)
             if (lg < lg_scratch) lg = lg_scratch;
             // hard limit of a geometry: G strips of (at least) 4 rows must fit the profile slice in LDS
             {
@@ -445,7 +465,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             ent.push_back(e);
         }
         size_t heavy = 0;
-        while (!i32 && heavy < its[kd].size() && its[kd][heavy].cost >= quad_frac * fair) ++heavy;
+        while (!i32 && !(q8 && kd == 1) && heavy < its[kd].size() && its[kd][heavy].cost >= quad_frac * fair) ++heavy;
         for (size_t k = 0; k < heavy; k += 4) {
             Entry e;
             e.cost = its[kd][k].cost;
@@ -490,6 +510,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     const size_t ovf_bytes = (size_t)ctx->nq * c.nblocks * 128 * sizeof(uint2) + 16;
     if (ovf_bytes > (64ull << 30)) return fail(OSWALD_HIP_EINVAL, "%u queries x %u sequence blocks in one chunk need a %zu-byte overflow queue; search in smaller chunks or query sets", ctx->nq, c.nblocks, ovf_bytes);
     HIP_TRY(c.ovf.reserve(ovf_bytes));
+    if (q8) HIP_TRY(c.ovf8.reserve(ovf_bytes)); // worst case: every lane of every pair item queues both of its queries
     HIP_TRY(c.scores.reserve((size_t)ctx->nq * c.score_stride * sizeof(int32_t) + 16));
     if (!flat[0].empty()) HIP_TRY(hipMemcpyAsync(c.items.p, flat[0].data(), flat[0].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
     if (!flat[1].empty()) HIP_TRY(hipMemcpyAsync(c.items_q.p, flat[1].data(), flat[1].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
@@ -592,7 +613,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "bring-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
         if (per_cu < 1) per_cu = 1;
         d.grid = (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu;
-        r = d.counters.reserve((2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
+        r = d.counters.reserve((OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
         // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
@@ -603,11 +624,11 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             r = scratch.reserve(tmp.size());
             if (r == hipSuccess) r = hipMemcpyAsync(scratch.p, tmp.data(), tmp.size(), hipMemcpyHostToDevice, d.stream);
             if (r == hipSuccess) r = hipMemcpyAsync(tmp.data(), scratch.p, tmp.size(), hipMemcpyDeviceToHost, d.stream);
-            if (r == hipSuccess) r = hipMemsetAsync(d.counters.p, 0, (2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream);
+            if (r == hipSuccess) r = hipMemsetAsync(d.counters.p, 0, (OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream);
             OswSearchArgs a;
             memset(&a, 0, sizeof a); // empty queues: every wave leaves at once
             a.counters = (uint32_t *)d.counters.p;
-            a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
+            a.counters_ovf = (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT;
             if (r == hipSuccess) r = osw_launch_s16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_s16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
@@ -629,9 +650,9 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         release_registered(d);
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
-                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages})
+                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8})
             b->release();
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -670,14 +691,16 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
     if (open_gap + extend_gap > 32767) return fail(OSWALD_HIP_EINVAL, "open+extend must fit int16");
     if (cell_bits == 0) cell_bits = getenv("OSWALD_HIP_CELL_BITS") ? atoi(getenv("OSWALD_HIP_CELL_BITS")) : 16;
-    if (cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 16 or 32");
+    if (cell_bits != 8 && cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 8, 16 or 32");
+    const bool was_q8 = ctx->have_scoring && first_pass_is_q8(ctx);
     memcpy(ctx->submat, submat, 24 * 32);
     ctx->open_gap = open_gap;
     ctx->extend_gap = extend_gap;
-    const bool repair = ctx->have_queries && cell_bits != ctx->cell_bits; // the pairing rule depends on the arithmetic
+    bool repair = ctx->have_queries && cell_bits != ctx->cell_bits; // the pairing rule depends on the arithmetic
     ctx->cell_bits = cell_bits;
     ctx->have_scoring = true;
     ctx->scoring_version++;
+    if (ctx->have_queries && was_q8 != first_pass_is_q8(ctx)) repair = true; // (eligibility depends on the matrix and the penalties)
     if (repair) { plan_pairs(ctx); ctx->queries_version++; }
     return 0;
 }
@@ -843,7 +866,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.scores = (int32_t *)c.scores.p;
     a.score_stride = c.score_stride;
     a.counters = (uint32_t *)d.counters.p;
-    a.counters_ovf = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
+    a.counters_ovf = (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT;
     a.ovf_items = (uint2 *)c.ovf.p;
     const uint32_t goe = (uint32_t)(ctx->open_gap + ctx->extend_gap), ge = (uint32_t)ctx->extend_gap;
     if (first_pass_is_frame(ctx)) {
@@ -873,7 +896,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             HIP_TRY(hipEventCreate(&ev.b));
         } else { ev = d.ev_pool.back(); d.ev_pool.pop_back(); }
     }
-    HIP_TRY(hipMemsetAsync(d.counters.p, 0, (2 * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
+    HIP_TRY(hipMemsetAsync(d.counters.p, 0, (OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
     const uint32_t grid = std::min<uint32_t>(d.grid, std::max<uint32_t>(1, (c.nitems + 3) / 4 + c.nitems_wg));
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
     const bool frame = first_pass_is_frame(ctx);
@@ -881,7 +904,38 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     const auto launch_pair = frame ? osw_launch_s16q : osw_launch_pk16q;
     OswSearchArgs as = a; // single queries (`a` itself stays on the plain integer profile for the int32 kernel)
     if (frame) { as.prof = (const uint2 *)d.prof_alt.p; as.prof_fb = (const uint2 *)d.prof.p; }
-    if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
+    if (first_pass_is_q8(ctx)) {
+        // 8-bit first pass over the query pairs, then -- all on this stream, each kernel reading what the one before
+        // queued -- a leftover unpaired query on the plain int16 kernel, the int16 re-run of what left the 7-bit range
+        // (queue length on the device), and below the int32 re-run of what reached the int16 ceiling
+        if (c.nitems_q > 0) {
+            OswSearchArgs aq = a;
+            aq.items = (const uint2 *)c.items_q.p;
+            aq.nitems = c.nitems_q;
+            aq.nitems_wg = c.nitems_q_wg; // 0: wave items only
+            aq.prof = (const uint2 *)d.prof_pair8.p;
+            aq.prof_off = (const uint32_t *)d.pair_off.p;
+            aq.qlen = (const uint16_t *)d.pair_len.p;
+            aq.pair_q = (const uint32_t *)d.pair_q.p;
+            aq.counters = (uint32_t *)d.counters.p + OSW_CTR_COUNT;
+            aq.ovf8_items = (uint2 *)c.ovf8.p;
+            const uint32_t b8 = (uint32_t)bias8_of(ctx), go8 = (uint32_t)ctx->open_gap, ge8 = (uint32_t)ctx->extend_gap;
+            aq.bias8 = b8 * 0x01010101u;
+            aq.go8 = go8 * 0x01010101u;
+            aq.ge8 = ge8 * 0x01010101u;
+            HIP_TRY(osw_launch_q8(aq, std::min<uint32_t>(d.grid, (c.nitems_q + 3) / 4), d.stream));
+        }
+        if (c.nitems + c.nitems_wg > 0) HIP_TRY(osw_launch_pk16(as, grid, d.stream));
+        if (c.nitems_q > 0) {
+            OswSearchArgs ar = a; // plain single-query profile, (open+extend, extend)
+            ar.items = (const uint2 *)c.ovf8.p;
+            ar.nitems = 0;
+            ar.nitems_wg = 0;
+            ar.nitems_dev = a.counters_ovf + 1;
+            ar.counters = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
+            HIP_TRY(osw_launch_pk16(ar, std::min<uint32_t>(d.grid, 512u), d.stream));
+        }
+    } else if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
         // query pairs first (the bulk of a multi-query search), on their own queue counters
         OswSearchArgs aq = a;
         aq.items = (const uint2 *)c.items_q.p;
@@ -1043,11 +1097,25 @@ int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, 
     HIP_TRY(hipStreamSynchronize(d.stream));
     drain_events(d);
     uint32_t ctr[8] = {0};
-    HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
     if (dp_kernel_ms) *dp_kernel_ms = d.dp_ms;
     if (dp_launches) *dp_launches = d.dp_launches;
     if (rerun_items) *rerun_items = ctr[0]; // of the most recent search
     if (reset) { d.dp_ms = 0; d.dp_launches = 0; }
+    return 0;
+}
+
+int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2)
+{
+    if (int r = check_dev(ctx, dev)) return r;
+    if (!out2) return fail(OSWALD_HIP_EINVAL, "null output");
+    Device &d = ctx->dev[dev];
+    HIP_TRY(hipSetDevice(d.id));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    uint32_t ctr[2] = {0, 0};
+    HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
+    out2[0] = ctr[1]; // 8-bit pass -> int16
+    out2[1] = ctr[0]; // int16 -> int32
     return 0;
 }
 

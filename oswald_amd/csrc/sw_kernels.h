@@ -11,6 +11,8 @@
 #define OSW_RMAX32 16        // query rows per strip, int32 kernel
 #define OSW_LDS_ROWS16 128   // profile rows a wave keeps in LDS per round (8 KB), packed int16 kernel
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
+#define OSW_RMAX8 16         // query rows per strip, SWAR 8-bit kernel (compiler-scheduled)
+#define OSW_LDS_ROWS8 128    // profile rows a wave keeps in LDS per round, SWAR 8-bit kernel (8 KB)
 #define OSW_LDS_SKEW8 128    // extra 8-byte units per wave region: group g's slice sits g entries (<= 16 B) further on, G <= 64
 #define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
 #define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64), kept zero
@@ -83,6 +85,9 @@ static __host__ __device__ inline uint32_t osw_plan_maxrows(const OswPlan &p) { 
 #define OSW_CTR_CU0 8         // per-CU arrival counters (which workgroup came first on a CU)
 #define OSW_CTR_CUS 4096
 #define OSW_CTR_COUNT (OSW_CTR_CU0 + OSW_CTR_CUS)
+#define OSW_CTR_BLOCKS 3      // counter blocks per device: single-query launch, query-pair launch, int16 re-run of the 8-bit pass
+// behind the blocks, shared by all launches of a search: [0] = items queued for the int32 kernel,
+// [1] = items queued by the 8-bit pass for the int16 re-run
 
 // One wave block of the re-tiled chunk: 128 consecutive sequences of the
 // (length-sorted) chunk, stored column-major: tiled[col*64 + lane] = uint16 {8*residue of
@@ -117,7 +122,10 @@ struct OswSearchArgs {
     int32_t *scores;           // [nq][score_stride]
     uint32_t score_stride;
     uint32_t *counters;        // this launch's queue counters (OSW_CTR_*)
-    uint32_t *counters_ovf;    // shared by all launches of a search: [0] = items queued for the int32 kernel
+    uint32_t *counters_ovf;    // shared by all launches of a search: [0] = items queued for the int32 kernel, [1] = for the int16 re-run
+    const uint32_t *nitems_dev;// packed-int16 kernels: if set, the length of the wave-item queue is read from the device (re-run queue)
+    uint2 *ovf8_items;         // 8-bit kernel: the queue it fills for the int16 re-run
+    uint32_t bias8, go8, ge8;  // 8-bit kernel: profile bias, gap open, gap extend, replicated in the four bytes
     const uint32_t *pair_q;    // query-pair kernel: the two queries of pair i (rows of the score table)
     uint2 *ovf_items;
     uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves; column-frame kernels: (open, extend)
@@ -133,6 +141,10 @@ hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_q8(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_build_pair_profile8(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
+                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
+                                          int bias, uint2 *prof_pair8, hipStream_t s);
 hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          bool intsum, uint4 *prof_pair, hipStream_t s);

@@ -560,6 +560,83 @@ struct CellI32 {
     }
 };
 
+// ---------------------------------------------------------------------------
+// 8-bit cells (BASELINE configs[2]: "int8 packed cells with int16 overflow re-run"; the reference's first
+// pass is 16 x int8 with saturation at 127, sw.cl:60-78, HybridSearch.c:1618-1633, and everything that reaches
+// 127 is redone in int16, :1670-1680).  gfx950 has no packed 8-bit maximum or saturating add, so four 7-bit
+// values ride in the four bytes of a register, bit 7 of every byte is a guard, and maximum / saturating
+// subtract are SWAR sequences of plain 32-bit operations (6 each).  A lane works on a 2 x 2 tile: the two
+// queries of a pair against its two sequences, bytes {A.s0, B.s0, A.s1, B.s1}.  The profile stores S + bias
+// (bias = -min S, so every entry is a 7-bit non-negative byte); a diagonal sum D + S + bias >= 128 sets the
+// guard bit, which is OR-ed into a sticky flag per byte: a flagged (query, sequence) has left the 7-bit range
+// at some point and is queued for the packed-int16 kernel; one that was never flagged is exact.  About three
+// times the instructions per cell of the packed-int16 cell: this mode exists for the configuration, not for
+// speed.  Compiler-scheduled (sw_round_plain).
+// ---------------------------------------------------------------------------
+struct CellQ8 {
+    typedef uint32_t T;
+    struct GapT { uint32_t go, ge, bias; }; // gap OPEN, gap extend and the profile bias, each replicated in the four bytes
+    static constexpr bool kFast = false;
+    static constexpr uint32_t kFloorBits = 0;
+    static constexpr bool kShifted = false;
+    static constexpr int kRows = OSW_RMAX8;
+    static constexpr int kLdsRows = OSW_LDS_ROWS8;
+    static constexpr int kRowBytes = 64; // 32 codes x 2 queries x 1 byte
+    typedef uint2 Entry;                 // one code: 4 rows x (S_A, S_B) bytes
+    static constexpr uint32_t G = 0x80808080u, L = 0x7f7f7f7fu;
+    static __device__ __forceinline__ T zero() { return 0u; }
+    static __device__ __forceinline__ T from_bits(uint32_t x) { return x; }
+    static __device__ __forceinline__ uint32_t to_bits(T x) { return x; }
+    // per byte, operands 7-bit: 0x7f where a >= b, else 0
+    static __device__ __forceinline__ uint32_t ge_mask(uint32_t a, uint32_t b)
+    {
+        const uint32_t m = ((a | G) - b) & G;
+        return m - (m >> 7);
+    }
+    static __device__ __forceinline__ uint32_t max7(uint32_t a, uint32_t b)
+    {
+        const uint32_t k = ge_mask(a, b);
+        return (a & k) | (b & ~k);
+    }
+    static __device__ __forceinline__ uint32_t satsub7(uint32_t a, uint32_t c) // max(a - c, 0)
+    {
+        const uint32_t d = (a | G) - c, m = d & G;
+        return d & (m - (m >> 7));
+    }
+    // running score: low 7 bits of every byte the best score, bit 7 the sticky "left the 7-bit range" flag
+    static __device__ __forceinline__ T vmax(T a, T b) { return max7(a & L, b & L) | ((a | b) & G); }
+
+    template <int R>
+    static __device__ __forceinline__ void column(uint32_t base, uint32_t codes, int /*half*/, T (&D)[R], T (&E)[R],
+                                                  T top_prev, T &f, T &hl, GapT gp, GapT /*same*/, T &score)
+    {
+        const uint32_t go = gp.go, ge = gp.ge, bias = gp.bias;
+        const lds_cp l0 = (lds_cp)(uintptr_t)(base + (codes & 0xffu)), l1 = (lds_cp)(uintptr_t)(base + ((codes >> 8) & 0xffu));
+        T diag = top_prev, sc = score & L, fl = score;
+#pragma unroll
+        for (int rb = 0; rb < R / 4; ++rb) {
+            const u32x2 p0 = *(lds_u2p)(l0 + rb * 256), p1 = *(lds_u2p)(l1 + rb * 256);
+            const uint32_t s[4] = {__builtin_amdgcn_perm(p1.x, p0.x, 0x05040100u), __builtin_amdgcn_perm(p1.x, p0.x, 0x07060302u),
+                                   __builtin_amdgcn_perm(p1.y, p0.y, 0x05040100u), __builtin_amdgcn_perm(p1.y, p0.y, 0x07060302u)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rb * 4 + k;
+                uint32_t y = diag + s[k];         // D + S + bias: at most 127 + 127, no carry between the bytes
+                fl |= y;                          // guard bit set: out of range from here on (sticky)
+                y &= L;
+                const uint32_t x = satsub7(y, bias);
+                const uint32_t h = max7(max7(x, E[r]), f);
+                const uint32_t u = satsub7(h, go); // H - gap open
+                E[r] = satsub7(max7(E[r], u), ge);
+                f = satsub7(max7(f, u), ge);
+                sc = max7(sc, h);
+                if (r + 1 < R) { diag = D[r + 1]; D[r + 1] = h; } else { hl = h; }
+            }
+        }
+        score = sc | (fl & G);
+    }
+};
+
 static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
@@ -988,6 +1065,8 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     // (shared profile slice, rounds in step), or on a quad of four independent heavy wave items.  Phase 2: every
     // wave on its own, light wave items.  One loop, so that the (large, fully unrolled) round code exists once.
     const uint2 *wave_items = p.items + (size_t)p.nitems_wg * 4;
+    // (the re-run queue of the 8-bit pass was filled by the previous kernel on this stream)
+    const uint32_t nitems = p.nitems_dev ? __builtin_amdgcn_readfirstlane(*p.nitems_dev) : p.nitems;
     bool phase1 = true;
     for (;;) {
         uint2 item;
@@ -1013,10 +1092,10 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
             uint32_t it = 0;
             if (lane == 0) {
                 it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
-                if (it < p.nitems && p.two_ended_waves) it = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT], 1u) : p.nitems - 1 - atomicAdd(&p.counters[OSW_CTR_BACK], 1u);
+                if (it < nitems && p.two_ended_waves) it = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT], 1u) : nitems - 1 - atomicAdd(&p.counters[OSW_CTR_BACK], 1u);
             }
             it = __builtin_amdgcn_readfirstlane(it);
-            if (it >= p.nitems) break;
+            if (it >= nitems) break;
             item = wave_items[it];
         }
         const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y & ~OSW_ITEM_WG_FLAG;
@@ -1085,6 +1164,79 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
             if ((uint32_t)lane < gl)
                 p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 8-bit first pass (cell_bits = 8): query-pair items of the wave queue, one 2 x 2 tile per lane (CellQ8).
+// Every (query, sequence) that left the 7-bit range is queued for the packed-int16 kernel, which re-runs the
+// two lanes (four sequences) around it at geometry 32 and queues what reaches ITS ceiling for the int32 kernel.
+// ---------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_q8(OswSearchArgs p)
+{
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS8 * 8 + OSW_LDS_SKEW8];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
+    uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
+    const uint2 *items = p.items + (size_t)p.nitems_wg * 4;
+    const CellQ8::GapT gp = {p.go8, p.ge8, p.bias8};
+    for (;;) {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= p.nitems) break;
+        const uint2 item = items[it];
+        const uint32_t pair = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
+        const OswBlock blk = p.blocks[B];
+        const uint32_t gl = 64u >> lg;
+        const uint32_t score = run_item<CellQ8>(p, p.prof, pair, B, blk, sigma, lg, lane, 0, false, lds_prof[wv], bnd_wave, gp, gp);
+        if ((uint32_t)lane < gl) {
+            const uint32_t lam = sigma * gl + lane; // lane of the block = sequence pair
+            const uint32_t qa = p.pair_q[2 * pair], qb = p.pair_q[2 * pair + 1];
+            const size_t seq = (size_t)blk.seq0 + 2 * lam;
+            int2 ra, rb;
+            ra.x = (int)(score & 0x7fu);         // A . s0
+            rb.x = (int)((score >> 8) & 0x7fu);  // B . s0
+            ra.y = (int)((score >> 16) & 0x7fu); // A . s1
+            rb.y = (int)((score >> 24) & 0x7fu); // B . s1
+            *(int2 *)(p.scores + (size_t)qa * p.score_stride + seq) = ra;
+            *(int2 *)(p.scores + (size_t)qb * p.score_stride + seq) = rb;
+            if (score & 0x00800080u) { // query A, either sequence
+                const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
+                p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam >> 1, 5u, 3u), B);
+            }
+            if (score & 0x80008000u) {
+                const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
+                p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qb, lam >> 1, 5u, 3u), B);
+            }
+        }
+    }
+}
+
+// 8-bit pair profile: prof8[(pair_off[p] + i/4)*32 + code] = 8 bytes {A r0, B r0, A r1, B r1, ...}, every byte
+// S + bias (rows past a query's end: bias, i.e. score 0), built from the plain int16 single-query profiles.
+extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile8(const uint2 *__restrict__ prof, const uint32_t *__restrict__ prof_off,
+                                                                           const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ pair_q,
+                                                                           const uint32_t *__restrict__ pair_off, const uint16_t *__restrict__ pair_len,
+                                                                           uint32_t npairs, int bias, uint2 *__restrict__ prof8)
+{
+    const uint32_t pr = blockIdx.y;
+    if (pr >= npairs) return;
+    const uint32_t qa = pair_q[2 * pr], qb = pair_q[2 * pr + 1];
+    const uint32_t nrb = (pair_len[pr] + 3u) / 4u > 0 ? (pair_len[pr] + 3u) / 4u : 1u;
+    const uint32_t na = (qlen[qa] + 3u) / 4u, nb = (qlen[qb] + 3u) / 4u;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < nrb * 32; e += gridDim.x * blockDim.x) {
+        const uint32_t rb = e >> 5, code = e & 31;
+        const uint2 A = rb < na ? prof[(size_t)(prof_off[qa] + rb) * 32 + code] : make_uint2(0, 0);
+        const uint2 Bv = rb < nb ? prof[(size_t)(prof_off[qb] + rb) * 32 + code] : make_uint2(0, 0);
+        auto pack = [&](uint32_t a16, uint32_t b16) { // -> {A + bias, B + bias} as two bytes
+            return (uint32_t)(((int)(int16_t)a16 + bias) & 0xff) | ((uint32_t)(((int)(int16_t)b16 + bias) & 0xff) << 8);
+        };
+        uint2 o;
+        o.x = pack(A.x & 0xffffu, Bv.x & 0xffffu) | (pack(A.x >> 16, Bv.x >> 16) << 16);
+        o.y = pack(A.y & 0xffffu, Bv.y & 0xffffu) | (pack(A.y >> 16, Bv.y >> 16) << 16);
+        prof8[(size_t)(pair_off[pr] + rb) * 32 + code] = o;
     }
 }
 
@@ -1328,6 +1480,25 @@ hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof
     uint32_t gx = (max_rowblocks * 32 + 255) / 256;
     if (gx == 0) gx = 1;
     hipLaunchKernelGGL(osw_build_pair_profile, dim3(gx, npairs), dim3(256), 0, s, prof, prof_off, qlen, pair_q, pair_off, pair_len, npairs, intsum ? 1u : 0u, prof_pair);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_q8(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_q8, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_build_pair_profile8(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
+                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
+                                          int bias, uint2 *prof_pair8, hipStream_t s)
+{
+    if (npairs == 0) return hipSuccess;
+    uint32_t gx = (max_rowblocks * 32 + 255) / 256;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(osw_build_pair_profile8, dim3(gx, npairs), dim3(256), 0, s, prof, prof_off, qlen, pair_q, pair_off, pair_len, npairs, bias, prof_pair8);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -31,7 +31,7 @@ def cases(draw):
     return dict(seed=seed, qlens=qlens, nseq=nseq, max_len=max_len,
                 matrix=draw(st.sampled_from(submat.NAMES)), go=draw(st.integers(0, 40)), ge=ge,
                 W=draw(st.sampled_from([16, 32, 64, 128])), lg=draw(st.sampled_from([-1, -1, 0, 1, 2, 3, 4, 5, 6])),
-                wg=draw(st.sampled_from([-1, -1, 0, 1])), pairs=draw(st.sampled_from([0, 1, 2])), bits=draw(st.sampled_from([0, 16, 16, 32])),
+                wg=draw(st.sampled_from([-1, -1, 0, 1])), pairs=draw(st.sampled_from([0, 1, 2])), bits=draw(st.sampled_from([0, 16, 16, 32, 8, 8])),
                 homolog=draw(st.booleans()))
 
 

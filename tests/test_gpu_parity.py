@@ -483,3 +483,49 @@ def test_scores_around_the_frame_cell_ceiling(hip_ctx, oracle, ge, go):
     want = expect(oracle, qs, b, n, disp, 16, sm, go, ge)
     np.testing.assert_array_equal(got, want)
     assert want.max(axis=1).tolist() == targets[1::3]
+
+
+@pytest.mark.parametrize("matrix,go,ge", [("blosum62", 10, 2), ("pam250", 14, 2), ("blosum45", 0, 0), ("pam30", 30, 5)])
+@pytest.mark.parametrize("nq", [2, 5])
+def test_int8_first_pass_with_int16_rerun(hip_ctx, oracle, matrix, go, ge, nq):
+    """cell_bits = 8 (BASELINE configs[2]): the SWAR 8-bit first pass on query pairs, everything that leaves its
+    7-bit range re-run by the packed-int16 kernel (and beyond that in int32); an odd query runs in int16.  Scores
+    must be the exact ones for every (query, sequence), whatever tier computed them."""
+    qs = synth.make_queries([50, 129, 375, 31, 700][:nq], seed=5)
+    L, R, O = random_db(300, seed=77, max_len=400, queries=qs, homologs=3)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load(matrix)
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge, cell_bits=8, resident=True)
+    want = expect(oracle, qs, b, n, disp, 16, sm, go, ge)
+    np.testing.assert_array_equal(got, want)
+    to16, to32 = hip_ctx.rerun_counts()
+    assert want.max() > 127 and to16 >= 1          # the planted copies are beyond the 8-bit range
+
+
+@pytest.mark.parametrize("lg", [0, 2, 4, 6])
+def test_int8_every_geometry_and_thresholds(hip_ctx, oracle, lg, monkeypatch):
+    """Forced wave geometries, multi-round queries (spill of the 8-bit boundary row) and self-alignments scoring just
+    below, at and above the point where the 8-bit range ends (127 - bias and 127)."""
+    monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
+    targets = [110, 118, 122, 123, 124, 126, 127, 128, 140]
+    qs = [_self_scoring(t, 900 + t) for t in targets[::2]] + [synth.random_residues(4, 0, 300)]
+    seqs = [_self_scoring(t, 900 + t) for t in targets] + [synth.random_residues(3000 + i, 0, 30 + 11 * i) for i in range(40)]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2, cell_bits=8)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want.max(axis=1)[:5].tolist() == targets[::2]
+
+
+def test_int8_falls_back_to_int16_when_penalties_do_not_fit(hip_ctx, oracle):
+    """Gap penalties above 127 do not fit the 8-bit cells (the reference's int8 kernels wrap there,
+    HybridSearch.c:1520): the search runs on the int16 cells and stays exact."""
+    qs = synth.make_queries([60, 90], seed=3)
+    L, R, O = random_db(150, seed=4, max_len=200, queries=qs, homologs=2)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 200, 70, cell_bits=8)
+    np.testing.assert_array_equal(got, expect(oracle, qs, b, n, disp, 16, sm, 200, 70))
+    assert hip_ctx.rerun_counts()[0] == 0
