@@ -421,7 +421,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             // hard limit of a geometry: G strips of (at least) 4 rows must fit the profile slice in LDS
             {
                 const Kind &kd = kinds[e.kind];
-                if (!wg && (4u << lg) > kd.ldsr && !i32 && force_wg != 0 && (4u << lg) <= kd.ldsr * wgx && lg >= 2) wg = true;
+                if (!wg && (4u << lg) > kd.ldsr && !i32 && !(q8 && e.kind == 1) && force_wg != 0 && (4u << lg) <= kd.ldsr * wgx && lg >= 2) wg = true;
                 while ((4u << lg) > (wg ? kd.ldsr * wgx : kd.ldsr) && lg > 0) --lg;
                 if (lg < lg_scratch) return fail(OSWALD_HIP_EINVAL, "a sequence block of %u columns does not fit the spill scratch at any geometry", ncols);
             }
@@ -487,6 +487,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     c.nitems = n_wave[0];
     c.nitems_q_wg = n_entries[1];
     c.nitems_q = n_wave[1];
+    if (q8 && c.nitems_q_wg) return fail(OSWALD_HIP_ERUNTIME, "planner produced workgroup entries for the 8-bit kernel");
     if (getenv("OSWALD_HIP_DEBUG")) {
         fprintf(stderr, "[oswald_hip] plan: %zu single queries, %zu query pairs, total %.3g slots, %.0f waves, target %.3g, max lg %u\n",
                 i32 ? (size_t)ctx->nq : ctx->singles.size(), i32 ? (size_t)0 : ctx->pair_len.size(), total, nwaves, target, c.max_lg);

@@ -93,25 +93,32 @@ def test_c2_full_size_properties(hip_ctx, oracle, db100k):
 
 
 def test_c3_pam250_full_size(hip_ctx, oracle, db100k):
-    """BASELINE configs[2]: the same queries and database with PAM250, gap 14/2 (matrix / gap configurability).
-    The library's narrowest cells are the packed int16 ones (no packed 8-bit maximum on gfx950, DESIGN.md);
-    their escalation to int32 gives the reference's exact scores."""
+    """BASELINE configs[2]: the same queries and database with PAM250, gap 14/2, in the named cell mode -- int8 cells
+    (cell_bits = 8: SWAR 8-bit first pass, int16 re-run of what leaves its range, int32 beyond) -- and on the
+    default int16 cells: both must give the reference's exact scores, i.e. identical tables."""
     qs, sl, sr, so, b, n, disp = db100k
     nseq = len(sl)
     a, m, ad = pack_queries(qs)
     sm = submat.load("pam250")
-    hip_ctx.set_scoring(sm, 14, 2)
-    hip_ctx.set_queries(a, m, ad)
-    h = hip_ctx.chunk_upload(b, n, disp, 16)
-    t1 = np.zeros((len(qs), len(n) * 16), np.int32)
-    hip_ctx.chunk_search(h, t1)
-    hip_ctx.wait()
-    sc, ix = hip_ctx.chunk_topr(h, nseq, 10)
-    hip_ctx.chunk_release(h)
-    check_properties(t1, sc, ix, nseq, m, sl, sm)
-    assert (sc[:, 0] > 127).all()
+    tables = {}
+    for bits in (8, 16):
+        hip_ctx.set_scoring(sm, 14, 2, bits)
+        hip_ctx.set_queries(a, m, ad)
+        h = hip_ctx.chunk_upload(b, n, disp, 16)
+        t = np.zeros((len(qs), len(n) * 16), np.int32)
+        hip_ctx.chunk_search(h, t)
+        hip_ctx.wait()
+        sc, ix = hip_ctx.chunk_topr(h, nseq, 10)
+        to16, to32 = hip_ctx.rerun_counts()
+        hip_ctx.chunk_release(h)
+        check_properties(t, sc, ix, nseq, m, sl, sm)
+        assert (sc[:, 0] > 127).all()
+        tables[bits] = t
+        if bits == 8:
+            assert 0 < to16 < 0.05 * t.size      # the homologs and a few strong random hits, not the bulk
+    np.testing.assert_array_equal(tables[8], tables[16])
     seqs = sample_groups(nseq, 32, 40, 8)
-    np.testing.assert_array_equal(t1[:, seqs], cpu_port_scores(oracle, a, m, ad, sl, sr, so, seqs, sm, 14, 2))
+    np.testing.assert_array_equal(tables[8][:, seqs], cpu_port_scores(oracle, a, m, ad, sl, sr, so, seqs, sm, 14, 2))
 
 
 def test_c5_long_query_full_size(hip_ctx, oracle, db100k):
