@@ -1,0 +1,127 @@
+// oswald_amd/host/host_search.cpp -- the HOST compute path of the command line tool: `-m 2` (host only) and the
+// host share of `-m 1` (hybrid).  It is a mode the caller selects, never a fallback: `-m 0` and the C ABI fail
+// loudly without a GPU.  It stands where the reference has its host SIMD kernels (reference
+// host/src/HybridSearch.c:1540-1880 SSE, :790-1140 AVX2), whose contract is "the exact Smith-Waterman score of every
+// (query, database sequence)"; the formulation here is its own: sixteen database sequences of a group side by side
+// in the sixteen int16 lanes of one AVX2 register, the database streamed column by column, a per-column score
+// profile (24 vectors, two byte shuffles each), H and E of every query row in two arrays, saturating int16
+// arithmetic, and an exact scalar int32 pass for the few sequences whose score reaches the int16 ceiling.
+#include "oswald_host.h"
+
+#include <immintrin.h>
+#include <omp.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+namespace oswald {
+
+namespace {
+
+// exact score of one query against lane `lane` of an interleaved group (dummy residues score 0 and are harmless)
+int32_t scalar_score(const uint8_t *a, uint32_t m, const uint8_t *grp, uint32_t ncols, int W, int lane, const int8_t *submat, int goe, int ge,
+                     std::vector<int32_t> &H, std::vector<int32_t> &E)
+{
+    H.assign(m + 1, 0);
+    E.assign(m + 1, 0);
+    int32_t best = 0;
+    for (uint32_t j = 0; j < ncols; ++j) {
+        const uint32_t r = grp[(size_t)j * W + lane] & 31u;
+        int32_t diag = 0, f = 0;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t ai = a[i] < 24 ? a[i] : 23;
+            int32_t h = diag + submat[ai * 32 + r];
+            h = std::max(std::max(h, E[i]), std::max(f, 0));
+            diag = H[i];
+            H[i] = h;
+            best = std::max(best, h);
+            const int32_t u = h - goe;
+            E[i] = std::max(E[i] - ge, u);
+            f = std::max(f - ge, u);
+        }
+    }
+    return best;
+}
+
+struct Scratch {
+    std::vector<int16_t> H, E; // 16 lanes per query row
+    std::vector<int32_t> h32, e32;
+};
+
+// sixteen lanes at once; returns the lanes' best scores (32767 = reached the ceiling)
+__attribute__((target("avx2"))) void simd_group(const uint8_t *a, uint32_t m, const uint8_t *grp, uint32_t ncols, const int8_t *submat, int goe, int ge,
+                                               Scratch &s, int16_t out[16])
+{
+    s.H.assign((size_t)m * 16, 0);
+    s.E.assign((size_t)m * 16, 0);
+    __m256i *H = (__m256i *)s.H.data(), *E = (__m256i *)s.E.data(); // unaligned accesses below
+    const __m256i vgoe = _mm256_set1_epi16((short)std::min(goe, 32767)), vge = _mm256_set1_epi16((short)std::min(ge, 32767)), zero = _mm256_setzero_si256();
+    __m256i best = zero;
+    __m128i lo[24], hi[24];
+    for (int c = 0; c < 24; ++c) {
+        lo[c] = _mm_loadu_si128((const __m128i *)(submat + c * 32));
+        hi[c] = _mm_loadu_si128((const __m128i *)(submat + c * 32 + 16));
+    }
+    __m256i P[24];
+    const __m128i fifteen = _mm_set1_epi8(15);
+    for (uint32_t j = 0; j < ncols; ++j) {
+        const __m128i r = _mm_and_si128(_mm_loadu_si128((const __m128i *)(grp + (size_t)j * 16)), _mm_set1_epi8(31));
+        const __m128i upper = _mm_cmpgt_epi8(r, fifteen); // codes 16..31 live in the second half of a matrix row
+        for (int c = 0; c < 24; ++c) {
+            const __m128i s8 = _mm_blendv_epi8(_mm_shuffle_epi8(lo[c], r), _mm_shuffle_epi8(hi[c], _mm_and_si128(r, fifteen)), upper);
+            P[c] = _mm256_cvtepi8_epi16(s8);
+        }
+        __m256i diag = zero, f = zero;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t ai = a[i] < 24 ? a[i] : 23;
+            __m256i h = _mm256_adds_epi16(diag, P[ai]);
+            const __m256i e = _mm256_loadu_si256(E + i);
+            h = _mm256_max_epi16(_mm256_max_epi16(h, e), _mm256_max_epi16(f, zero));
+            diag = _mm256_loadu_si256(H + i);
+            _mm256_storeu_si256(H + i, h);
+            best = _mm256_max_epi16(best, h);
+            const __m256i u = _mm256_subs_epi16(h, vgoe);
+            _mm256_storeu_si256(E + i, _mm256_max_epi16(_mm256_subs_epi16(e, vge), u));
+            f = _mm256_max_epi16(_mm256_subs_epi16(f, vge), u);
+        }
+    }
+    _mm256_storeu_si256((__m256i *)out, best);
+}
+
+} // namespace
+
+void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int W, const int8_t *submat, int open_gap, int extend_gap,
+                        int threads, int32_t *scores, uint64_t row_stride, uint64_t col0)
+{
+    if (W != kFpgaVectorLength) throw std::runtime_error("OSWALD: the host path works on groups of 16 sequences.");
+    const int goe = open_gap + extend_gap, ge = extend_gap;
+    const bool avx2 = __builtin_cpu_supports("avx2");
+    const uint64_t nq = q.m.size();
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        Scratch s;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t gi = (int64_t)g1 - 1; gi >= (int64_t)g0; --gi) { // longest groups first
+            const uint64_t g = (uint64_t)gi;
+            const uint8_t *grp = c.b + c.disp[g];
+            const uint32_t ncols = c.n[g];
+            for (uint64_t qi = 0; qi < nq; ++qi) {
+                const uint8_t *a = q.a.data() + q.a_disp[qi];
+                const uint32_t m = q.m[qi];
+                int32_t *dst = scores + qi * row_stride + col0 + (g - g0) * W;
+                int16_t lane16[16];
+                if (avx2) simd_group(a, m, grp, ncols, submat, goe, ge, s, lane16);
+                for (int lane = 0; lane < W; ++lane) {
+                    if (avx2 && lane16[lane] < 32767) dst[lane] = lane16[lane];
+                    else dst[lane] = scalar_score(a, m, grp, ncols, W, lane, submat, goe, ge, s.h32, s.e32); // at the int16 ceiling: exact int32
+                }
+            }
+        }
+    }
+}
+
+} // namespace oswald

@@ -7,7 +7,10 @@
 // the search driver -- OpenCL bring-up, score-profile build, enqueue path --
 // is replaced by calls into the C ABI of include/oswald_hip.h; this file is
 // the mirror of fpga_search() (reference host/src/FPGAsearch.c:4-374) with
-// GPUs where the reference has FPGAs.  There is no host compute path here.
+// GPUs where the reference has FPGAs.  `-m 0` (accelerator only) has no host compute path and fails loudly without a
+// GPU; `-m 1` (hybrid, the reference's default: hybrid_search_*, host/src/HybridSearch.c) gives the host a share of
+// the database measured on a test portion; `-m 2` (host only, BASELINE configs[0]) never touches a GPU.  The host
+// kernel is this package's own (host_search.cpp).
 #include <argp.h>
 #include <algorithm>
 #include <utility>
@@ -19,6 +22,7 @@
 #include <ctime>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "oswald_hip.h"
@@ -69,8 +73,8 @@ int parse_opt(int key, char *arg, struct argp_state *state)
         if (o->extend_gap < 0 || o->extend_gap > 127) argp_failure(state, 1, 0, "%d is not a valid option for gap extend penalty.", o->extend_gap);
         break;
     case 'm':
-        o->execution_mode = atoi(arg);
-        if (o->execution_mode != 0 && o->execution_mode != 1) argp_failure(state, 1, 0, "%d is not a valid option for execution mode.", o->execution_mode);
+        o->execution_mode = !strcmp(arg, "host-only") ? 2 : atoi(arg);
+        if (o->execution_mode < 0 || o->execution_mode > 2) argp_failure(state, 1, 0, "%d is not a valid option for execution mode.", o->execution_mode);
         break;
     case 'c':
         o->cpu_threads = atoi(arg);
@@ -138,6 +142,15 @@ void check(int rc, const char *what)
     }
 }
 
+// devices 0 .. num_devices-1, or the list in OSWALD_DEVICE_IDS ("0,0": two context devices on one GPU; test hook)
+int bring_up(const Options &o, oswald_hip_ctx **ctx)
+{
+    std::vector<int> ids;
+    if (const char *e = getenv("OSWALD_DEVICE_IDS"))
+        for (const char *p = e; *p;) { ids.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+    return oswald_hip_init((int)o.num_devices, ids.size() == o.num_devices ? ids.data() : nullptr, ctx);
+}
+
 int do_preprocess(const Options &o)
 {
     const double tick = dwalltime();
@@ -166,15 +179,209 @@ int do_info()
     return 0;
 }
 
-int do_search(Options &o)
+void print_header(const Options &o, const oswald::Database &db)
+{
+    printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)db.sequences_count, (long)db.D);
+    printf("Longest database sequence: \t%d residues\n", db.sequences_db_max_length);
+    printf("Substitution matrix:\t\t%s\n", o.submat_name.c_str());
+    printf("Gap open penalty:\t\t%d\n", o.open_gap);
+    printf("Gap extend penalty:\t\t%d\n", o.extend_gap);
+    printf("Query filename:\t\t\t%s\n", o.queries);
+}
+
+// query sections and footer of the report (reference FPGAsearch.c:312-331, HybridSearch.c:1218-1234)
+void print_report(const Options &o, const oswald::Queries &q, const oswald::Database &db, const std::vector<std::vector<int32_t>> &top_s,
+                  const std::vector<std::vector<uint64_t>> &top_i, time_t current_time, double work_time, double gcups_time)
+{
+    std::vector<uint64_t> wanted;
+    for (const auto &ti : top_i) wanted.insert(wanted.end(), ti.begin(), ti.end());
+    const std::vector<std::string> headers = oswald::load_database_headers_at(o.db, wanted);
+    size_t hpos = 0;
+    for (uint64_t i = 0; i < q.m.size(); ++i) {
+        printf("\nQuery no.\t\t\t%d\n", (int)i + 1);
+        printf("Query description: \t\t%s\n", q.titles[i].c_str() + 1);
+        printf("Query length:\t\t\t%d residues\n", q.m[i]);
+        printf("\nScore\tSequence description\n");
+        for (size_t j = 0; j < top_s[i].size(); ++j) {
+            const std::string &h = headers[hpos++];
+            printf("%d\t%s\n", top_s[i][j], h.empty() ? "" : h.c_str() + 1);
+        }
+    }
+    printf("\nSearch date:\t\t\t%s", ctime(&current_time));
+    printf("Search time:\t\t\t%lf seconds\n", work_time);
+    printf("Search speed:\t\t\t%.2lf GCUPS\n", (double)(q.Q * db.D) / (gcups_time * 1000000000));
+    printf("CPU threads:\t\t\t%d\n", o.cpu_threads);
+    printf("CPU vector length:\t\t%d\n", 16);
+    printf("CPU block width:\t\t%d\n", o.cpu_block_size);
+    printf("Number of FPGAs:\t\t%u\n", o.num_devices);
+    printf("FPGA vector length:\t\t%d\n", oswald::kFpgaVectorLength);
+    printf("FPGA block width:\t\t%d\n", oswald::kFpgaBlockWidth);
+    printf("Max. chunk size in FPGA:\t%ld bytes\n", (long)o.max_chunk_size);
+    // (not part of the reference's report, FPGAsearch.c:327-331: only on request)
+    if (getenv("OSWALD_REPORT_ACCELERATOR"))
+        printf("Accelerator:\t\t\t%u x AMD Instinct GPU via HIP (the \"FPGA\" lines above describe the input layout)\n", o.num_devices);
+}
+
+void tops_from_table(const Options &o, const oswald::Database &db, const std::vector<int32_t> &scores, uint64_t nq,
+                     std::vector<std::vector<int32_t>> &top_s, std::vector<std::vector<uint64_t>> &top_i)
+{
+    const uint64_t W = oswald::kFpgaVectorLength;
+    top_s.assign(nq, {});
+    top_i.assign(nq, {});
+    for (uint64_t i = 0; i < nq; ++i) oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, top_s[i], top_i[i]);
+}
+
+// -m 2: every group on the host cores; no accelerator call at all.
+int do_search_host_only(Options &o)
 {
     const time_t current_time = time(nullptr);
     printf("\nOSWALD v%s \n\n", oswald::kVersion);
     printf("Database file:\t\t\t%s\n", o.db);
-    if (o.execution_mode == 1)
-        fprintf(stderr, "OSWALD: hybrid mode (-m 1) splits work between host SIMD and the accelerator; this build runs the whole "
-                        "database on the GPU(s) (as -m 0).\n");
+    oswald::Queries q = oswald::load_query_sequences(o.queries);
+    oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, 1);
+    const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength;
+    print_header(o, db);
+    if (db.sequences_count < o.top) o.top = db.sequences_count;
+    std::vector<int32_t> scores(nq * db.vect_sequences_count * W, 0);
+    const double tick = dwalltime();
+    for (const oswald::Chunk &c : db.chunks)
+        oswald::host_search_groups(q, c, 0, c.n.size(), (int)W, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, o.cpu_threads, scores.data(),
+                                   db.vect_sequences_count * W, c.accum * W);
+    const double work_time = dwalltime() - tick;
+    std::vector<std::vector<int32_t>> top_s;
+    std::vector<std::vector<uint64_t>> top_i;
+    tops_from_table(o, db, scores, nq, top_s, top_i);
+    print_report(o, q, db, top_s, top_i, current_time, work_time, work_time);
+    return 0;
+}
 
+// A run of whole groups [g0, g1) of a chunk as a chunk of its own (displacements rebased): what the hybrid mode
+// hands to the accelerator.
+struct GroupRun {
+    const uint8_t *b;
+    uint64_t bytes;
+    const uint16_t *n;
+    std::vector<uint32_t> disp;
+    uint64_t first_group; // in the whole database
+};
+GroupRun group_run(const oswald::Chunk &c, uint64_t g0, uint64_t g1)
+{
+    GroupRun r;
+    r.b = c.b + c.disp[g0];
+    r.n = c.n.data() + g0;
+    r.disp.resize(g1 - g0);
+    for (uint64_t g = g0; g < g1; ++g) r.disp[g - g0] = c.disp[g] - c.disp[g0];
+    const uint64_t end = g1 < c.n.size() ? c.disp[g1] : c.b_size;
+    r.bytes = end - c.disp[g0];
+    r.first_group = c.accum + g0;
+    return r;
+}
+
+// -m 1: the reference's hybrid scheme (hybrid_search_*, HybridSearch.c:124-228, :620-631; assemble_db_chunks,
+// sequences.c:828-1094): both sides search a test portion of the database (the first -p of its groups) to measure
+// their speeds, the rest is divided in that proportion -- the accelerator takes the groups that follow the test
+// portion, the host the longest sequences at the end -- and both work at the same time.
+int do_search_hybrid(Options &o)
+{
+    const time_t current_time = time(nullptr);
+    printf("\nOSWALD v%s \n\n", oswald::kVersion);
+    printf("Database file:\t\t\t%s\n", o.db);
+    oswald::Queries q = oswald::load_query_sequences(o.queries);
+    oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, o.num_devices);
+    const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength, G = db.vect_sequences_count, row = G * W;
+    print_header(o, db);
+    if (db.sequences_count < o.top) o.top = db.sequences_count;
+    const int8_t *sm = oswald::submat_by_name(o.submat);
+    std::vector<int32_t> scores(nq * row, 0);
+    oswald_hip_ctx *ctx = nullptr;
+    check(bring_up(o, &ctx), "device bring-up");
+    check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space");
+    check(oswald_hip_set_scoring(ctx, sm, o.open_gap, o.extend_gap, 0), "scoring setup");
+    check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
+    auto padded = [&](uint64_t g0, uint64_t g1) { // padded residues of database groups [g0, g1)
+        uint64_t v = 0;
+        for (const oswald::Chunk &c : db.chunks)
+            for (uint64_t g = std::max(g0, c.accum); g < std::min<uint64_t>(g1, c.accum + c.n.size()); ++g) v += (uint64_t)c.n[g - c.accum] * W;
+        return v;
+    };
+    // searches database groups [g0, g1) on the accelerator(s), chunk by chunk, into the score table
+    auto gpu_groups = [&](uint64_t g0, uint64_t g1) {
+        std::vector<GroupRun> runs;
+        for (const oswald::Chunk &c : db.chunks) {
+            const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
+            if (a0 < a1) runs.push_back(group_run(c, a0 - c.accum, a1 - c.accum));
+        }
+        std::vector<std::vector<int32_t>> tmp(o.num_devices);
+        for (size_t k = 0; k < runs.size(); k += o.num_devices) { // run k + d of a round goes to device d (FPGAsearch.c:132-138)
+            const size_t active = std::min<size_t>(o.num_devices, runs.size() - k);
+            for (size_t d = 0; d < active; ++d) {
+                const GroupRun &r = runs[k + d];
+                tmp[d].assign(nq * r.disp.size() * W, 0);
+                check(oswald_hip_search_chunk_async(ctx, (int)d, r.b, r.bytes, r.n, r.disp.data(), (uint32_t)r.disp.size(), (uint32_t)W, tmp[d].data()),
+                      "chunk search");
+            }
+            check(oswald_hip_wait(ctx, -1), "wait");
+            for (size_t d = 0; d < active; ++d) {
+                const GroupRun &r = runs[k + d];
+                const size_t cols = r.disp.size() * W;
+                for (uint64_t qi = 0; qi < nq; ++qi) memcpy(scores.data() + qi * row + r.first_group * W, tmp[d].data() + qi * cols, cols * sizeof(int32_t));
+            }
+        }
+    };
+    auto cpu_groups = [&](uint64_t g0, uint64_t g1) {
+        for (const oswald::Chunk &c : db.chunks) {
+            const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
+            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, o.cpu_threads, scores.data(), row, a0 * W);
+        }
+    };
+    // test portion: both sides, at the same time (the host's scores are the ones kept)
+    const uint64_t test_groups = std::min<uint64_t>(G, std::max<uint64_t>(1, (uint64_t)(o.test_db_percentage * (double)G)));
+    double test_gpu_time = 0, test_cpu_time = 0;
+    {
+        // (one after the other: both write the same table columns -- the same scores; the host's pass is the one kept)
+        double t = dwalltime();
+        gpu_groups(0, test_groups);
+        test_gpu_time = dwalltime() - t;
+        t = dwalltime();
+        cpu_groups(0, test_groups);
+        test_cpu_time = dwalltime() - t;
+    }
+    const double test_vd = (double)padded(0, test_groups);
+    const double cpu_gcups = q.Q * test_vd / (test_cpu_time * 1e9), gpu_gcups = q.Q * test_vd / (test_gpu_time * 1e9);
+    printf("Test DB percentage:\t\t%.4lf%% \n", o.test_db_percentage);
+    printf("CPU estimated speed:\t\t%.2lf GCUPS\n", cpu_gcups);
+    printf("FPGA estimated speed:\t\t%.2lf GCUPS\n", gpu_gcups);
+    const double gpu_pow = gpu_gcups / (gpu_gcups + cpu_gcups);
+    // the accelerator takes groups [test_groups, split) = gpu_pow of the remaining padded residues
+    uint64_t split = test_groups;
+    {
+        const double want = gpu_pow * (double)padded(test_groups, G);
+        double have = 0;
+        for (const oswald::Chunk &c : db.chunks)
+            for (uint64_t g = std::max(test_groups, c.accum); g < c.accum + c.n.size() && have < want; ++g) { have += (double)c.n[g - c.accum] * W; split = g + 1; }
+    }
+    const double tick = dwalltime();
+    {
+        std::thread gpu([&] { gpu_groups(test_groups, split); });
+        cpu_groups(split, G);
+        gpu.join();
+    }
+    const double work_time = dwalltime() - tick;
+    oswald_hip_finalize(ctx);
+    std::vector<std::vector<int32_t>> top_s;
+    std::vector<std::vector<uint64_t>> top_i;
+    tops_from_table(o, db, scores, nq, top_s, top_i);
+    print_report(o, q, db, top_s, top_i, current_time, work_time, work_time + std::max(test_gpu_time, test_cpu_time));
+    return 0;
+}
+
+int do_search(Options &o)
+{
+    if (o.execution_mode == 2) return do_search_host_only(o);
+    if (o.execution_mode == 1) return do_search_hybrid(o);
+    const time_t current_time = time(nullptr);
+    printf("\nOSWALD v%s \n\n", oswald::kVersion);
+    printf("Database file:\t\t\t%s\n", o.db);
     const bool phases = getenv("OSWALD_DEBUG_PHASES") != nullptr; // wall time of the host-side phases, to stderr
     double tp = dwalltime();
     auto lap = [&](const char *what) { if (phases) { const double t = dwalltime(); fprintf(stderr, "[oswald] %-34s %8.3f ms\n", what, (t - tp) * 1e3); tp = t; } };
@@ -184,12 +391,7 @@ int do_search(Options &o)
     lap("load database + assemble chunks");
     const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength;
 
-    printf("Database size:\t\t\t%ld sequences (%ld residues) \n", (long)db.sequences_count, (long)db.D);
-    printf("Longest database sequence: \t%d residues\n", db.sequences_db_max_length);
-    printf("Substitution matrix:\t\t%s\n", o.submat_name.c_str());
-    printf("Gap open penalty:\t\t%d\n", o.open_gap);
-    printf("Gap extend penalty:\t\t%d\n", o.extend_gap);
-    printf("Query filename:\t\t\t%s\n", o.queries);
+    print_header(o, db);
 
     if (db.sequences_count < o.top) o.top = db.sequences_count;
     // The report needs the top-r scores per query only.  For r <= 1024 they are selected on the device, chunk
@@ -204,7 +406,7 @@ int do_search(Options &o)
 
     // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80)
     oswald_hip_ctx *ctx = nullptr;
-    check(oswald_hip_init((int)o.num_devices, nullptr, &ctx), "device bring-up");
+    check(bring_up(o, &ctx), "device bring-up");
     check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space"); // buffers sized before the clock starts, FPGAsearch.c:85-96
     lap("device bring-up");
     const double tick = dwalltime();
@@ -282,33 +484,8 @@ int do_search(Options &o)
         wanted.insert(wanted.end(), ti.begin(), ti.end());
     }
     lap("top scores");
-    const std::vector<std::string> headers = oswald::load_database_headers_at(o.db, wanted);
-    lap("load headers");
-    size_t hpos = 0;
-    for (uint64_t i = 0; i < nq; ++i) {
-        printf("\nQuery no.\t\t\t%d\n", (int)i + 1);
-        printf("Query description: \t\t%s\n", q.titles[i].c_str() + 1);
-        printf("Query length:\t\t\t%d residues\n", q.m[i]);
-        printf("\nScore\tSequence description\n");
-        for (size_t j = 0; j < top_s[i].size(); ++j) {
-            const std::string &h = headers[hpos++];
-            printf("%d\t%s\n", top_s[i][j], h.empty() ? "" : h.c_str() + 1);
-        }
-    }
-    lap("report");
-    printf("\nSearch date:\t\t\t%s", ctime(&current_time));
-    printf("Search time:\t\t\t%lf seconds\n", workTime);
-    printf("Search speed:\t\t\t%.2lf GCUPS\n", (double)(q.Q * db.D) / (workTime * 1000000000));
-    printf("CPU threads:\t\t\t%d\n", o.cpu_threads);
-    printf("CPU vector length:\t\t%d\n", 16);
-    printf("CPU block width:\t\t%d\n", o.cpu_block_size);
-    printf("Number of FPGAs:\t\t%u\n", o.num_devices);
-    printf("FPGA vector length:\t\t%d\n", oswald::kFpgaVectorLength);
-    printf("FPGA block width:\t\t%d\n", oswald::kFpgaBlockWidth);
-    printf("Max. chunk size in FPGA:\t%ld bytes\n", (long)o.max_chunk_size);
-    // (not part of the reference's report, FPGAsearch.c:327-331: only on request)
-    if (getenv("OSWALD_REPORT_ACCELERATOR"))
-        printf("Accelerator:\t\t\t%u x AMD Instinct GPU via HIP (the \"FPGA\" lines above describe the input layout)\n", o.num_devices);
+    print_report(o, q, db, top_s, top_i, current_time, workTime, workTime);
+    lap("headers + report");
     return 0;
 }
 
@@ -328,7 +505,7 @@ int main(int argc, char *argv[])
         {"sm", 's', "<string>", 0, "Substitution matrix. Supported values: blosum45, blosum50, blosum62, blosum80, blosum90, pam30, pam70, pam250 (default: blosum62).", 3},
         {"gap_open", 'g', "<integer>", 0, "Gap open penalty (default: 10).", 3},
         {"gap_extend", 'e', "<integer>", 0, "Gap extend penalty (default: 2).", 3},
-        {"execution_mode", 'm', "<integer>", 0, "0 for accelerator mode, 1 for hybrid mode (accepted, runs as 0) (default: 1).", 3},
+        {"execution_mode", 'm', "<integer>", 0, "0 for accelerator mode, 1 for hybrid mode (host + accelerator), 2 or host-only for host mode (default: 1).", 3},
         {"cpu_threads", 'c', "<integer>", 0, "Number of CPU threads (default: 4).", 3},
         {"vector_length", 'v', "<integer>", 0, "Vector length in host: 16 or 32 (accepted for compatibility) (default: 16).", 3},
         {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (accepted for compatibility) (default: 256).", 3},

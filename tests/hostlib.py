@@ -73,6 +73,15 @@ def assemble(dbname, W=16, max_chunk=134217728, ndev=1):
     return r
 
 
+def host_search_chunk(chunk, nq, groups, matrix, go, ge, threads=4):
+    """oswald::host_search_groups (the `-m 2` / hybrid host kernel) on a chunk of the database assembled last, for
+    the queries loaded last: int32 [nq][groups*16]."""
+    out = np.zeros((nq, groups * 16), np.int32)
+    if load().oswald_host_search_chunk(chunk, matrix.encode(), go, ge, threads, out.ctypes.data_as(C.c_void_p)):
+        raise RuntimeError(load().oswald_host_last_error().decode())
+    return out
+
+
 def from_cache():
     """Did the last assemble() take its chunks from <db>.g16?"""
     return bool(load().oswald_host_db_from_cache())

@@ -88,7 +88,32 @@ def test_cli_info_and_footer(tmp_path):
     assert lines[i].startswith("Search date:\t\t\t")
     assert re.fullmatch(r"Search time:\t\t\t\d+\.\d{6} seconds", lines[i + 1])
     assert re.fullmatch(r"Search speed:\t\t\t\d+\.\d\d GCUPS", lines[i + 2])
+    assert lines[i + 10] == ""      # nothing after the reference's last footer line
     assert lines[i + 3:i + 10] == ["CPU threads:\t\t\t7", "CPU vector length:\t\t16", "CPU block width:\t\t128", "Number of FPGAs:\t\t1",
                                    "FPGA vector length:\t\t16", "FPGA block width:\t\t28", "Max. chunk size in FPGA:\t134217728 bytes"]
     # -r larger than the database is clipped to the database size (reference FPGAsearch.c:68)
     assert sum(1 for l in lines if re.match(r"^\d+\tsyn\|", l)) == 64
+
+
+@pytest.mark.parametrize("ndev", [1, 2])
+def test_cli_hybrid_mode_equals_accelerator_mode(tmp_path, ndev):
+    """`-m 1` (the reference's default): a test portion of the database on both sides, the rest divided in the
+    measured proportion, host and GPU at the same time (HybridSearch.c:124-228, :620-631).  Same query sections as
+    `-m 0`, plus the three calibration lines of the reference's hybrid report."""
+    qs = synth.make_queries([150, 61, 300], seed=41)
+    L, R, O = synth.make_database(2000, qs, seed=43, homologs_per_query=3)
+    synth.write_fasta(str(tmp_path / "db.fasta"), [R[O[i]:O[i + 1]] for i in range(2000)])
+    synth.write_fasta(str(tmp_path / "q.fasta"), qs)
+    db = str(tmp_path / "db")
+    subprocess.run([hostlib.CLI, "-O", "preprocess", "-i", str(tmp_path / "db.fasta"), "-o", db], check=True, capture_output=True)
+    common = ["-q", str(tmp_path / "q.fasta"), "-d", db, "-r", "15", "-k", "300000"]
+    gpu = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0"] + common, capture_output=True, text=True)
+    assert gpu.returncode == 0, gpu.stderr
+    # (run ndev context devices on the one GPU of the box)
+    hyb = subprocess.run([hostlib.CLI, "-O", "search", "-m", "1", "-p", "0.05", "-c", "8", "-f", str(ndev)] + common, capture_output=True, text=True,
+                         env=dict(os.environ, OSWALD_DEVICE_IDS=",".join(["0"] * ndev)))
+    assert hyb.returncode == 0, hyb.stderr
+    assert parse_report(hyb.stdout) == parse_report(gpu.stdout)
+    assert re.search(r"Test DB percentage:\t\t0\.0500% \nCPU estimated speed:\t\t\d+\.\d\d GCUPS\nFPGA estimated speed:\t\t\d+\.\d\d GCUPS\n", hyb.stdout)
+    host = subprocess.run([hostlib.CLI, "-O", "search", "-m", "2", "-c", "8"] + common, capture_output=True, text=True)
+    assert host.returncode == 0 and parse_report(host.stdout) == parse_report(gpu.stdout)
