@@ -50,10 +50,14 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9                 # max clock (MI355X_MICROARCH.md)
 N_CU = 256
 SIMD_PER_CU = 4
-PK_ISSUE_CYCLES = 4.0            # packed 16-bit VOP3P: one wave instruction per 4 cycles per SIMD (profiles/r02_oprate_valu_issue.txt: 4.25)
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
 PK_OPS_PER_ROW = {16: (7.5, 6.5), 32: (24.0, 24.0), 8: (26.5, 26.5)}  # 8: ~53 SWAR instructions per 2 x 2 tile row = 256 cells
+# ... and what such a row costs in core-clock cycles per SIMD at 4 waves per SIMD.  int16: MEASURED on the cell's own
+# instruction mix (tools/oprate2.hip, profiles/r02_oprate2_valu_mix.txt: 3.5 VOP3P + 3 VOP2 = 25.3 cycles for the query-pair
+# row; the sequence-pair row keeps the packed add and has a v_perm_b32: 26.3 + 4.25); int32 / int8: instructions x 4.25
+# resp. x 3 (mostly 2-cycle VOP2 in a mix), estimates.
+ROW_CYCLES = {16: (30.5, 25.3), 32: (102.0, 102.0), 8: (80.0, 80.0)}
 DTYPE = {16: "int16", 32: "int32", 8: "int8"}
 CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells",
               8: "int8 cells (four 7-bit SWAR cells per register) with int16 re-run of what leaves their range, int32 above"}
@@ -217,7 +221,8 @@ def main():
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         kern_gcups = sum_m * d_local * args.steps / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
         ops_row = PK_OPS_PER_ROW[cell_bits][1 if nq > 1 else 0]  # a multi-query search runs (mostly) as query pairs
-        valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / PK_ISSUE_CYCLES) * 128.0 / ops_row / 1e9
+        row_cycles = ROW_CYCLES[cell_bits][1 if nq > 1 else 0]
+        valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / row_cycles) * 128.0 / 1e9
         kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
         traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None)
         cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1"}[args.workload]
@@ -237,8 +242,8 @@ def main():
                          "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launches_per_step": round(nlaunch / max(1, args.steps), 2),
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
-                                  "instr_per_128_cells": ops_row,
-                                  "note": "the DP is VALU-issue bound: instr_per_128_cells VALU instructions per wave per query row (query-pair cell for a multi-query search), one packed 16-bit instruction per 4 cycles per SIMD"}},
+                                  "instr_per_128_cells": ops_row, "cycles_per_128_cells": row_cycles,
+                                  "note": "the DP is VALU-issue bound: instr_per_128_cells VALU instructions per wave per query row (query-pair cell for a multi-query search) issue in cycles_per_128_cells core-clock cycles per SIMD (measured on the cell's instruction mix, profiles/r02_oprate2_valu_mix.txt); ceiling = 1024 SIMDs x 2.4 GHz / that x 128"}},
             # the north star's ">= 0.5 x HBM roofline" is only well posed under the reference's own traffic
             # model, 1 B of substitution score per cell streamed from device DRAM (sw.cl:57): 8 TB/s = 8000 GCUPS
             "reference_traffic_model": {"bytes_per_cell": 1.0, "roofline_gcups": HBM_PEAK_GBS, "frac": round(gcups / world / HBM_PEAK_GBS, 4)},
