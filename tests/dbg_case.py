@@ -1,7 +1,7 @@
 """Debug aid: small GPU-vs-oracle comparisons at forced geometries (run on the GPU box)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from oswald_amd import capi, submat, synth
 from oracle import pyoracle

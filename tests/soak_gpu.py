@@ -1,9 +1,9 @@
 """Soak: many searches with changing query sets against one resident database, every score checked against the
-CPU port (oracle), plus repeated identical searches (determinism).  Run on the GPU box: python tools/soak.py [iters]."""
+CPU port (oracle), plus repeated identical searches (determinism).  Test infrastructure (it checks against oracle/, so it lives under tests/).  Run on the GPU box: python tests/soak_gpu.py [iters]."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oswald_amd import capi, submat, synth, dblayout
 from oracle import pyoracle
 from helpers import pack_queries
@@ -32,7 +32,7 @@ for it in range(iters):
     a, m, ad = pack_queries(qs)
     sm = submat.load(mats[it % len(mats)])
     go, ge = int(rng.integers(0, 20)), int(rng.integers(0, 6))
-    bits = [0, 16, 32, 0][it % 4] if it % 8 == 2 else 0
+    bits = [0, 16, 32, 8][(it // 3) % 4] if it % 3 == 2 else 0   # every third search in an explicit cell mode, 8-bit included
     ctx.set_scoring(sm, go, ge, bits)
     ctx.set_queries(a, m, ad)
     if h is None:
