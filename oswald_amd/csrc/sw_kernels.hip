@@ -1172,7 +1172,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
 // Every (query, sequence) that left the 7-bit range is queued for the packed-int16 kernel, which re-runs the
 // two lanes (four sequences) around it at geometry 32 and queues what reaches ITS ceiling for the int32 kernel.
 // ---------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_q8(OswSearchArgs p)
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_q8(OswSearchArgs p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS8 * 8 + OSW_LDS_SKEW8];
     const int lane = threadIdx.x & 63;
