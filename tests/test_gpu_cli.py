@@ -35,7 +35,8 @@ def parse_report(text):
     return blocks
 
 
-@pytest.mark.parametrize("matrix,go,ge,extra", [("blosum62", 10, 2, []), ("pam250", 14, 2, ["-k", "60000"])])
+@pytest.mark.parametrize("matrix,go,ge,extra", [("blosum62", 10, 2, []), ("pam250", 14, 2, ["-k", "60000"]),
+                                                ("blosum62", 10, 2, ["-k", "60000", "-f", "2"])])   # two context devices: async uploads per round
 def test_cli_search_report(tmp_path, oracle, matrix, go, ge, extra):
     qs = synth.make_queries([120, 45, 300], seed=3)
     L, R, O = synth.make_database(600, qs, seed=9, homologs_per_query=4)
@@ -46,7 +47,8 @@ def test_cli_search_report(tmp_path, oracle, matrix, go, ge, extra):
     db = str(tmp_path / "db")
     subprocess.run([hostlib.CLI, "-O", "preprocess", "-i", str(tmp_path / "db.fasta"), "-o", db], check=True, capture_output=True)
     p = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-q", str(tmp_path / "q.fasta"), "-d", db, "-s", matrix,
-                        "-g", str(go), "-e", str(ge), "-r", "7"] + extra, capture_output=True, text=True)
+                        "-g", str(go), "-e", str(ge), "-r", "7"] + extra, capture_output=True, text=True,
+                       env=dict(os.environ, OSWALD_DEVICE_IDS="0,0"))   # (used only with -f 2: both on the box's one GPU)
     assert p.returncode == 0, p.stderr
     out = p.stdout
     assert out.startswith("\nOSWALD v1.0 \n\nDatabase file:\t\t\t" + db + "\n")
