@@ -36,3 +36,28 @@ def test_bench_line_schema(first_pass):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["gpu_scores_equal_on_sample"] is True
     assert d["value"] > 100 and d["dtype"] == "int16"
+
+
+def _bench(args, env):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_sharded_ranks_rehearsal(first_pass):
+    """`bench.py --gpus 2` started bare: it spawns its two ranks (one process per rank, here sharing the box's one
+    GPU, top-r gather over gloo instead of RCCL), shards ONE database by the reference's chunk rule and reports
+    strong scaling; the merged top-1 scores are those of the single-GPU run on the same database."""
+    if first_pass != "i16":
+        pytest.skip("one run is enough")
+    env = dict(os.environ)
+    env.pop("OSWALD_HIP_CELL_BITS", None)
+    common = ["--steps", "2", "--warmup", "1", "--nseq", "40000", "--cpu-seconds", "0", "--max-chunk", "4000000"]
+    one = _bench(["--gpus", "1"] + common, env)
+    two = _bench(["--gpus", "2"] + common, dict(env, OSWALD_BENCH_BACKEND="gloo", MASTER_PORT="29611"))
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "sharded over 2 GPUs" in two["config"]["sharding"]
+    assert one["config"]["chunks_rank0"] >= 3 and two["config"]["chunks_rank0"] >= 2          # several chunks, dealt round-robin
+    assert two["config"]["db_residues_total"] == one["config"]["db_residues_total"]            # one database, not one per rank
+    assert two["top1_scores"] == one["top1_scores"] and two["value"] > 100
