@@ -334,35 +334,45 @@ int do_search_hybrid(Options &o)
             if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, o.cpu_threads, scores.data(), row, a0 * W);
         }
     };
-    // test portion: both sides, at the same time (the host's scores are the ones kept)
+    // Test portion.  The host searches the first -p of the groups, as in the reference.  The accelerator's speed
+    // cannot be read off so small a portion (a launch has a fixed cost of about a millisecond: 1 % of a 100 000-sequence
+    // database would rate an MI355X at 60 GCUPS): it goes on from the start of the database in portions of doubling
+    // size until one takes 20 ms, and that one is its measurement.  Everything it computed on the way is final.
     const uint64_t test_groups = std::min<uint64_t>(G, std::max<uint64_t>(1, (uint64_t)(o.test_db_percentage * (double)G)));
-    double test_gpu_time = 0, test_cpu_time = 0;
+    double test_gpu_time = 0, test_cpu_time = 0, gpu_gcups = 0;
+    uint64_t gpu_done = 0;
+    for (uint64_t n = test_groups; gpu_done < G; n *= 2) {
+        const uint64_t g1 = std::min<uint64_t>(G, gpu_done + n);
+        const double t = dwalltime();
+        gpu_groups(gpu_done, g1);
+        const double dt = dwalltime() - t;
+        gpu_gcups = q.Q * (double)padded(gpu_done, g1) / (dt * 1e9);
+        test_gpu_time += dt;
+        gpu_done = g1;
+        if (dt >= 0.02) break;
+    }
     {
-        // (one after the other: both write the same table columns -- the same scores; the host's pass is the one kept)
-        double t = dwalltime();
-        gpu_groups(0, test_groups);
-        test_gpu_time = dwalltime() - t;
-        t = dwalltime();
+        // (the same table columns the accelerator has just filled -- the same scores)
+        const double t = dwalltime();
         cpu_groups(0, test_groups);
         test_cpu_time = dwalltime() - t;
     }
-    const double test_vd = (double)padded(0, test_groups);
-    const double cpu_gcups = q.Q * test_vd / (test_cpu_time * 1e9), gpu_gcups = q.Q * test_vd / (test_gpu_time * 1e9);
+    const double cpu_gcups = q.Q * (double)padded(0, test_groups) / (test_cpu_time * 1e9);
     printf("Test DB percentage:\t\t%.4lf%% \n", o.test_db_percentage);
     printf("CPU estimated speed:\t\t%.2lf GCUPS\n", cpu_gcups);
     printf("FPGA estimated speed:\t\t%.2lf GCUPS\n", gpu_gcups);
     const double gpu_pow = gpu_gcups / (gpu_gcups + cpu_gcups);
-    // the accelerator takes groups [test_groups, split) = gpu_pow of the remaining padded residues
-    uint64_t split = test_groups;
+    // the accelerator takes groups [gpu_done, split) = gpu_pow of the remaining padded residues, the host the rest
+    uint64_t split = gpu_done;
     {
-        const double want = gpu_pow * (double)padded(test_groups, G);
+        const double want = gpu_pow * (double)padded(gpu_done, G);
         double have = 0;
         for (const oswald::Chunk &c : db.chunks)
-            for (uint64_t g = std::max(test_groups, c.accum); g < c.accum + c.n.size() && have < want; ++g) { have += (double)c.n[g - c.accum] * W; split = g + 1; }
+            for (uint64_t g = std::max(gpu_done, c.accum); g < c.accum + c.n.size() && have < want; ++g) { have += (double)c.n[g - c.accum] * W; split = g + 1; }
     }
     const double tick = dwalltime();
     {
-        std::thread gpu([&] { gpu_groups(test_groups, split); });
+        std::thread gpu([&] { gpu_groups(gpu_done, split); });
         cpu_groups(split, G);
         gpu.join();
     }
