@@ -529,3 +529,29 @@ def test_int8_falls_back_to_int16_when_penalties_do_not_fit(hip_ctx, oracle):
     got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 200, 70, cell_bits=8)
     np.testing.assert_array_equal(got, expect(oracle, qs, b, n, disp, 16, sm, 200, 70))
     assert hip_ctx.rerun_counts()[0] == 0
+
+
+def test_api_misuse_of_the_round2_entry_points(hip_ctx):
+    """Errors are reported through the return code and oswald_hip_last_error(), never swallowed."""
+    from oswald_amd import capi
+    sm = submat.load("blosum62")
+    qs = synth.make_queries([40], seed=2)
+    a, m, ad = pack_queries(qs)
+    L, R, O = random_db(50, seed=3, max_len=60)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    hip_ctx.set_scoring(sm, 10, 2)
+    hip_ctx.set_queries(a, m, ad)
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.reserve(1000, dev=7)                       # device index out of range
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.set_scoring(sm, 10, 2, 12)                  # cell_bits must be 0, 8, 16 or 32
+    h = hip_ctx.chunk_upload(b, n, disp, 16, wait=False)
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_topr(h, 50, 3)                        # not searched yet
+    hip_ctx.chunk_release(h)                                # releasing a chunk whose upload is still queued is fine
+    hip_ctx.wait()
+    hip_ctx.reserve(65520)                                  # the longest sequence the formats allow
+    out = np.zeros((1, len(n) * 16), np.int32)
+    hip_ctx.search_chunk_async(b, n, disp, out, 16)
+    hip_ctx.wait()
+    assert out.max() > 0
