@@ -987,6 +987,14 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             sum_end += e;
         }
         fprintf(stderr, "[oswald_hip] DP launch span %.1f us over %u workgroups; mean finish at %.0f%% of span\n", span, grid, 100.0 * sum_end / grid / span);
+        {
+            uint32_t ctr[8] = {0};
+            HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
+            // waves x span in core-clock cycles (2.4 GHz nominal) against the cycles spent in the slice reloads of workgroup items
+            const double wave_cycles = (double)grid * 4.0 * span * 2400.0;
+            fprintf(stderr, "[oswald_hip]   workgroup items: slice reload + barrier waits %.3g cycles = %.1f%% of all wave time\n",
+                    (double)ctr[4] * 1024.0, 100.0 * (double)ctr[4] * 1024.0 / wave_cycles);
+        }
         fprintf(stderr, "[oswald_hip]   phase-1 exits by decile:");
         for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_p1[k]);
         fprintf(stderr, "\n[oswald_hip]   finishes by decile:    ");

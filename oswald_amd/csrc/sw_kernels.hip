@@ -932,11 +932,14 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
         if (wg) {
+            // (diagnostics, OSWALD_HIP_DEBUG_TIMES: core-clock cycles this wave spends in the slice reload incl. both barriers)
+            const unsigned long long tb = p.wg_times ? __builtin_readcyclecounter() : 0ull;
             __syncthreads(); // every wave is done with the previous slice
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
             fill_profile_slice<Entry>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
             __syncthreads();
+            if (p.wg_times && lane == 0) atomicAdd(&p.counters_ovf[4], (uint32_t)((__builtin_readcyclecounter() - tb) >> 10));
         } else {
             // only this wave touches its region; LDS operations of one wave execute in order, the wave barriers
             // only pin the compiler's order
