@@ -19,7 +19,8 @@ ctx.set_scoring(submat.load("blosum62"), 10, 2)
 ctx.set_queries(a, m, ad)
 for world in worlds:
     times, res = [], []
-    for rank in range(world):
+    only = os.environ.get("ONLY_RANK")
+    for rank in ([int(only)] if only is not None else range(world)):
         sh = multigpu.ShardedDatabase(plan, 16, max_chunk, world, rank)
         chunks = [sh.chunk(k) for k in range(len(sh.mine))]
         hs = [ctx.chunk_upload(c["b"], c["n"], c["disp"], 16) for c in chunks]
