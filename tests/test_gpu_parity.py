@@ -47,7 +47,10 @@ def test_small_databases_all_group_shapes(hip_ctx, oracle, nseq):
 
 
 @pytest.mark.parametrize("matrix,go,ge", [("blosum62", 10, 2), ("pam250", 14, 2), ("blosum45", 0, 0), ("pam30", 30, 5), ("blosum90", 3, 1),
-                                          ("blosum62", 200, 70), ("blosum62", 3, 60), ("blosum62", 0, 9), ("blosum62", 1000, 1000)])
+                                          ("blosum62", 200, 70), ("blosum62", 3, 60), ("blosum62", 0, 9), ("blosum62", 1000, 1000),
+                                          # gap open around 1024: beyond it the column-frame cell's 32-bit subtract of the penalty could borrow
+                                          # across the halves of the packed pair, so the kernel must take the plain cell (osw_frame_cell_takes)
+                                          ("blosum62", 1023, 1), ("blosum62", 1024, 0), ("blosum62", 1025, 1), ("pam250", 2000, 2)])
 def test_matrices_and_gaps(hip_ctx, oracle, matrix, go, ge):
     qs = synth.make_queries([50, 129, 375], seed=5)
     L, R, O = random_db(200, seed=77, max_len=400, queries=qs, homologs=3)
