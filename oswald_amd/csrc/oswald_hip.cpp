@@ -86,6 +86,7 @@ struct Chunk {
     const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     std::vector<uint16_t> sub_cols;     // host copy of the live extents (see osw_block_extent), for the planner
+    std::vector<OswBlock> blocks_host;  // source of the asynchronous upload of the block table: must outlive it
     uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
     uint32_t nitems_q = 0, nitems_q_wg = 0; // the same for the query-pair kernel's queue
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
@@ -757,7 +758,8 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     c.nblocks = (ngroups + gpb - 1) / gpb;
     c.score_stride = c.nblocks * OSW_BLOCK_SEQS;
     c.ncols4_alloc.assign(c.nblocks, 0);
-    std::vector<OswBlock> blocks(c.nblocks);
+    std::vector<OswBlock> &blocks = c.blocks_host; // (a member: oswald_hip_chunk_upload_async returns before the copy has run)
+    blocks.assign(c.nblocks, OswBlock{});
     uint64_t off = OSW_TILED_PAD_GROUPS; // all-dummy columns in front of the first block
     c.max_ncols4 = 0;
     for (uint32_t B = 0; B < c.nblocks; ++B) {
