@@ -338,7 +338,15 @@ int do_search_hybrid(Options &o)
     // cannot be read off so small a portion (a launch has a fixed cost of about a millisecond: 1 % of a 100 000-sequence
     // database would rate an MI355X at 60 GCUPS): it goes on from the start of the database in portions of doubling
     // size until one takes 20 ms, and that one is its measurement.  Everything it computed on the way is final.
-    const uint64_t test_groups = std::min<uint64_t>(G, std::max<uint64_t>(1, (uint64_t)(o.test_db_percentage * (double)G)));
+    // (the reference sizes the test portion in residues, test_chunk_size = D x p, sequences.c:680: the shortest groups that hold them)
+    uint64_t test_groups = 0;
+    {
+        const double want = o.test_db_percentage * (double)db.vD;
+        double have = 0;
+        for (const oswald::Chunk &c : db.chunks)
+            for (uint64_t g = 0; g < c.n.size() && have < want; ++g) { have += (double)c.n[g] * W; ++test_groups; }
+        test_groups = std::min<uint64_t>(G, std::max<uint64_t>(1, test_groups));
+    }
     double test_gpu_time = 0, test_cpu_time = 0, gpu_gcups = 0;
     uint64_t gpu_done = 0;
     for (uint64_t n = test_groups; gpu_done < G; n *= 2) {
