@@ -227,6 +227,28 @@ void interleave_groups(const std::vector<uint16_t> &len, const uint8_t *residues
     }
 }
 
+// CRC-32 of 256 evenly spaced 4 KiB pieces of the residue area of <db>.seq (all of it when it is smaller): cheap
+// enough for every search, and a database rebuilt with the same sequence lengths but other residues is caught
+uint32_t residue_sample_crc(const std::string &seq_path, uint64_t count, uint64_t D)
+{
+    FILE *f = fopen(seq_path.c_str(), "rb");
+    if (!f) return 0;
+    const uint64_t base = count * sizeof(uint16_t), piece = 4096, pieces = 256;
+    std::vector<uint8_t> buf;
+    if (D <= piece * pieces) {
+        buf.resize(D);
+        if (fseek(f, (long)base, SEEK_SET) != 0 || fread(buf.data(), 1, buf.size(), f) != buf.size()) buf.clear();
+    } else {
+        buf.resize(piece * pieces);
+        for (uint64_t k = 0; k < pieces; ++k) {
+            const uint64_t off = base + (D - piece) / (pieces - 1) * k;
+            if (fseek(f, (long)off, SEEK_SET) != 0 || fread(buf.data() + k * piece, 1, piece, f) != piece) { buf.clear(); break; }
+        }
+    }
+    fclose(f);
+    return buf.empty() ? 0u : crc32_of(buf.data(), buf.size());
+}
+
 size_t cache_payload_offset(uint64_t groups) { return (sizeof(GroupCacheHeader) + groups * sizeof(uint16_t) + 63) / 64 * 64; }
 
 } // namespace
@@ -262,6 +284,7 @@ void write_group_cache(const std::string &sequences_filename)
     h.vD = gdisp[G];
     h.seq_file_bytes = seq_bytes;
     h.lengths_crc32 = crc32_of((const uint8_t *)len.data(), len.size() * sizeof(uint16_t));
+    h.residues_crc32 = residue_sample_crc(sequences_filename + ".seq", N, info.D);
     const std::string tmp = sequences_filename + ".g16.tmp";
     {
         std::ofstream f(tmp, std::ios::binary);
@@ -318,6 +341,7 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
             const bool ok = !memcmp(h.magic, "OSWG16\0\0", 8) && h.version == 1 && h.vector_length == (uint32_t)W && h.sequences_count == N &&
                             h.D == db.D && h.groups == G && h.vD == db.vD && seq_ok && mf->bytes == cache_payload_offset(G) + db.vD &&
                             h.lengths_crc32 == crc32_of((const uint8_t *)len.data(), len.size() * sizeof(uint16_t)) &&
+                            h.residues_crc32 == residue_sample_crc(sequences_filename + ".seq", N, db.D) &&
                             !memcmp(mf->p + sizeof h, n.data(), n.size() * sizeof(uint16_t));
             if (ok) {
                 db.cache = mf;

@@ -51,7 +51,7 @@ PreprocessStats preprocess_db(const std::string &input_filename, const std::stri
 // length (reference host/src/sequences.c:457-498).  The layout does not depend on the chunk plan (a chunk is a
 // run of whole groups), so a search maps the file and hands slices of it to the device, whatever -k / -f say.
 // <db>.seq stays the canonical database; the cache is used only if it matches it (count, D, size of the .seq
-// file, CRC-32 of its length table), else it is ignored and the groups are interleaved from <db>.seq.
+// file, CRC-32 of its length table and of a sample of its residues), else it is ignored and the groups are interleaved from <db>.seq.
 struct GroupCacheHeader {
     char magic[8];          // "OSWG16\0\0"
     uint32_t version;       // 1
@@ -59,7 +59,7 @@ struct GroupCacheHeader {
     uint64_t sequences_count, D, groups, vD;
     uint64_t seq_file_bytes;
     uint32_t lengths_crc32; // of the uint16 length table of <db>.seq
-    uint32_t reserved;
+    uint32_t residues_crc32;// of a sample of its residues: 256 evenly spaced 4 KiB pieces
 };                          // followed by uint16 n[groups], zero padding to a multiple of 64 B, then uint8 b[vD]
 static_assert(sizeof(GroupCacheHeader) == 64, "on-disk header");
 // Writes <db>.g16 from <db>.info / <db>.seq (also usable on a database preprocessed by the reference).

@@ -153,6 +153,17 @@ def test_group_cache_equals_interleave(tmp_path, monkeypatch):
     again = hostlib.assemble(db, 16, 134217728, 1)
     assert hostlib.from_cache()
     np.testing.assert_array_equal(again["chunks"][0]["b"], stale["chunks"][0]["b"])
+    # the database rebuilt with the same lengths but other residues (same .info, same .seq size, same length table)
+    with open(db + ".seq", "r+b") as f:
+        f.seek(2 * 1000 + 777)
+        byte = f.read(1)
+        f.seek(2 * 1000 + 777)
+        f.write(bytes([(byte[0] + 1) % 23]))
+    changed = hostlib.assemble(db, 16, 134217728, 1)
+    assert not hostlib.from_cache() and not np.array_equal(changed["chunks"][0]["b"], again["chunks"][0]["b"])
+    hostlib.write_group_cache(db)
+    hostlib.assemble(db, 16, 134217728, 1)
+    assert hostlib.from_cache()
     # truncated cache file
     with open(db + ".g16", "r+b") as f:
         f.truncate(os.path.getsize(db + ".g16") - 5)
