@@ -74,9 +74,9 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--max-chunk", type=int, default=134217728, help="chunk size limit in bytes (the reference's -k, default 128 MiB)")
-    ap.add_argument("--cell-bits", type=int, default=16, choices=[8, 16, 32],
+    ap.add_argument("--cell-bits", type=int, default=0, choices=[0, 8, 16, 32],
                     help="cell arithmetic: 16 = packed int16 (the cells BASELINE.json configs[1] names; the library's default), 32 = int32 only, "
-                         "8 = SWAR 8-bit first pass with int16 re-run (configs[2])")
+                         "8 = SWAR 8-bit first pass with int16 re-run (configs[2]); default: 8 for --workload c3 (the cell mode that configuration names), else 16")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
     ap.add_argument("--write-top-golden", action="store_true", help="N = 1 only: write tests/golden/bench_top_<workload>_<nseq>.json")
@@ -161,7 +161,7 @@ def main():
     index_base = 0 if strong else rank * nseq_total      # weak mode: global index = shard base + sorted position
 
     ctx = capi.Context(1, [gpu])
-    cell_bits = args.cell_bits
+    cell_bits = args.cell_bits or (8 if args.workload == "c3" else 16)
     ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
     ctx.set_queries(a, m, a_disp)
     chunks = []          # resident chunks of this rank (+ their host arrays for the PCIe-inclusive leg)
