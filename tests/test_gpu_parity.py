@@ -558,3 +558,20 @@ def test_api_misuse_of_the_round2_entry_points(hip_ctx):
     hip_ctx.search_chunk_async(b, n, disp, out, 16)
     hip_ctx.wait()
     assert out.max() > 0
+
+
+@pytest.mark.parametrize("bits", [0, 8])
+def test_longest_queries(hip_ctx, oracle, bits):
+    """Queries of 30 000 and 65 535 residues (the longest a uint16 length allows; the reference's FPGA kernel stops at
+    5 478, sw.cl:5): hundreds of strips per lane group, many rounds, and a second query far shorter (pairs of very
+    different lengths in the 8-bit mode)."""
+    qs = [synth.random_residues(71, 0, 65535), synth.random_residues(72, 0, 30000), synth.random_residues(73, 0, 12)]
+    seqs = [synth.random_residues(300 + i, 0, 30 + 13 * i) for i in range(24)]
+    seqs.append(qs[1][10000:10400].copy())                # a 400-residue piece of the second query: exact score 2000+
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2, cell_bits=bits)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want[1].max() > 2000
