@@ -354,7 +354,7 @@ def test_pairing_is_invisible(hip_ctx, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("go,ge", [(10, 2), (0, 0), (5, 0), (3, 1)])
-@pytest.mark.parametrize("seq_len,qlen", [(9000, 300), (30000, 150)])
+@pytest.mark.parametrize("seq_len,qlen", [(9000, 300), (30000, 150), (65520, 120)])   # 65 520: the longest sequence the formats allow
 def test_very_long_sequences_with_multi_round_queries(hip_ctx, oracle, seq_len, qlen, go, ge):
     """Blocks longer than a wave's spill region holds at G = 1 (4096 columns): the planner must pick a
     geometry with fewer lanes per group, and the boundary row still has to come back exactly.
