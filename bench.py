@@ -12,20 +12,26 @@ the rate with the host buffers handed over inside the timed region (SURVEY 8d's
 region: upload + kernels + download) is reported next to it as
 `pcie_inclusive`, never as `value`.
 
-Workload
-  N = 1: BASELINE.json configs[1] (C2) -- 20 queries of length 100..1000 (sum
-         11 000) against a 100 000-sequence synthetic length-binned database
-         (~36.7 M residues), BLOSUM62, gap 10/2, int16 cells (packed, exact below
-         22256; sequences above are re-run in int32).
-  N > 1: BASELINE.json configs[3] (C4) -- the same queries against ONE
-         1 000 000-sequence database (~364.6 M residues), length-sorted once and
-         cut by the reference's rule (host/src/sequences.c:510-515: shards of
-         ceil(vD/ndev) padded residues; chunk c goes to device c mod ndev,
-         host/src/FPGAsearch.c:132-138).  Total work is fixed as N grows:
-         "scaling": "strong".  Database indices are positions in the globally
-         sorted database, so the merged top-10 is comparable across N
-         (tests/golden/bench_top_*.json holds the single-GPU result).
-  --nseq overrides the TOTAL number of database sequences for any N;
+Workload (default, every N): BASELINE.json configs[3] (C4), the configuration the
+  metric "GCUPS at 1/2/4/8 MI355X" is quoted on -- 20 queries of length 100..1000
+  (sum 11 000) against ONE 1 000 000-sequence synthetic length-binned database
+  (~364.6 M residues), BLOSUM62, gap 10/2, int16 cells (packed, exact below
+  22256; sequences above are re-run in int32).  It fits one GPU, so N = 1 runs the
+  same database as N = 2, 4, 8: one series, total work fixed as N grows
+  ("scaling": "strong").  The database is length-sorted once and divided among
+  the ranks (--shard-rule):
+    deal       (default) wave blocks of 128 consecutive sorted sequences dealt to
+               the ranks in alternating order (oswald_amd/multigpu.py): every
+               rank gets the same length distribution and they finish together;
+    reference  the reference's rule: contiguous shards of ceil(vD/ndev) padded
+               residues (host/src/sequences.c:510-515), chunk c to device c mod
+               ndev (host/src/FPGAsearch.c:132-138) -- the longest sequences all
+               land in the last shard.
+  Database indices are positions in the globally sorted database, so the merged
+  top-10 is the same list for every N and rule (tests/golden/bench_top_*.json
+  holds the single-GPU result; a mismatch fails the run).
+  --nseq overrides the TOTAL number of database sequences (--nseq 100000 =
+  BASELINE.json configs[1], C2); --workload c3 / c5 / q1 default to 100 000;
   --weak restores round 1's mode (an independent --nseq database per GPU).
 
 GCUPS = sum(query lengths) x unpadded database residues / seconds / 1e9, the
@@ -69,7 +75,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nseq", type=int, default=0, help="TOTAL database sequences (default: 100000 at --gpus 1 = C2, 1000000 at --gpus > 1 = C4); per GPU with --weak")
+    ap.add_argument("--nseq", type=int, default=0, help="TOTAL database sequences (default: 1000000 = C4 for the default workload at every --gpus, 100000 for c3 / c5 / q1; 100000 = C2); per GPU with --weak")
+    ap.add_argument("--shard-rule", default="deal", choices=["deal", "reference"], help="how the sorted database is divided among the ranks (see the module docstring)")
     ap.add_argument("--weak", action="store_true", help="round-1 mode: every rank searches its own independent --nseq database")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
     ap.add_argument("--top", type=int, default=10)
@@ -150,14 +157,14 @@ def main():
     # group lengths padded to x28).
     t0 = time.time()
     strong = not args.weak
-    nseq_total = args.nseq or (100000 if world == 1 or args.weak else 1000000)
+    nseq_total = args.nseq or (1000000 if args.workload == "c2" and not args.weak else 100000)
     if strong:
         plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB, 12)
         shard_world, shard_rank = world, rank
     else:
         plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB + 1000003 * rank, 12)
         shard_world, shard_rank = 1, 0
-    shard = multigpu.ShardedDatabase(plan, 16, args.max_chunk, shard_world, shard_rank)
+    shard = multigpu.ShardedDatabase(plan, 16, args.max_chunk, shard_world, shard_rank, args.shard_rule)
     index_base = 0 if strong else rank * nseq_total      # weak mode: global index = shard base + sorted position
 
     ctx = capi.Context(1, [gpu])
@@ -228,17 +235,21 @@ def main():
         kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
         traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None)
         cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1"}[args.workload]
-        shard_note = (f"one database sharded over {world} GPUs by the reference's chunk rule (chunk c -> GPU c mod {world}), "
+        if cfg_name == "C4" and world == 1:
+            cfg_name = "C4 database on one GPU"
+        rule_note = "128-sequence wave blocks dealt to the GPUs in alternating order" if args.shard_rule == "deal" else f"the reference's chunk rule (chunk c -> GPU c mod {world})"
+        shard_note = (f"one database sharded over {world} GPUs by {rule_note}, "
                       f"{'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}") if world > 1 and strong else \
                      (f"independent {nseq_total}-sequence database per GPU x{world}, {'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}" if world > 1 else "single GPU")
         result = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "timed_region": "search (DP kernels + int32 re-run) + device top-r + merge" + (" + all_gather" if world > 1 else "") + "; database resident in HBM; SURVEY 8d's region (upload + kernels + download) is pcie_inclusive",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": DTYPE[cell_bits], "data": "synthetic",
             "config": {"workload": f"{cfg_name}: " + wl["label"].format(nseq=nseq_total) + ", " + CELL_LABEL[cell_bits] + "; database resident in HBM (re-tiled) before the timed region",
                        "queries": nq, "query_residues": sum_m, "db_sequences_total": nseq_total * (1 if strong else world),
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
-                       "top": args.top, "sharding": shard_note, "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
+                       "top": args.top, "sharding": shard_note, "shard_rule": args.shard_rule, "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),

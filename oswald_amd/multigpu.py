@@ -1,8 +1,22 @@
 """Sharding of the search path over GPUs: one process per GPU, every rank owns
-one contiguous shard of the length-sorted database (the reference gives chunk
-c of a round to device c mod ndev, host/src/FPGAsearch.c:132-138, and merges
-by memcpy, :236-237); the only exchange is the gather of the per-rank top-r
-lists, which is what runs over RCCL/xGMI (backend "nccl") or gloo on CPUs.
+a shard of the length-sorted database; the only exchange is the gather of the
+per-rank top-r lists, which is what runs over RCCL/xGMI (backend "nccl") or
+gloo on CPUs.  Two shard rules:
+
+  "deal"       (default of bench.py) the database is dealt to the ranks in wave
+               blocks of 128 consecutive sorted sequences -- the unit one wave
+               of the search kernels works on -- in rounds of `world` blocks,
+               forwards in even rounds and backwards in odd ones (a rank that
+               got the shortest block of one round gets the longest of the
+               next).  Every rank then sees the whole length
+               distribution (same plan quality, same share of the longest
+               sequences), so the ranks finish together; the reference's rule
+               puts all the longest sequences into the last shard.
+  "reference"  contiguous shards of equal padded size: the reference gives chunk
+               c of a round to device c mod ndev (host/src/FPGAsearch.c:132-138)
+               after cutting the database into chunks of ceil(vD/ndev) padded
+               residues (host/src/sequences.c:510-515), and merges by memcpy
+               (FPGAsearch.c:236-237).  The CLI's -f uses this rule.
 
 Plumbing only: torch.distributed carries (score, global index) pairs; the
 ordering rule is the reference's (descending score, ties by descending index,
@@ -22,31 +36,66 @@ def rank_chunks(n_groups_len, W: int, max_chunk_size: int, world: int, rank: int
     return [p for c, p in enumerate(plan) if c % world == rank]
 
 
-class ShardedDatabase:
-    """A synthetic database (synth.DatabasePlan) sorted by length once and cut for `world` ranks by the
-    reference's rule (rank_chunks).  Every rank holds the plan of the whole database -- lengths only -- and
-    materialises, interleaves and uploads just its own chunks; database indices are positions in the globally
-    sorted database, whatever the number of ranks."""
+DEAL_BLOCK_SEQS = 128   # sequences per dealt unit = one wave block of the search kernels (sw_kernels.h OSW_BLOCK_SEQS)
 
-    def __init__(self, plan, W: int, max_chunk_size: int, world: int, rank: int):
-        self.plan, self.W = plan, W
+
+def dealt_positions(nseq: int, world: int, rank: int, block_seqs: int = DEAL_BLOCK_SEQS) -> np.ndarray:
+    """Sorted positions of the sequences rank `rank` owns under the "deal" rule.  Blocks are counted from the LONGEST
+    end (so that the incomplete last round holds the shortest sequences): of the blocks of round t it gets number
+    `rank` when t is even and number world - 1 - rank when t is odd.  Returned in ascending order."""
+    nblk = (nseq + block_seqs - 1) // block_seqs
+    t = np.arange((nblk + world - 1) // world, dtype=np.int64)
+    from_end = t * world + np.where(t % 2 == 0, rank, world - 1 - rank)
+    mine = (nblk - 1 - from_end[from_end < nblk])[::-1]
+    pos = (mine[:, None] * block_seqs + np.arange(block_seqs, dtype=np.int64)[None, :]).reshape(-1)
+    return pos[pos < nseq]
+
+
+class ShardedDatabase:
+    """A synthetic database (synth.DatabasePlan) sorted by length once and divided among `world` ranks by `rule`
+    (module docstring).  Every rank holds the plan of the whole database -- lengths only -- and materialises,
+    interleaves and uploads just its own chunks; database indices are positions in the globally sorted
+    database, whatever the number of ranks and the rule (chunk()["gpos"] maps a chunk's sequences to them)."""
+
+    def __init__(self, plan, W: int, max_chunk_size: int, world: int, rank: int, rule: str = "deal"):
+        if rule not in ("deal", "reference"):
+            raise ValueError(f"unknown shard rule {rule!r}")
+        if DEAL_BLOCK_SEQS % W:
+            raise ValueError("lane width must divide the dealt block")
+        self.plan, self.W, self.rule = plan, W, rule
         self.order = np.argsort(plan.lengths, kind="stable")     # reference: stable sort by length (sequences.c:125)
         self.sorted_lengths = plan.lengths[self.order]
         self.n_all = dblayout.group_lengths(self.sorted_lengths, W)
-        self.mine = rank_chunks(self.n_all, W, max_chunk_size, world, rank)
+        if rule == "reference":
+            self.mine = rank_chunks(self.n_all, W, max_chunk_size, world, rank)
+            self.pos = None
+        else:
+            # the rank's sequences, still sorted by length: whole wave blocks, so its W-lane groups ARE groups of the
+            # global layout (same members, same padded lengths); cut into as few equal chunks as max_chunk_size allows
+            self.pos = dealt_positions(plan.nseq, world, rank)
+            n_sub = dblayout.group_lengths(self.sorted_lengths[self.pos], W) if len(self.pos) else np.zeros(0, np.int64)
+            parts = max(1, -(-int(n_sub.sum()) * W // max_chunk_size))
+            self.mine = dblayout.chunk_plan(n_sub, W, max_chunk_size, parts) if len(n_sub) else []
 
     def chunk(self, k: int) -> dict:
-        """Chunk k of this rank in the layout the C ABI takes: b / n / disp (reference sequences.c:479-498), its
-        first sorted position s0, its number of real sequences, and the sorted sequences themselves."""
+        """Chunk k of this rank in the layout the C ABI takes: b / n / disp (reference sequences.c:479-498), the
+        sorted positions gpos of its sequences (s0 = the first), its number of real sequences, and the sorted
+        sequences themselves."""
         g0, g1 = self.mine[k]
-        s0, s1 = g0 * self.W, min(g1 * self.W, self.plan.nseq)
-        ls = self.sorted_lengths[s0:s1]
-        res = self.plan.residues_of(self.order[s0:s1])
+        if self.pos is None:
+            s0, s1 = g0 * self.W, min(g1 * self.W, self.plan.nseq)
+            gpos = np.arange(s0, s1, dtype=np.int64)
+        else:
+            gpos = self.pos[g0 * self.W:min(g1 * self.W, len(self.pos))]
+        ls = self.sorted_lengths[gpos]
+        res = self.plan.residues_of(self.order[gpos])
         off = np.zeros(len(ls) + 1, np.int64)
         np.cumsum(ls, out=off[1:])
         b, n, disp = dblayout.interleave(ls, res, off, self.W)
-        assert np.array_equal(n, self.n_all[g0:g1].astype(np.uint16))
-        return dict(g0=g0, g1=g1, s0=s0, nseq=s1 - s0, b=b, n=n, disp=disp.astype(np.uint32), ls=ls, res=res, off=off)
+        if self.pos is None:
+            assert np.array_equal(n, self.n_all[g0:g1].astype(np.uint16))
+        return dict(g0=g0, g1=g1, s0=int(gpos[0]) if len(gpos) else 0, gpos=gpos, nseq=len(gpos), b=b, n=n, disp=disp.astype(np.uint32),
+                    ls=ls, res=res, off=off)
 
 
 def rank_step(chunks, launch, collect, nq: int, r: int, index_base: int = 0, dist=None, device=None):
@@ -58,18 +107,24 @@ def rank_step(chunks, launch, collect, nq: int, r: int, index_base: int = 0, dis
     parts = []
     for c in chunks:
         sc, ix = collect(c)
-        parts.append((sc, global_index(ix, index_base + c["s0"])))
+        parts.append((sc, global_index(ix, index_base + c["s0"], c.get("gpos"), index_base)))
     if not parts:  # more ranks than chunks: this rank has nothing to search
         parts = [(np.full((nq, r), -1, np.int32), np.full((nq, r), -1, np.int64))]
     sc, gix = merge_local(parts, r)
     return gather_topr(sc, gix, r, dist, device)
 
 
-def global_index(chunk_index: np.ndarray, base: int) -> np.ndarray:
+def global_index(chunk_index: np.ndarray, base: int, gpos=None, gpos_base: int = 0) -> np.ndarray:
     """Index-in-chunk lists from oswald_hip_chunk_topr (uint32, 0xffffffff = empty slot) -> positions in the
-    globally sorted database (int64, -1 = empty slot); `base` = sorted position of the chunk's first sequence."""
+    globally sorted database (int64, -1 = empty slot): gpos[index] + gpos_base when the chunk carries the sorted
+    positions of its sequences (a dealt chunk is not one contiguous run), else index + base (`base` = sorted
+    position of the chunk's first sequence)."""
     ix = np.asarray(chunk_index).astype(np.int64)
-    return np.where(ix == 0xFFFFFFFF, -1, ix + int(base))
+    empty = ix == 0xFFFFFFFF
+    if gpos is not None:
+        g = np.asarray(gpos, dtype=np.int64)
+        return np.where(empty, -1, g[np.where(empty, 0, ix).clip(0, max(len(g) - 1, 0))] + int(gpos_base)) if len(g) else np.full(ix.shape, -1, np.int64)
+    return np.where(empty, -1, ix + int(base))
 
 
 def merge_local(parts, r: int):

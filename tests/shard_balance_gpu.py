@@ -1,5 +1,6 @@
 """Diagnostic (GPU box): time every rank's shard of the C4 database on ONE GPU, one after the other, to predict the
-load balance of the reference's chunk rule at N ranks: efficiency = mean(shard time) / max(shard time).
+load balance of a shard rule (RULE=deal|reference, default both) at N ranks: efficiency = mean(shard time) / max(shard
+time); the predicted speed-up is against the same database searched whole on the one GPU (measured first).
     python tests/shard_balance_gpu.py [world ...]"""
 import os, sys, time
 import numpy as np
@@ -17,11 +18,13 @@ plan = synth.DatabasePlan(1000000, qs, synth.SEED_DB, 12)
 ctx = capi.Context(1)
 ctx.set_scoring(submat.load("blosum62"), 10, 2)
 ctx.set_queries(a, m, ad)
-for world in worlds:
+rules = [os.environ["RULE"]] if os.environ.get("RULE") else ["deal", "reference"]
+t_whole = None
+for rule, world in [("deal", 1)] + [(r, w) for r in rules for w in worlds]:
     times, res = [], []
     only = os.environ.get("ONLY_RANK")
-    for rank in ([int(only)] if only is not None else range(world)):
-        sh = multigpu.ShardedDatabase(plan, 16, max_chunk, world, rank)
+    for rank in ([int(only)] if only is not None and world > 1 else range(world)):
+        sh = multigpu.ShardedDatabase(plan, 16, max_chunk, world, rank, rule)
         chunks = [sh.chunk(k) for k in range(len(sh.mine))]
         hs = [ctx.chunk_upload(c["b"], c["n"], c["disp"], 16) for c in chunks]
         def step():
@@ -34,6 +37,10 @@ for world in worlds:
         res.append(sum(int(c["off"][-1]) for c in chunks))
         for h in hs: ctx.chunk_release(h)
     tot = float(m.astype(np.int64).sum()) * sum(res)
-    print(f"max_chunk {max_chunk} chunks/rank {len(sh.mine)} world {world}: shard ms {[round(t * 1e3, 1) for t in times]}  residues {[round(r / 1e6, 1) for r in res]} M  "
-          f"-> predicted {tot / max(times) / 1e9:.0f} GCUPS = {tot / max(times) / (tot / sum(times)) :.2f} x one GPU, balance {np.mean(times) / max(times):.3f}", flush=True)
+    if world == 1:
+        t_whole = times[0]
+        print(f"whole database on one GPU ({len(sh.mine)} chunks): {t_whole * 1e3:.1f} ms = {tot / t_whole / 1e9:.0f} GCUPS", flush=True)
+        continue
+    print(f"rule {rule} max_chunk {max_chunk} chunks/rank {len(sh.mine)} world {world}: shard ms {[round(t * 1e3, 1) for t in times]}  residues {[round(r / 1e6, 1) for r in res]} M  "
+          f"-> predicted {tot / max(times) / 1e9:.0f} GCUPS = {t_whole / max(times):.2f} x the whole database on one GPU, balance {np.mean(times) / max(times):.3f}", flush=True)
 ctx.close()

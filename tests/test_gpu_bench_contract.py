@@ -48,8 +48,8 @@ def _bench(args, env):
 
 def test_bench_sharded_ranks_rehearsal(first_pass):
     """`bench.py --gpus 2` started bare: it spawns its two ranks (one process per rank, here sharing the box's one
-    GPU, top-r gather over gloo instead of RCCL), shards ONE database by the reference's chunk rule and reports
-    strong scaling; the merged top-1 scores are those of the single-GPU run on the same database."""
+    GPU, top-r gather over gloo instead of RCCL), shards ONE database (by dealt wave blocks, and by the reference's
+    chunk rule) and reports strong scaling; the merged top-1 scores are those of the single-GPU run on the same database."""
     if first_pass != "i16":
         pytest.skip("one run is enough")
     env = dict(os.environ)
@@ -60,4 +60,7 @@ def test_bench_sharded_ranks_rehearsal(first_pass):
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "sharded over 2 GPUs" in two["config"]["sharding"]
     assert one["config"]["chunks_rank0"] >= 3 and two["config"]["chunks_rank0"] >= 2          # several chunks, dealt round-robin
     assert two["config"]["db_residues_total"] == one["config"]["db_residues_total"]            # one database, not one per rank
-    assert two["top1_scores"] == one["top1_scores"] and two["value"] > 100
+    assert two["top1_scores"] == one["top1_scores"] and two["value"] > 100 and two["config"]["shard_rule"] == "deal"
+    ref = _bench(["--gpus", "2", "--shard-rule", "reference"] + common, dict(env, OSWALD_BENCH_BACKEND="gloo", MASTER_PORT="29612"))
+    assert ref["top1_scores"] == one["top1_scores"] and ref["config"]["db_residues_total"] == one["config"]["db_residues_total"]
+    assert "chunk rule" in ref["config"]["sharding"] and ref["config"]["chunks_rank0"] >= 2

@@ -1,5 +1,6 @@
-"""N > 1 path on CPUs: two processes over gloo, each owning the chunks the
-reference's round-robin would give its device; per-rank top-r lists are
+"""N > 1 path on CPUs: processes over gloo, each owning its part of the sorted
+database under either shard rule (wave blocks dealt to the ranks, or the chunks
+the reference's round-robin would give its device); per-rank top-r lists are
 all-gathered and merged with the reference's tie rule.  The per-rank scores
 come from the CPU oracle here (no GPU), so this covers sharding, global index
 bookkeeping, the collective and the merge."""
@@ -31,7 +32,7 @@ def _free_port():
 QLENS, NSEQ, DBSEED = [60, 35, 90], 900, 21
 
 
-def _worker(rank, world, port, r, max_chunk, ret):
+def _worker(rank, world, port, r, max_chunk, rule, ret):
     """bench.py's N > 1 code path (multigpu.ShardedDatabase + multigpu.rank_step) with the CPU oracle standing in
     for the GPU search of a chunk and gloo for RCCL."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -42,7 +43,7 @@ def _worker(rank, world, port, r, max_chunk, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     qs = synth.make_queries(QLENS, seed=5)
     plan = synth.DatabasePlan(NSEQ, qs, DBSEED, 5)
-    shard = multigpu.ShardedDatabase(plan, 16, max_chunk, world, rank)
+    shard = multigpu.ShardedDatabase(plan, 16, max_chunk, world, rank, rule)
     chunks = [shard.chunk(k) for k in range(len(shard.mine))]
     a, m, ad = pack_queries(qs)
     sm = submat.load("blosum62")
@@ -63,17 +64,20 @@ def _worker(rank, world, port, r, max_chunk, ret):
     if rank == 0:
         ret["scores"], ret["index"] = out_s, out_i
     ret[f"chunks{rank}"] = [(c["g0"], c["g1"]) for c in chunks]
+    ret[f"gpos{rank}"] = [c["gpos"] for c in chunks]
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,max_chunk,r", [(2, 134217728, 12), (4, 134217728, 12), (4, 60000, 10), (3, 90000, 1000)])
-def test_ranks_shard_and_merge(oracle, world, max_chunk, r):
+@pytest.mark.parametrize("world,max_chunk,r,rule", [(2, 134217728, 12, "reference"), (4, 134217728, 12, "reference"), (4, 60000, 10, "reference"),
+                                                    (3, 90000, 1000, "reference"), (2, 134217728, 12, "deal"), (4, 60000, 10, "deal"), (3, 90000, 1000, "deal")])
+def test_ranks_shard_and_merge(oracle, world, max_chunk, r, rule):
     """world ranks over gloo == one process over the whole database: same top-r scores AND the same
-    positions in the globally sorted database (r = 1000 > sequences per chunk: empty slots on the way)."""
+    positions in the globally sorted database (r = 1000 > sequences per chunk: empty slots on the way),
+    under both shard rules."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), r, max_chunk, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), r, max_chunk, rule, ret), nprocs=world, join=True)
     qs = synth.make_queries(QLENS, seed=5)
     L, R, O = synth.make_database(NSEQ, qs, seed=DBSEED, homologs_per_query=5)
     order, sl, sr, so = dblayout.sort_by_length(L, R, O)
@@ -86,9 +90,32 @@ def test_ranks_shard_and_merge(oracle, world, max_chunk, r):
         np.testing.assert_array_equal(ret["index"][q, :len(wi)], wi)
         assert (ret["index"][q, len(wi):] == -1).all()
     allc = sorted(c for k in range(world) for c in ret[f"chunks{k}"])
-    assert allc[0][0] == 0 and allc[-1][1] == len(n) and all(allc[i][1] == allc[i + 1][0] for i in range(len(allc) - 1))
+    if rule == "reference":
+        assert allc[0][0] == 0 and allc[-1][1] == len(n) and all(allc[i][1] == allc[i + 1][0] for i in range(len(allc) - 1))
+    # together the ranks hold every sequence of the sorted database exactly once
+    np.testing.assert_array_equal(np.sort(np.concatenate([g for k in range(world) for g in ret[f"gpos{k}"]])), np.arange(NSEQ))
     if max_chunk < 134217728:
-        assert len(allc) > world   # several chunks per rank, dealt round-robin
+        assert len(allc) > world   # several chunks per rank
+
+
+def test_dealt_shards_are_whole_wave_blocks_and_balanced():
+    """The "deal" rule hands out whole 128-sequence wave blocks, every sequence exactly once, and the ranks' shares of
+    the residues (= of the DP cells of every query) differ by well under 1 % at the size bench.py runs."""
+    plan = synth.DatabasePlan(200000, None, 11, 0)
+    sl = np.sort(plan.lengths, kind="stable")
+    for world in (2, 3, 4, 8):
+        pos = [multigpu.dealt_positions(plan.nseq, world, r) for r in range(world)]
+        np.testing.assert_array_equal(np.sort(np.concatenate(pos)), np.arange(plan.nseq))
+        for p in pos:
+            assert (np.diff(p) > 0).all()
+            blocks = np.unique(p // 128)
+            assert len(p) == sum(min(128, plan.nseq - 128 * int(b)) for b in blocks)   # whole blocks
+        res = np.array([int(sl[p].sum()) for p in pos], dtype=np.float64)
+        assert res.min() / res.max() > 0.99, (world, res)
+    # a dealt chunk's groups are groups of the global layout: same members, same padded lengths
+    sh = multigpu.ShardedDatabase(plan, 16, 134217728, 4, 1)
+    c = sh.chunk(0)
+    np.testing.assert_array_equal(c["n"], sh.n_all[c["gpos"][::16] // 16].astype(np.uint16))
 
 
 def test_sharded_database_equals_whole():
@@ -100,7 +127,7 @@ def test_sharded_database_equals_whole():
     bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
     got = {}
     for rank in range(3):
-        sh = multigpu.ShardedDatabase(plan, 16, 300000, 3, rank)
+        sh = multigpu.ShardedDatabase(plan, 16, 300000, 3, rank, "reference")
         for k in range(len(sh.mine)):
             c = sh.chunk(k)
             got[c["g0"]] = c
