@@ -41,14 +41,15 @@ DEAL_BLOCK_SEQS = 128   # sequences per dealt unit = one wave block of the searc
 
 def dealt_positions(nseq: int, world: int, rank: int, block_seqs: int = DEAL_BLOCK_SEQS) -> np.ndarray:
     """Sorted positions of the sequences rank `rank` owns under the "deal" rule.  Blocks are counted from the LONGEST
-    end (so that the incomplete last round holds the shortest sequences): of the blocks of round t it gets number
+    end -- block u holds the sorted positions [nseq - (u+1)*128, nseq - u*128) -- so that both the one incomplete
+    block and the incomplete last round hold the shortest sequences; of the blocks of round t a rank gets number
     `rank` when t is even and number world - 1 - rank when t is odd.  Returned in ascending order."""
     nblk = (nseq + block_seqs - 1) // block_seqs
     t = np.arange((nblk + world - 1) // world, dtype=np.int64)
-    from_end = t * world + np.where(t % 2 == 0, rank, world - 1 - rank)
-    mine = (nblk - 1 - from_end[from_end < nblk])[::-1]
-    pos = (mine[:, None] * block_seqs + np.arange(block_seqs, dtype=np.int64)[None, :]).reshape(-1)
-    return pos[pos < nseq]
+    u = t * world + np.where(t % 2 == 0, rank, world - 1 - rank)
+    u = u[u < nblk][::-1]
+    pos = (nseq - (u[:, None] + 1) * block_seqs + np.arange(block_seqs, dtype=np.int64)[None, :]).reshape(-1)
+    return pos[pos >= 0]
 
 
 class ShardedDatabase:
@@ -60,8 +61,6 @@ class ShardedDatabase:
     def __init__(self, plan, W: int, max_chunk_size: int, world: int, rank: int, rule: str = "deal"):
         if rule not in ("deal", "reference"):
             raise ValueError(f"unknown shard rule {rule!r}")
-        if DEAL_BLOCK_SEQS % W:
-            raise ValueError("lane width must divide the dealt block")
         self.plan, self.W, self.rule = plan, W, rule
         self.order = np.argsort(plan.lengths, kind="stable")     # reference: stable sort by length (sequences.c:125)
         self.sorted_lengths = plan.lengths[self.order]
@@ -70,8 +69,8 @@ class ShardedDatabase:
             self.mine = rank_chunks(self.n_all, W, max_chunk_size, world, rank)
             self.pos = None
         else:
-            # the rank's sequences, still sorted by length: whole wave blocks, so its W-lane groups ARE groups of the
-            # global layout (same members, same padded lengths); cut into as few equal chunks as max_chunk_size allows
+            # the rank's sequences, still sorted by length, interleaved like a database of their own; cut into as few
+            # equal chunks as max_chunk_size allows
             self.pos = dealt_positions(plan.nseq, world, rank)
             n_sub = dblayout.group_lengths(self.sorted_lengths[self.pos], W) if len(self.pos) else np.zeros(0, np.int64)
             parts = max(1, -(-int(n_sub.sum()) * W // max_chunk_size))
