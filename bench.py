@@ -178,6 +178,7 @@ def main():
         if c["b"].size >= 2**32:
             raise SystemExit("chunk too large; lower --max-chunk")
         c["h"] = ctx.chunk_upload(c["b"], c["n"], c["disp"], 16)
+        ctx.chunk_set_index(c["h"], 0, c["nseq"], c["gpos"])   # the chunk's sequences -> positions in the sorted database
         chunks.append(c)
         d_local += int(c["off"][-1])
     t_gen = time.time() - t0
@@ -190,9 +191,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     def step():
-        return multigpu.rank_step(chunks, lambda c: ctx.chunk_search(c["h"], None),
-                                  lambda c: ctx.chunk_topr(c["h"], c["nseq"], args.top),   # syncs the library's stream
-                                  nq, args.top, index_base, dist, coll_dev if dist is not None else None)
+        # every chunk's search queues the selection of its top r behind it (oswald_hip_topr_begin); oswald_hip_topr
+        # waits for the device once and merges the rank's lists in the library
+        ctx.topr_begin(args.top)
+        return multigpu.rank_step(chunks, lambda c: ctx.chunk_search(c["h"], None), None, nq, args.top, index_base, dist,
+                                  coll_dev if dist is not None else None, collect_rank=lambda: ctx.topr(args.top))
 
     if dist is not None:  # the first collective of a process group sets up its channels: not part of any step
         multigpu.gather_topr(np.full((nq, args.top), -1, np.int32), np.full((nq, args.top), -1, np.int64), args.top, dist, coll_dev)

@@ -44,7 +44,7 @@ extern "C" {
 #define OSWALD_HIP_ENOMEM (-4)   /* host or device allocation failed */
 #define OSWALD_HIP_ESTATE (-5)   /* call sequence violated (e.g. search before set_queries) */
 
-#define OSWALD_HIP_ABI_VERSION 1
+#define OSWALD_HIP_ABI_VERSION 2
 
 typedef struct oswald_hip_ctx oswald_hip_ctx;
 
@@ -142,6 +142,31 @@ int oswald_hip_wait(oswald_hip_ctx *ctx, int dev);
  * per-GPU part of the multi-GPU merge. */
 int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nvalid, uint32_t r,
                           int32_t *scores, uint32_t *index);
+
+/* Context-level top-r: the r best (score, database index) pairs per query over EVERY chunk searched on EVERY
+ * device of the context, in the order sort_scores() produces (descending score, equal scores by DESCENDING
+ * database index, host/src/utils.c:3-86).  Replaces the merge of the devices' score tables into the global one
+ * (host/src/FPGAsearch.c:236-237), sort_scores() (utils.c:71-86) and the top-r loop (FPGAsearch.c:312-321) -- the
+ * "multi-GPU gather" of a process that drives several GPUs through one context.  Use:
+ *   oswald_hip_topr_begin(ctx, r)       start collecting (drops what was collected before); r <= 1024;
+ *   oswald_hip_chunk_set_index(...)     after an upload: the chunk's place in the database -- sequence k of the chunk
+ *                                       is database sequence first_index + k, or index_map[k] if a map is given (it is
+ *                                       copied; a chunk need not be one contiguous run); nvalid real sequences;
+ *   oswald_hip_chunk_search(...)        of a chunk that has its index now also selects the chunk's r best on its
+ *                                       device, queued on the device's stream behind the search: nothing waits, and the
+ *                                       chunk may be released (its slot re-used) right after the call;
+ *   oswald_hip_topr(ctx, r, ...)        waits for all devices and merges everything collected since _begin
+ *                                       (r <= the r given to _begin).  scores / db_index: [nq][r], host memory; slots
+ *                                       beyond the number of database sequences seen: score -1, index 0xffffffff.
+ * The one merge implementation of the library; oswald_hip_merge_candidates exposes it for callers that combine
+ * lists of several contexts or processes (ncand candidates per query, [nq][ncand]; score < 0 = empty slot).  It is
+ * host logic and works without a GPU. */
+int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r);
+int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t first_index, uint32_t nvalid,
+                               const uint32_t *index_map);
+int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *db_index);
+int oswald_hip_merge_candidates(uint32_t nq, uint64_t ncand, const int32_t *cand_scores, const uint32_t *cand_index,
+                                uint32_t r, int32_t *scores, uint32_t *db_index);
 
 /* Device time spent in the DP kernels since the last reset, measured with HIP
  * events on the device's stream (enabled by oswald_hip_set_profiling). */

@@ -21,6 +21,7 @@ SYMBOLS = (
     "oswald_hip_info", "oswald_hip_set_scoring", "oswald_hip_set_queries", "oswald_hip_chunk_upload", "oswald_hip_chunk_search",
     "oswald_hip_chunk_release", "oswald_hip_search_chunk_async", "oswald_hip_wait", "oswald_hip_chunk_topr",
     "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry", "oswald_hip_chunk_upload_async", "oswald_hip_reserve", "oswald_hip_rerun_counts",
+    "oswald_hip_topr_begin", "oswald_hip_chunk_set_index", "oswald_hip_topr", "oswald_hip_merge_candidates",
 )
 
 
@@ -58,6 +59,10 @@ def load():
     lib.oswald_hip_search_chunk_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, vp]
     lib.oswald_hip_wait.argtypes = [vp, i32]
     lib.oswald_hip_chunk_topr.argtypes = [vp, i32, i32, u32, u32, vp, vp]
+    lib.oswald_hip_topr_begin.argtypes = [vp, u32]
+    lib.oswald_hip_chunk_set_index.argtypes = [vp, i32, i32, u32, u32, vp]
+    lib.oswald_hip_topr.argtypes = [vp, u32, vp, vp]
+    lib.oswald_hip_merge_candidates.argtypes = [u32, u64, vp, vp, u32, vp, vp]
     lib.oswald_hip_set_profiling.argtypes = [vp, i32]
     lib.oswald_hip_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), i32]
     lib.oswald_hip_chunk_geometry.argtypes = [vp, i32, i32, C.POINTER(u64)]
@@ -75,6 +80,19 @@ def _ptr(a):
 def _chk(rc):
     if rc != 0:
         raise OswaldHipError(f"liboswald_hip: error {rc}: {load().oswald_hip_last_error().decode(errors='replace')}")
+
+
+def merge_candidates(cand_scores: np.ndarray, cand_index: np.ndarray, r: int):
+    """oswald_hip_merge_candidates: [nq][K] candidates (score < 0 = empty slot) -> the r best per query in the
+    reference's order (descending score, ties by descending database index): ([nq][r] int32, [nq][r] uint32),
+    empty slots (-1, 0xffffffff).  Host logic of the library (no GPU needed)."""
+    cs = np.ascontiguousarray(cand_scores, dtype=np.int32)
+    ci = np.ascontiguousarray(cand_index, dtype=np.uint32)
+    assert cs.ndim == 2 and cs.shape == ci.shape
+    out_s = np.empty((cs.shape[0], r), np.int32)
+    out_i = np.empty((cs.shape[0], r), np.uint32)
+    _chk(load().oswald_hip_merge_candidates(cs.shape[0], cs.shape[1], _ptr(cs), _ptr(ci), r, _ptr(out_s), _ptr(out_i)))
+    return out_s, out_i
 
 
 def device_count() -> int:
@@ -168,6 +186,21 @@ class Context:
         sc = np.empty((self.nq, r), dtype=np.int32)
         ix = np.empty((self.nq, r), dtype=np.uint32)
         _chk(self.lib.oswald_hip_chunk_topr(self.h, dev, chunk, nvalid, r, _ptr(sc), _ptr(ix)))
+        return sc, ix
+
+    def topr_begin(self, r: int):
+        _chk(self.lib.oswald_hip_topr_begin(self.h, r))
+
+    def chunk_set_index(self, chunk: int, first_index: int, nvalid: int, index_map=None, dev: int = 0):
+        im = None if index_map is None else np.ascontiguousarray(index_map, dtype=np.uint32)
+        assert im is None or im.size >= nvalid
+        _chk(self.lib.oswald_hip_chunk_set_index(self.h, dev, chunk, first_index, nvalid, _ptr(im)))
+
+    def topr(self, r: int):
+        """([nq][r] int32 scores, [nq][r] uint32 database indices) over everything searched since topr_begin."""
+        sc = np.empty((self.nq, r), dtype=np.int32)
+        ix = np.empty((self.nq, r), dtype=np.uint32)
+        _chk(self.lib.oswald_hip_topr(self.h, r, _ptr(sc), _ptr(ix)))
         return sc, ix
 
     def set_profiling(self, on: bool):

@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -42,11 +44,63 @@ int fail(int code, const char *fmt, ...)
                         hipGetErrorString(e__));                                                              \
     } while (0)
 
-// OSWALD_HIP_DEBUG_PHASES=1: wall time of the host-side phases of an upload / search (diagnostics)
+// Environment hooks.  They are read when a context is CONFIGURED (oswald_hip_init, oswald_hip_set_scoring,
+// oswald_hip_set_queries), never on the per-search path.  The default build knows the test hooks and the
+// host-side timing prints only -- none of them changes a result.  The planner sweep knobs and the kernel timing
+// diagnostics (one of which, NOSPILL, yields wrong scores) exist only in the -DOSW_DIAG build
+// (`make -C oswald_amd/csrc diag` -> liboswald_hip_diag.so, which tools/ load on request and nothing else does).
+struct Tunables {
+    int cell_bits_default = 16;        // OSWALD_HIP_CELL_BITS: cell arithmetic when the caller passes cell_bits 0
+    bool no_frame = false;             // OSWALD_HIP_NO_FRAME=1: plain biased int16 cell only
+    int force_lg = -1, force_wg = -1;  // OSWALD_HIP_FORCE_LG=k: every item at G = 2^k; OSWALD_HIP_FORCE_WG=0|1
+    int pairs = 1;                     // OSWALD_HIP_PAIRS=0|1|2: never pair / pair when cheaper / pair every neighbour
+    bool debug_plan = false;           // OSWALD_HIP_DEBUG=1: print the work-queue plan
+    bool debug_phases = false;         // OSWALD_HIP_DEBUG_PHASES=1: wall time of the host-side phases
+    bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
+    // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
+    double pair_margin = 1.03, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
+    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, two_ended = 0;
+    bool no_prio = false, one_stream = false;
+    bool debug_times = false, debug_nospill = false; // -DOSW_DIAG only
+    void refresh();
+};
+bool g_debug_slow = false; // OSWALD_HIP_DEBUG_SLOW=1: report allocations / pinning that take > 5 ms
+
+void Tunables::refresh()
+{
+    auto num = [](const char *name, double dflt) { const char *e = getenv(name); return e ? atof(e) : dflt; };
+    auto flag = [](const char *name) { return getenv(name) != nullptr; };
+    *this = Tunables();
+    cell_bits_default = (int)num("OSWALD_HIP_CELL_BITS", 16);
+    no_frame = flag("OSWALD_HIP_NO_FRAME");
+    force_lg = std::min(6, (int)num("OSWALD_HIP_FORCE_LG", -1));
+    force_wg = (int)num("OSWALD_HIP_FORCE_WG", -1);
+    pairs = (int)num("OSWALD_HIP_PAIRS", 1);
+    debug_plan = flag("OSWALD_HIP_DEBUG");
+    debug_phases = flag("OSWALD_HIP_DEBUG_PHASES");
+    no_pin = flag("OSWALD_HIP_NO_PIN");
+    g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
+#ifdef OSW_DIAG
+    pair_margin = num("OSWALD_HIP_PAIR_MARGIN", pair_margin);
+    col_cost = num("OSWALD_HIP_COL_COST", col_cost);
+    target_div = num("OSWALD_HIP_TARGET_DIV", target_div);
+    quad_frac = num("OSWALD_HIP_QUAD_FRAC", quad_frac);
+    wg_min_cols = (uint32_t)num("OSWALD_HIP_WG_MINCOLS", wg_min_cols);
+    wg_wide_cols = (uint32_t)num("OSWALD_HIP_WG_WIDECOLS", wg_wide_cols);
+    wg_min_rounds = (uint32_t)num("OSWALD_HIP_WG_MINROUNDS", wg_min_rounds);
+    two_ended = (uint32_t)num("OSWALD_HIP_TWO_ENDED", 0);
+    no_prio = flag("OSWALD_HIP_NO_PRIO");
+    one_stream = flag("OSWALD_HIP_ONE_STREAM");
+    debug_times = flag("OSWALD_HIP_DEBUG_TIMES");
+    debug_nospill = flag("OSWALD_HIP_DEBUG_NOSPILL");
+#endif
+}
+
+// wall time of the host-side phases of an upload / search (Tunables::debug_phases)
 struct PhaseTimer {
     bool on;
     std::chrono::steady_clock::time_point t;
-    PhaseTimer() : on(getenv("OSWALD_HIP_DEBUG_PHASES") != nullptr), t(std::chrono::steady_clock::now()) {}
+    explicit PhaseTimer(bool enabled) : on(enabled), t(std::chrono::steady_clock::now()) {}
     void lap(const char *what)
     {
         if (!on) return;
@@ -68,7 +122,7 @@ struct DevBuf {
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (ms > 5.0 && getenv("OSWALD_HIP_DEBUG_SLOW")) fprintf(stderr, "[oswald_hip] slow hipMalloc: %zu bytes took %.1f ms\n", want, ms);
+        if (ms > 5.0 && g_debug_slow) fprintf(stderr, "[oswald_hip] slow hipMalloc: %zu bytes took %.1f ms\n", want, ms);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
         return hipSuccess;
@@ -94,6 +148,43 @@ struct Chunk {
     uint32_t max_lg = 0;                // widest geometry in the item list
     bool searched = false;
     bool upload_pending = false;        // uploaded with _async: the device's stream has not been synchronised since
+    // the chunk's place in the database (oswald_hip_chunk_set_index): database index of its k-th sequence =
+    // index_map[k] if a map was given, else first_index + k; nvalid real sequences
+    bool has_index = false;
+    uint32_t first_index = 0, nvalid = 0;
+    std::shared_ptr<const std::vector<uint32_t>> index_map;
+};
+
+// One chunk's top list on its way to the context-level merge (oswald_hip_topr): [nq][r] scores and indices-in-chunk in
+// pinned host memory, filled by copies queued on the device's stream right behind the search.
+struct TopPart {
+    int32_t *scores = nullptr;
+    uint32_t *index = nullptr;
+    uint32_t nq = 0, r = 0, first_index = 0;
+    std::shared_ptr<const std::vector<uint32_t>> index_map;
+};
+
+// Pinned host memory for the TopParts, handed out in pieces and recycled by oswald_hip_topr_begin.
+struct PinnedPool {
+    std::vector<std::pair<char *, size_t>> slabs;
+    size_t slab = 0, used = 0;
+    void *take(size_t bytes)
+    {
+        bytes = (bytes + 63) & ~(size_t)63;
+        while (slab < slabs.size() && used + bytes > slabs[slab].second) { ++slab; used = 0; }
+        if (slab == slabs.size()) {
+            const size_t sz = std::max<size_t>(bytes, 1u << 20);
+            void *p = nullptr;
+            if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess) return nullptr;
+            slabs.push_back({(char *)p, sz});
+            used = 0;
+        }
+        void *out = slabs[slab].first + used;
+        used += bytes;
+        return out;
+    }
+    void rewind() { slab = 0; used = 0; }
+    void release() { for (auto &s : slabs) (void)hipHostFree(s.first); slabs.clear(); rewind(); }
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -107,12 +198,15 @@ struct Device {
     uint32_t grid = 0;               // persistent workgroups per launch
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
+    std::vector<uint32_t> top_pages_host; // source of the asynchronous upload of top_pages
     std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
     uint64_t scoring_version = ~0ull;
     std::vector<Chunk> chunks;
     std::vector<EventPair> ev_pool, ev_used;
+    std::vector<TopPart> top_parts;  // top lists accumulated since oswald_hip_topr_begin
+    PinnedPool top_pool;
     double dp_ms = 0;
     uint64_t dp_launches = 0, rerun_items = 0;
 };
@@ -121,6 +215,7 @@ struct Device {
 
 struct oswald_hip_ctx {
     std::vector<Device> dev;
+    Tunables tun;
     // scoring
     bool have_scoring = false;
     int8_t submat[24 * 32];
@@ -138,13 +233,14 @@ struct oswald_hip_ctx {
     uint32_t pair_rowblocks = 0, pair_max_rowblocks = 0;
     uint64_t queries_version = 0;
     bool profiling = false;
+    uint32_t topr_r = 0;             // oswald_hip_topr_begin: every search also selects the chunk's top r (0: off)
 };
 
 namespace {
 
 // cell_bits 16 runs the column-frame int16 cell (ArithI16S) with the plain biased cell as its fallback;
 // OSWALD_HIP_NO_FRAME=1 (test hook) runs the plain cell only
-bool first_pass_is_frame(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 16 && !getenv("OSWALD_HIP_NO_FRAME"); }
+bool first_pass_is_frame(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 16 && !ctx->tun.no_frame; }
 
 // cell_bits 8: the SWAR 8-bit first pass (CellQ8) runs the query PAIRS; what leaves its 7-bit range is re-run by the
 // plain packed-int16 kernel, what reaches that one's ceiling by the int32 kernel.  It needs every profile entry
@@ -170,10 +266,9 @@ void plan_pairs(oswald_hip_ctx *ctx)
     const double pair_row = fr ? 6.5 : 7.5, single_row = fr ? 7.5 : 8.5;
     ctx->pair_q.clear(); ctx->pair_off.clear(); ctx->pair_len.clear(); ctx->singles.clear();
     ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
-    int mode = 1;
-    if (const char *e = getenv("OSWALD_HIP_PAIRS")) mode = atoi(e);
+    int mode = ctx->tun.pairs;
     if (first_pass_is_q8(ctx)) mode = 2; // the 8-bit cell works on query pairs only: pair every neighbour (a leftover query runs in int16)
-    const double margin = getenv("OSWALD_HIP_PAIR_MARGIN") ? atof(getenv("OSWALD_HIP_PAIR_MARGIN")) : 1.03;
+    const double margin = ctx->tun.pair_margin;
     std::vector<uint32_t> order(nq);
     for (uint32_t q = 0; q < nq; ++q) order[q] = q;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return m[x] < m[y]; });
@@ -224,6 +319,7 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     if (!ctx->have_scoring) return fail(OSWALD_HIP_ESTATE, "oswald_hip_set_scoring has not been called");
     if (!ctx->have_queries) return fail(OSWALD_HIP_ESTATE, "oswald_hip_set_queries has not been called");
     if (d.queries_version == ctx->queries_version && d.scoring_version == ctx->scoring_version) return 0;
+    HIP_TRY(hipStreamSynchronize(d.stream)); // a call that failed half-way may have left copies from the host arrays queued
     const uint32_t nq = ctx->nq;
     HIP_TRY(d.queries.reserve(ctx->a.size() + 16));
     HIP_TRY(d.qlen.reserve(nq * sizeof(uint16_t) + 16));
@@ -250,9 +346,9 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     }
     // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
     // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern).  Uploaded on the
-    // device's stream like everything else here (ordered behind a search still in flight); `pages` lives until the
-    // synchronisation at the end of this function.
-    std::vector<uint32_t> pages((128 + OSW_I16S_TABLE) * 2, 0u);
+    // device's stream like everything else here (ordered behind a search still in flight).
+    std::vector<uint32_t> &pages = d.top_pages_host; // a member: an early return must not free the source of a queued copy
+    pages.assign((128 + OSW_I16S_TABLE) * 2, 0u);
     for (size_t i = 64; i < 128; ++i) pages[2 * i] = pages[2 * i + 1] = 0x04000400u;
     for (size_t k = 0; k < OSW_I16S_TABLE; ++k) {
         const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
@@ -320,7 +416,8 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     }
     const uint32_t ne = (uint32_t)ents.size();
     const uint32_t wgx = OSW_WG_THREADS / 64;
-    const double col_cost = getenv("OSWALD_HIP_COL_COST") ? atof(getenv("OSWALD_HIP_COL_COST")) : 10.0; // issue slots per column step besides the cells
+    const Tunables &tun = ctx->tun;
+    const double col_cost = tun.col_cost; // issue slots per column step besides the cells
     auto item_cost = [&](const Entity &e, uint32_t lg, uint32_t ncols, bool wg) {
         const Kind &kd = kinds[e.kind];
         const OswPlan pl = osw_plan(e.m, 1u << lg, wg ? kd.ldsr * wgx : kd.ldsr, kd.rmax);
@@ -366,17 +463,11 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             total += (double)(1u << def[k].lg) * item_cost(ents[k], def[k].lg, c.ncols4_alloc[b] * 4, def[k].wg);
     }
     const double nwaves = (double)d.grid * wgx;
-    const double target_div = getenv("OSWALD_HIP_TARGET_DIV") ? atof(getenv("OSWALD_HIP_TARGET_DIV")) : 1.25;
-    const double target = std::max(total / nwaves / target_div, 4.0e4);
+    const double target = std::max(total / nwaves / tun.target_div, 4.0e4);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
-    int force_lg = -1, force_wg = -1;
-    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048;
-    if (const char *e = getenv("OSWALD_HIP_WG_MINCOLS")) wg_min_cols = (uint32_t)atoi(e);
-    if (const char *e = getenv("OSWALD_HIP_WG_WIDECOLS")) wg_wide_cols = (uint32_t)atoi(e);
-    if (const char *e = getenv("OSWALD_HIP_FORCE_LG")) force_lg = atoi(e);
-    if (const char *e = getenv("OSWALD_HIP_FORCE_WG")) force_wg = atoi(e);
-    if (force_lg > 6) force_lg = 6;
+    int force_lg = tun.force_lg, force_wg = tun.force_wg;
+    const uint32_t wg_min_cols = tun.wg_min_cols, wg_wide_cols = tun.wg_wide_cols;
     if (i32) force_wg = 0; // the int32 kernel has no workgroup phase
     struct It { double cost; uint32_t x, b; };
     std::vector<It> its[2], its_wg[2];
@@ -443,7 +534,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
         for (const It &i : its_wg[kd]) planned += i.cost * 4;
     }
     const double fair = planned / nwaves;
-    const bool no_prio = getenv("OSWALD_HIP_NO_PRIO") != nullptr;
+    const bool no_prio = tun.no_prio;
     auto prio_of = [&](double cost) { return no_prio ? 0u : cost > fair / 2 ? 3u : cost > fair / 4 ? 2u : cost > fair / 8 ? 1u : 0u; };
     // Phase 1 of a launch is ONE queue of workgroup entries, heaviest first (longest-processing-time order): a
     // workgroup item (four sub-blocks of one item on the four waves, shared profile slice), or a QUAD of four
@@ -452,7 +543,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     // of the fair share that starts at 60 % of the launch defines its end.)  Phase 2, the per-wave queue, keeps
     // the light wave items that fill the tail.  An entry is four item slots, one per wave; slot.y bit 31 marks a
     // workgroup item, slot.y == OSW_ITEM_NONE an empty slot of the last quad.
-    const double quad_frac = getenv("OSWALD_HIP_QUAD_FRAC") ? atof(getenv("OSWALD_HIP_QUAD_FRAC")) : 0.5; // measured: 0.25 costs C2 6 % (waves in step), 1.0 loses the gain on C5
+    const double quad_frac = tun.quad_frac; // 0.5; measured: 0.25 costs C2 6 % (waves in step), 1.0 loses the gain on C5
     struct Entry { double cost; uint2 slot[4]; };
     std::vector<uint2> flat[2];
     uint32_t n_entries[2] = {0, 0}, n_wave[2] = {0, 0}, n_quads[2] = {0, 0};
@@ -489,7 +580,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     c.nitems_q_wg = n_entries[1];
     c.nitems_q = n_wave[1];
     if (q8 && c.nitems_q_wg) return fail(OSWALD_HIP_ERUNTIME, "planner produced workgroup entries for the 8-bit kernel");
-    if (getenv("OSWALD_HIP_DEBUG")) {
+    if (tun.debug_plan) {
         fprintf(stderr, "[oswald_hip] plan: %zu single queries, %zu query pairs, total %.3g slots, %.0f waves, target %.3g, max lg %u\n",
                 i32 ? (size_t)ctx->nq : ctx->singles.size(), i32 ? (size_t)0 : ctx->pair_len.size(), total, nwaves, target, c.max_lg);
         for (int kd = 0; kd < 2; ++kd) {
@@ -542,12 +633,18 @@ int ensure_scratch(Device &d, uint32_t max_cols)
     HIP_TRY(hipStreamSynchronize(d.stream)); // nothing may still be spilling into the old regions
     HIP_TRY(hipStreamSynchronize(d.stream2));
     const uint64_t slots = (uint64_t)d.grid * (OSW_WG_THREADS / 64);
-    d.bnd.release();
-    d.bnd_stride = 0;
-    HIP_TRY(d.bnd.reserve(2 * slots * (stride + OSW_SCRATCH_DATA) * sizeof(uint2)));
-    HIP_TRY(hipMemset2DAsync(d.bnd.p, (stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream));
-    d.bnd_stride = stride;
+    // the larger region is allocated BESIDE the old one and swapped in on success: if the allocation fails the old
+    // scratch, its stride and the plans made for it all stay valid (the caller gets OSWALD_HIP_ENOMEM)
+    DevBuf bigger;
+    HIP_TRY(bigger.reserve(2 * slots * (stride + OSW_SCRATCH_DATA) * sizeof(uint2)));
+    if (hipError_t e = hipMemset2DAsync(bigger.p, (stride + OSW_SCRATCH_DATA) * sizeof(uint2), 0, OSW_SCRATCH_DATA * sizeof(uint2), 2 * slots, d.stream)) {
+        bigger.release();
+        return fail(OSWALD_HIP_ERUNTIME, "hipMemset2DAsync(spill scratch): %s", hipGetErrorString(e));
+    }
     for (Chunk &c : d.chunks) c.items_version = ~0ull; // the plans were made for the old region size
+    d.bnd.release();
+    d.bnd = bigger;
+    d.bnd_stride = stride;
     return 0;
 }
 
@@ -568,6 +665,63 @@ void drain_events(Device &d)
         d.ev_pool.push_back(e);
     }
     d.ev_used.clear();
+}
+
+int queue_topr(oswald_hip_ctx *ctx, Device &d, Chunk &c, uint32_t nvalid, uint32_t r)
+{
+    const size_t cnt = (size_t)ctx->nq * r;
+    HIP_TRY(d.topr_scores.reserve(cnt * sizeof(int32_t)));
+    HIP_TRY(d.topr_index.reserve(cnt * sizeof(uint32_t)));
+    HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * osw_topr_parts(nvalid) * r * sizeof(unsigned long long)));
+    HIP_TRY(osw_launch_topr((const int32_t *)c.scores.p, c.score_stride, nvalid, r, ctx->nq, (unsigned long long *)d.topr_cand.p, (int32_t *)d.topr_scores.p,
+                            (uint32_t *)d.topr_index.p, d.stream));
+    return 0;
+}
+
+// Context-level top-r (oswald_hip_topr_begin): select the top r of the chunk just searched on its device and queue
+// the copy of the list into pinned host memory, all on the device's stream -- the caller is not made to wait, and the
+// device buffers are free for the next chunk's list as soon as the stream gets there.
+int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c)
+{
+    if (ctx->topr_r == 0 || !c.has_index || ctx->nq == 0) return 0;
+    const uint32_t r = ctx->topr_r;
+    if (c.nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "chunk index: nvalid %u exceeds the chunk's %u lanes", c.nvalid, c.ngroups * c.W);
+    const size_t cnt = (size_t)ctx->nq * r;
+    TopPart part;
+    part.scores = (int32_t *)d.top_pool.take(cnt * sizeof(int32_t));
+    part.index = (uint32_t *)d.top_pool.take(cnt * sizeof(uint32_t));
+    if (!part.scores || !part.index) return fail(OSWALD_HIP_ENOMEM, "pinned host memory for the top lists");
+    part.nq = ctx->nq;
+    part.r = r;
+    part.first_index = c.first_index;
+    part.index_map = c.index_map;
+    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0 || c.nvalid == 0) { // nothing was searched: an empty list
+        for (size_t k = 0; k < cnt; ++k) { part.scores[k] = -1; part.index[k] = 0xffffffffu; }
+    } else {
+        if (int rc = queue_topr(ctx, d, c, c.nvalid, r)) return rc;
+        HIP_TRY(hipMemcpyAsync(part.scores, d.topr_scores.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipMemcpyAsync(part.index, d.topr_index.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    }
+    d.top_parts.push_back(part);
+    return 0;
+}
+
+// THE merge of top lists (the reference's order, utils.c:3-86: descending score, equal scores by DESCENDING database
+// index = descending key score << 32 | index): K candidates per query, score < 0 = empty slot, -> the r best.
+void merge_candidates(uint32_t nq, size_t K, const int32_t *cs, const uint32_t *ci, uint32_t r, int32_t *out_s, uint32_t *out_i)
+{
+    std::vector<uint64_t> keys;
+    for (uint32_t q = 0; q < nq; ++q) {
+        keys.clear();
+        for (size_t k = 0; k < K; ++k)
+            if (cs[q * K + k] >= 0) keys.push_back(((uint64_t)(uint32_t)cs[q * K + k] << 32) | ci[q * K + k]);
+        const size_t take = std::min<size_t>(r, keys.size());
+        std::partial_sort(keys.begin(), keys.begin() + take, keys.end(), std::greater<uint64_t>());
+        for (size_t j = 0; j < r; ++j) {
+            out_s[(size_t)q * r + j] = j < take ? (int32_t)(keys[j] >> 32) : -1;
+            out_i[(size_t)q * r + j] = j < take ? (uint32_t)(keys[j] & 0xffffffffu) : 0xffffffffu;
+        }
+    }
 }
 
 } // namespace
@@ -599,6 +753,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         return fail(OSWALD_HIP_ENODEV, "no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
     oswald_hip_ctx *ctx = new (std::nothrow) oswald_hip_ctx;
     if (!ctx) return fail(OSWALD_HIP_ENOMEM, "out of host memory");
+    ctx->tun.refresh();
     ctx->dev.resize(ndev);
     for (int i = 0; i < ndev; ++i) {
         Device &d = ctx->dev[i];
@@ -656,6 +811,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
                           &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8})
             b->release();
+        d.top_pool.release();
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
@@ -692,7 +848,8 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     if (!ctx || !submat) return fail(OSWALD_HIP_EINVAL, "null argument");
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
     if (open_gap + extend_gap > 32767) return fail(OSWALD_HIP_EINVAL, "open+extend must fit int16");
-    if (cell_bits == 0) cell_bits = getenv("OSWALD_HIP_CELL_BITS") ? atoi(getenv("OSWALD_HIP_CELL_BITS")) : 16;
+    ctx->tun.refresh();
+    if (cell_bits == 0) cell_bits = ctx->tun.cell_bits_default;
     if (cell_bits != 8 && cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 8, 16 or 32");
     const bool was_q8 = ctx->have_scoring && first_pass_is_q8(ctx);
     memcpy(ctx->submat, submat, 24 * 32);
@@ -729,6 +886,7 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
     ctx->total_rowblocks = off;
     ctx->max_rowblocks = mx;
     ctx->nq = nq;
+    ctx->tun.refresh();
     plan_pairs(ctx);
     ctx->have_queries = true;
     ctx->queries_version++;
@@ -751,7 +909,7 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     for (size_t i = 0; i < d.chunks.size(); ++i) if (!d.chunks[i].live && !d.chunks[i].upload_pending) { slot = (int)i; break; }
     if (slot < 0) { d.chunks.emplace_back(); slot = (int)d.chunks.size() - 1; }
     Chunk &c = d.chunks[slot];
-    PhaseTimer pt;
+    PhaseTimer pt(ctx->tun.debug_phases);
     const uint32_t gpb = OSW_BLOCK_SEQS / W;
     c.ngroups = ngroups;
     c.W = W;
@@ -798,6 +956,8 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols.data(), c.sub_cols_dev(), c.sub_cols.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, d.stream));
     c.items_version = ~0ull;
     c.searched = false;
+    c.has_index = false;
+    c.index_map.reset();
     c.live = true;
     c.upload_pending = true;
     *chunk = slot;
@@ -841,13 +1001,14 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
-    PhaseTimer pt;
+    PhaseTimer pt(ctx->tun.debug_phases);
     if (int r = finish_upload(d, c)) return r; // the planner reads the chunk's live extents
     if (int r = sync_queries(ctx, d)) return r;
     pt.lap("search: queries + profiles");
     if (int r = build_items(ctx, d, c)) return r;
     pt.lap("search: work-queue plan");
-    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return 0; }
+    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return topr_after_search(ctx, d, c); }
+    if (!d.bnd.p || d.bnd_stride == 0) return fail(OSWALD_HIP_ESTATE, "device %d has no spill scratch (an earlier allocation failed)", dev);
 
     OswSearchArgs a;
     memset(&a, 0, sizeof a);
@@ -857,9 +1018,9 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.items = (const uint2 *)c.items.p;
     a.nitems = c.nitems;
     a.nitems_wg = c.nitems_wg;
-    a.two_ended_waves = getenv("OSWALD_HIP_TWO_ENDED") ? (uint32_t)atoi(getenv("OSWALD_HIP_TWO_ENDED")) : 0u;
+    a.two_ended_waves = ctx->tun.two_ended;
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
-    a.debug_nospill = getenv("OSWALD_HIP_DEBUG_NOSPILL") ? 1u : 0u; // timing experiment only: results are wrong
+    a.debug_nospill = ctx->tun.debug_nospill ? 1u : 0u; // -DOSW_DIAG builds only (timing experiment: results are wrong); always 0 otherwise
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;
     a.qlen = (const uint16_t *)d.qlen.p;
@@ -886,7 +1047,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.goe = (int32_t)goe;
     a.ge = (int32_t)ge;
 
-    const bool dbg_times = getenv("OSWALD_HIP_DEBUG_TIMES") != nullptr;
+    const bool dbg_times = ctx->tun.debug_times; // -DOSW_DIAG builds only
     if (dbg_times) {
         HIP_TRY(d.wg_times.reserve((size_t)d.grid * 4 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(d.wg_times.p, 0, (size_t)d.grid * 4 * sizeof(unsigned long long), d.stream));
@@ -951,7 +1112,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         aq.pair_q = (const uint32_t *)d.pair_q.p;
         aq.counters = (uint32_t *)d.counters.p + OSW_CTR_COUNT;
         const uint32_t gq = std::min<uint32_t>(d.grid, (c.nitems_q + 3) / 4 + c.nitems_q_wg);
-        if (c.nitems + c.nitems_wg > 0 && !getenv("OSWALD_HIP_ONE_STREAM")) {
+        if (c.nitems + c.nitems_wg > 0 && !ctx->tun.one_stream) {
             // the single-query launch goes to a second stream so that its workgroups fill the slots the
             // pair launch frees while it drains (both are persistent grids pulling from their own queues)
             HIP_TRY(hipEventRecord(d.ev_fork, d.stream));
@@ -972,6 +1133,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     HIP_TRY(osw_launch_i32(a, std::min<uint32_t>(d.grid, 1024u), d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
+    if (int r = topr_after_search(ctx, d, c)) return r;
     if (dbg_times) {
         // diagnostics only: when did the workgroups of the DP launch start / leave phase 1 / finish
         HIP_TRY(hipStreamSynchronize(d.stream));
@@ -1019,11 +1181,11 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         // pin the caller's table for the copy: the DMA engine then writes it directly (a copy into a pageable
         // buffer it has not seen before runs at ~1 GB/s here, 8.9 ms for the 8 MB of C2; this way 0.5 ms)
         const size_t bytes = (size_t)ctx->nq * row * sizeof(int32_t);
-        if (bytes >= (1u << 20) && !getenv("OSWALD_HIP_NO_PIN")) {
+        if (bytes >= (1u << 20) && !ctx->tun.no_pin) {
             const auto t0 = std::chrono::steady_clock::now();
             if (hipHostRegister(scores_out, bytes, hipHostRegisterDefault) == hipSuccess) d.registered.push_back(scores_out);
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (ms > 5.0 && getenv("OSWALD_HIP_DEBUG_SLOW")) fprintf(stderr, "[oswald_hip] slow hipHostRegister: %zu bytes took %.1f ms\n", bytes, ms);
+            if (ms > 5.0 && g_debug_slow) fprintf(stderr, "[oswald_hip] slow hipHostRegister: %zu bytes took %.1f ms\n", bytes, ms);
             else (void)hipGetLastError(); // e.g. already pinned by the caller: the plain copy below is still correct
             pt.lap("search: pin caller's table");
         }
@@ -1081,15 +1243,89 @@ int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nval
     if (r == 0 || ctx->nq == 0) return 0;
     HIP_TRY(hipSetDevice(d.id));
     const size_t cnt = (size_t)ctx->nq * r;
-    HIP_TRY(d.topr_scores.reserve(cnt * sizeof(int32_t)));
-    HIP_TRY(d.topr_index.reserve(cnt * sizeof(uint32_t)));
     if (r > 1024) return fail(OSWALD_HIP_EINVAL, "top-r on the device supports r <= 1024 (asked for %u)", r);
-    HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * osw_topr_parts(nvalid) * r * sizeof(unsigned long long)));
-    HIP_TRY(osw_launch_topr((const int32_t *)c.scores.p, c.score_stride, nvalid, r, ctx->nq, (unsigned long long *)d.topr_cand.p, (int32_t *)d.topr_scores.p,
-                            (uint32_t *)d.topr_index.p, d.stream));
+    if (int rc = queue_topr(ctx, d, c, nvalid, r)) return rc;
     HIP_TRY(hipMemcpyAsync(scores, d.topr_scores.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipMemcpyAsync(index, d.topr_index.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipStreamSynchronize(d.stream));
+    return 0;
+}
+
+int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t first_index, uint32_t nvalid, const uint32_t *index_map)
+{
+    if (int r = check_dev(ctx, dev)) return r;
+    Device &d = ctx->dev[dev];
+    if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
+    Chunk &c = d.chunks[chunk];
+    if (nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "nvalid %u exceeds the chunk's %u lanes", nvalid, c.ngroups * c.W);
+    if (!index_map && (uint64_t)first_index + nvalid > 0xffffffffull) return fail(OSWALD_HIP_EINVAL, "database indices must fit 32 bits");
+    c.first_index = first_index;
+    c.nvalid = nvalid;
+    c.index_map.reset();
+    if (index_map) c.index_map = std::make_shared<const std::vector<uint32_t>>(index_map, index_map + nvalid);
+    c.has_index = true;
+    return 0;
+}
+
+int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r)
+{
+    if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
+    if (r > 1024) return fail(OSWALD_HIP_EINVAL, "top-r on the device supports r <= 1024 (asked for %u): download the score table instead", r);
+    for (Device &d : ctx->dev) {
+        HIP_TRY(hipSetDevice(d.id));
+        HIP_TRY(hipStreamSynchronize(d.stream)); // copies into the lists about to be dropped may still be queued
+        d.top_parts.clear();
+        d.top_pool.rewind();
+    }
+    ctx->topr_r = r;
+    return 0;
+}
+
+int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *db_index)
+{
+    if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
+    if (r == 0 || ctx->nq == 0) return 0;
+    if (!scores || !db_index) return fail(OSWALD_HIP_EINVAL, "null output");
+    if (ctx->topr_r == 0) return fail(OSWALD_HIP_ESTATE, "oswald_hip_topr_begin has not been called");
+    if (r > ctx->topr_r) return fail(OSWALD_HIP_EINVAL, "r = %u exceeds the %u lists were collected for (oswald_hip_topr_begin)", r, ctx->topr_r);
+    const uint32_t nq = ctx->nq;
+    size_t K = 0;
+    for (Device &d : ctx->dev) {
+        HIP_TRY(hipSetDevice(d.id));
+        HIP_TRY(hipStreamSynchronize(d.stream)); // the lists have landed
+        release_registered(d);
+        for (const TopPart &p : d.top_parts) {
+            if (p.nq != nq) return fail(OSWALD_HIP_ESTATE, "the query set changed while top lists were being collected");
+            K += p.r;
+        }
+    }
+    // all lists side by side, indices-in-chunk turned into database indices; then the one merge
+    std::vector<int32_t> cs((size_t)nq * K, -1);
+    std::vector<uint32_t> ci((size_t)nq * K, 0xffffffffu);
+    size_t k0 = 0;
+    for (const Device &d : ctx->dev)
+        for (const TopPart &p : d.top_parts) {
+            for (uint32_t q = 0; q < nq; ++q)
+                for (uint32_t j = 0; j < p.r; ++j) {
+                    const int32_t sc = p.scores[(size_t)q * p.r + j];
+                    const uint32_t ix = p.index[(size_t)q * p.r + j];
+                    if (sc < 0 || ix == 0xffffffffu) continue;
+                    if (p.index_map && ix >= p.index_map->size()) return fail(OSWALD_HIP_ERUNTIME, "top list index %u outside the chunk's index map", ix);
+                    cs[(size_t)q * K + k0 + j] = sc;
+                    ci[(size_t)q * K + k0 + j] = p.index_map ? (*p.index_map)[ix] : p.first_index + ix;
+                }
+            k0 += p.r;
+        }
+    merge_candidates(nq, K, cs.data(), ci.data(), r, scores, db_index);
+    return 0;
+}
+
+int oswald_hip_merge_candidates(uint32_t nq, uint64_t ncand, const int32_t *cand_scores, const uint32_t *cand_index, uint32_t r,
+                                int32_t *scores, uint32_t *db_index)
+{
+    if (nq == 0 || r == 0) return 0;
+    if ((ncand > 0 && (!cand_scores || !cand_index)) || !scores || !db_index) return fail(OSWALD_HIP_EINVAL, "null argument");
+    merge_candidates(nq, (size_t)ncand, cand_scores, cand_index, r, scores, db_index);
     return 0;
 }
 

@@ -72,10 +72,13 @@ int parse_opt(int key, char *arg, struct argp_state *state)
         o->extend_gap = atoi(arg);
         if (o->extend_gap < 0 || o->extend_gap > 127) argp_failure(state, 1, 0, "%d is not a valid option for gap extend penalty.", o->extend_gap);
         break;
-    case 'm':
-        o->execution_mode = !strcmp(arg, "host-only") ? 2 : atoi(arg);
-        if (o->execution_mode < 0 || o->execution_mode > 2) argp_failure(state, 1, 0, "%d is not a valid option for execution mode.", o->execution_mode);
+    case 'm': {
+        char *end = nullptr;
+        const long v = !strcmp(arg, "host-only") ? 2 : strtol(arg, &end, 10);
+        if ((end && (end == arg || *end)) || v < 0 || v > 2) argp_failure(state, 1, 0, "%s is not a valid option for execution mode.", arg);
+        o->execution_mode = (int)v;
         break;
+    }
     case 'c':
         o->cpu_threads = atoi(arg);
         if (o->cpu_threads < 0) argp_failure(state, 1, 0, "The number of host threads must be greater than 0.");
@@ -328,10 +331,11 @@ int do_search_hybrid(Options &o)
             }
         }
     };
-    auto cpu_groups = [&](uint64_t g0, uint64_t g1) {
+    // database groups [g0, g1) on the host cores, into `dst` (rows of `dst_row` scores, group `dst_g0` in column 0)
+    auto cpu_groups = [&](uint64_t g0, uint64_t g1, int32_t *dst, uint64_t dst_row, uint64_t dst_g0) {
         for (const oswald::Chunk &c : db.chunks) {
             const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
-            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, o.cpu_threads, scores.data(), row, a0 * W);
+            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, o.cpu_threads, dst, dst_row, (a0 - dst_g0) * W);
         }
     };
     // Test portion.  The host searches the first -p of the groups, as in the reference.  The accelerator's speed
@@ -347,23 +351,29 @@ int do_search_hybrid(Options &o)
             for (uint64_t g = 0; g < c.n.size() && have < want; ++g) { have += (double)c.n[g] * W; ++test_groups; }
         test_groups = std::min<uint64_t>(G, std::max<uint64_t>(1, test_groups));
     }
+    // Both sides run their test at the same time, as in the reference (two `omp single nowait` blocks,
+    // HybridSearch.c:124-228), which is why the report charges max(test_fpga_time, test_cpu_time), :1227.  The host's
+    // test scores go to a table of their own and are dropped: the accelerator fills the same columns for good.
     double test_gpu_time = 0, test_cpu_time = 0, gpu_gcups = 0;
     uint64_t gpu_done = 0;
-    for (uint64_t n = test_groups; gpu_done < G; n *= 2) {
-        const uint64_t g1 = std::min<uint64_t>(G, gpu_done + n);
-        const double t = dwalltime();
-        gpu_groups(gpu_done, g1);
-        const double dt = dwalltime() - t;
-        gpu_gcups = q.Q * (double)padded(gpu_done, g1) / (dt * 1e9);
-        test_gpu_time += dt;
-        gpu_done = g1;
-        if (dt >= 0.02) break;
-    }
     {
-        // (the same table columns the accelerator has just filled -- the same scores)
-        const double t = dwalltime();
-        cpu_groups(0, test_groups);
-        test_cpu_time = dwalltime() - t;
+        std::vector<int32_t> test_scores(nq * test_groups * W, 0);
+        std::thread host_test([&] {
+            const double t = dwalltime();
+            cpu_groups(0, test_groups, test_scores.data(), test_groups * W, 0);
+            test_cpu_time = dwalltime() - t;
+        });
+        for (uint64_t n = test_groups; gpu_done < G; n *= 2) {
+            const uint64_t g1 = std::min<uint64_t>(G, gpu_done + n);
+            const double t = dwalltime();
+            gpu_groups(gpu_done, g1);
+            const double dt = dwalltime() - t;
+            gpu_gcups = q.Q * (double)padded(gpu_done, g1) / (dt * 1e9);
+            test_gpu_time += dt;
+            gpu_done = g1;
+            if (dt >= 0.02) break;
+        }
+        host_test.join();
     }
     const double cpu_gcups = q.Q * (double)padded(0, test_groups) / (test_cpu_time * 1e9);
     printf("Test DB percentage:\t\t%.4lf%% \n", o.test_db_percentage);
@@ -381,7 +391,7 @@ int do_search_hybrid(Options &o)
     const double tick = dwalltime();
     {
         std::thread gpu([&] { gpu_groups(gpu_done, split); });
-        cpu_groups(split, G);
+        cpu_groups(split, G, scores.data(), row, 0);
         gpu.join();
     }
     const double work_time = dwalltime() - tick;
@@ -412,15 +422,14 @@ int do_search(Options &o)
     print_header(o, db);
 
     if (db.sequences_count < o.top) o.top = db.sequences_count;
-    // The report needs the top-r scores per query only.  For r <= 1024 they are selected on the device, chunk
-    // by chunk, with the reference's tie rule (utils.c:3-86: equal scores -> later database index first) and
-    // merged here; the full score table (the reference downloads and sorts it, FPGAsearch.c:232, :312-321)
-    // is only brought to the host for larger r.
+    // The report needs the top-r scores per query only.  For r <= 1024 they are selected on the devices, chunk by
+    // chunk, and merged by the library with the reference's tie rule (oswald_hip_topr; utils.c:3-86: equal scores ->
+    // later database index first); the full score table (the reference downloads and sorts it, FPGAsearch.c:232,
+    // :312-321) is only brought to the host for larger r.
     const bool device_top = o.top <= 1024;
     std::vector<int32_t> scores;
     if (!device_top) scores.assign(nq * db.vect_sequences_count * W, 0);
     std::vector<std::vector<int32_t>> tmp(o.num_devices);
-    std::vector<std::vector<std::pair<int32_t, uint64_t>>> cand(nq); // (score, database index) per query, all chunks
 
     // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80)
     oswald_hip_ctx *ctx = nullptr;
@@ -430,19 +439,20 @@ int do_search(Options &o)
     const double tick = dwalltime();
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
+    if (device_top) check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");
     // chunk c of a round goes to device c mod ndev (reference FPGAsearch.c:132-138)
     std::vector<int> handle(o.num_devices, -1);
-    std::vector<int32_t> ts_dev;
-    std::vector<uint32_t> ti_dev;
     for (size_t k = 0; k < db.chunks.size(); k += o.num_devices) {
         const size_t active = std::min<size_t>(o.num_devices, db.chunks.size() - k);
         // uploads of the round's chunks are queued on all devices first (they overlap), then every device is
-        // given its search
+        // given its search; the chunk's top list is selected on the device behind the search
         if (device_top)
             for (size_t d = 0; d < active; ++d) {
                 const oswald::Chunk &c = db.chunks[k + d];
                 check(oswald_hip_chunk_upload_async(ctx, (int)d, c.b, c.b_size, c.n.data(), c.disp.data(), (uint32_t)c.n.size(), (uint32_t)W,
                                                     &handle[d]), "chunk upload");
+                const uint64_t first = c.accum * W, last = std::min<uint64_t>(db.sequences_count, (c.accum + c.n.size()) * W);
+                check(oswald_hip_chunk_set_index(ctx, (int)d, handle[d], (uint32_t)first, (uint32_t)(last - first), nullptr), "chunk index");
             }
         for (size_t d = 0; d < active; ++d) {
             const oswald::Chunk &c = db.chunks[k + d];
@@ -458,14 +468,7 @@ int do_search(Options &o)
         for (size_t d = 0; d < active; ++d) {
             const oswald::Chunk &c = db.chunks[k + d];
             if (device_top) {
-                const uint64_t first = c.accum * W, last = std::min<uint64_t>(db.sequences_count, (c.accum + c.n.size()) * W);
-                const uint32_t nvalid = (uint32_t)(last - first), r = (uint32_t)std::min<uint64_t>(o.top, nvalid);
-                ts_dev.resize(nq * r);
-                ti_dev.resize(nq * r);
-                check(oswald_hip_chunk_topr(ctx, (int)d, handle[d], nvalid, r, ts_dev.data(), ti_dev.data()), "top scores"); // waits for the device
-                check(oswald_hip_chunk_release(ctx, (int)d, handle[d]), "chunk release");
-                for (uint64_t qi = 0; qi < nq; ++qi)
-                    for (uint32_t j = 0; j < r; ++j) cand[qi].push_back({ts_dev[qi * r + j], first + ti_dev[qi * r + j]});
+                check(oswald_hip_chunk_release(ctx, (int)d, handle[d]), "chunk release"); // waits for the device: the host buffers of the round are free again
             } else {
                 const size_t row = c.n.size() * W;
                 for (uint64_t qi = 0; qi < nq; ++qi)
@@ -473,34 +476,25 @@ int do_search(Options &o)
             }
         }
     }
+    // top lists of all queries (inside the timed region: they stand for the download of the score table)
+    std::vector<std::vector<int32_t>> top_s(nq);
+    std::vector<std::vector<uint64_t>> top_i(nq);
+    if (device_top) {
+        std::vector<int32_t> ms(nq * o.top);
+        std::vector<uint32_t> mi(nq * o.top);
+        check(oswald_hip_topr(ctx, (uint32_t)o.top, ms.data(), mi.data()), "top scores");
+        for (uint64_t i = 0; i < nq; ++i)
+            for (uint64_t j = 0; j < o.top && ms[i * o.top + j] >= 0; ++j) { top_s[i].push_back(ms[i * o.top + j]); top_i[i].push_back(mi[i * o.top + j]); }
+    }
     const double workTime = dwalltime() - tick;
     lap("search (timed region)");
     oswald_hip_finalize(ctx);
     lap("device release");
 
-    // top lists of all queries first, then only the titles the report prints (the reference loads every title,
-    // sequences.c:1096-1127; a 1 M-sequence database has 1 M of them for 10 lines per query)
-    std::vector<std::vector<int32_t>> top_s(nq);
-    std::vector<std::vector<uint64_t>> top_i(nq);
-    std::vector<uint64_t> wanted;
-    for (uint64_t i = 0; i < nq; ++i) {
-        std::vector<int32_t> &ts = top_s[i];
-        std::vector<uint64_t> &ti = top_i[i];
-        if (device_top) {
-            // merge of the chunks' lists: descending score, ties by descending database index
-            auto &cd = cand[i];
-            std::sort(cd.begin(), cd.end(), [](const std::pair<int32_t, uint64_t> &x, const std::pair<int32_t, uint64_t> &y) {
-                return x.first != y.first ? x.first > y.first : x.second > y.second;
-            });
-            const size_t r = std::min<size_t>(o.top, cd.size());
-            ts.resize(r);
-            ti.resize(r);
-            for (size_t j = 0; j < r; ++j) { ts[j] = cd[j].first; ti[j] = cd[j].second; }
-        } else {
-            oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, ts, ti);
-        }
-        wanted.insert(wanted.end(), ti.begin(), ti.end());
-    }
+    // then only the titles the report prints (the reference loads every title, sequences.c:1096-1127; a
+    // 1 M-sequence database has 1 M of them for 10 lines per query)
+    if (!device_top)
+        for (uint64_t i = 0; i < nq; ++i) oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, top_s[i], top_i[i]);
     lap("top scores");
     print_report(o, q, db, top_s, top_i, current_time, workTime, workTime);
     lap("headers + report");

@@ -97,19 +97,26 @@ class ShardedDatabase:
                     ls=ls, res=res, off=off)
 
 
-def rank_step(chunks, launch, collect, nq: int, r: int, index_base: int = 0, dist=None, device=None):
-    """One search step of a rank: launch(chunk) queues the search of every chunk, collect(chunk) returns its
-    top list (scores [nq][r], index-in-chunk uint32 with 0xffffffff = empty); the lists are merged over the
-    rank's chunks and gathered over the ranks.  Returns the global ([nq][r] scores, [nq][r] sorted positions)."""
+def rank_step(chunks, launch, collect, nq: int, r: int, index_base: int = 0, dist=None, device=None, collect_rank=None):
+    """One search step of a rank: launch(chunk) queues the search of every chunk; then either collect_rank() returns
+    the rank's merged top list (oswald_hip_topr: [nq][r] scores, [nq][r] uint32 database indices, 0xffffffff = empty
+    slot), or collect(chunk) returns each chunk's list (scores [nq][r], index-in-chunk uint32 with 0xffffffff = empty)
+    and the lists are merged here.  The rank lists are gathered over the ranks.  Returns the global ([nq][r] scores,
+    [nq][r] sorted positions)."""
     for c in chunks:
         launch(c)
-    parts = []
-    for c in chunks:
-        sc, ix = collect(c)
-        parts.append((sc, global_index(ix, index_base + c["s0"], c.get("gpos"), index_base)))
-    if not parts:  # more ranks than chunks: this rank has nothing to search
-        parts = [(np.full((nq, r), -1, np.int32), np.full((nq, r), -1, np.int64))]
-    sc, gix = merge_local(parts, r)
+    if collect_rank is not None:
+        sc, ix = collect_rank()
+        ix = np.asarray(ix).astype(np.int64)
+        sc, gix = np.asarray(sc, dtype=np.int32), np.where(ix == 0xFFFFFFFF, -1, ix + int(index_base))
+    else:
+        parts = []
+        for c in chunks:
+            sc, ix = collect(c)
+            parts.append((sc, global_index(ix, index_base + c["s0"], c.get("gpos"), index_base)))
+        if not parts:  # more ranks than chunks: this rank has nothing to search
+            parts = [(np.full((nq, r), -1, np.int32), np.full((nq, r), -1, np.int64))]
+        sc, gix = merge_local(parts, r)
     return gather_topr(sc, gix, r, dist, device)
 
 
@@ -126,11 +133,21 @@ def global_index(chunk_index: np.ndarray, base: int, gpos=None, gpos_base: int =
     return np.where(empty, -1, ix + int(base))
 
 
+def merge_rows(scores: np.ndarray, index: np.ndarray, r: int):
+    """[nq][K] candidates (index < 0 = empty slot) -> ([nq][r] int32, [nq][r] int64), empty slots (-1, -1): the
+    library's one merge implementation (oswald_hip_merge_candidates: descending score, ties by descending index)."""
+    from . import capi
+    index = np.asarray(index, dtype=np.int64)
+    cs = np.where(index < 0, -1, np.asarray(scores)).astype(np.int32)
+    out_s, out_i = capi.merge_candidates(cs, np.where(index < 0, 0, index).astype(np.uint32), r)
+    return out_s, np.where(out_s < 0, -1, out_i.astype(np.int64))
+
+
 def merge_local(parts, r: int):
     """Top lists of one rank's chunks ([(scores [nq][r], global index [nq][r]), ...]) -> one ([nq][r], [nq][r])."""
     if len(parts) == 1:
         return parts[0][0].astype(np.int32), parts[0][1].astype(np.int64)
-    return dblayout.merge_topr_rows(np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1), r)
+    return merge_rows(np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1), r)
 
 
 def gather_topr(local_scores: np.ndarray, local_global_index: np.ndarray, r: int, dist=None, device=None):
@@ -138,7 +155,7 @@ def gather_topr(local_scores: np.ndarray, local_global_index: np.ndarray, r: int
     index < 0 = empty slot) and merge them on every rank.  `dist` is
     torch.distributed (initialised) or None for a single process."""
     if dist is None or dist.get_world_size() == 1:
-        return dblayout.merge_topr_rows(local_scores, local_global_index, r)
+        return merge_rows(local_scores, local_global_index, r)
     import torch
     mine = torch.from_numpy(np.stack([local_scores.astype(np.int64), local_global_index.astype(np.int64)], axis=0))
     if device is not None:
@@ -148,4 +165,4 @@ def gather_topr(local_scores: np.ndarray, local_global_index: np.ndarray, r: int
     allp = torch.stack(got).cpu().numpy()            # [world][2][nq][r]
     sc = np.concatenate(list(allp[:, 0]), axis=1)
     ix = np.concatenate(list(allp[:, 1]), axis=1)
-    return dblayout.merge_topr_rows(sc, ix, r)
+    return merge_rows(sc, ix, r)

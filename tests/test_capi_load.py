@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert capi.load().oswald_hip_abi_version() == 1
+    assert capi.load().oswald_hip_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure():
@@ -57,3 +57,22 @@ def test_header_documents_the_cell_modes():
     text = open(os.path.join(ROOT, "include", "oswald_hip.h")).read()
     for word in ("cell_bits", "packed int16", "22256", "int32"):
         assert word in text
+
+
+def test_merge_candidates_is_the_reference_order():
+    """oswald_hip_merge_candidates (the library's one top-list merge; host logic, runs without a GPU) against the
+    numpy mirror of sort_scores()'s order (reference utils.c:3-86: descending score, ties by DESCENDING index) --
+    many ties, empty slots, fewer candidates than r."""
+    import numpy as np
+    from oswald_amd import dblayout
+    rng = np.random.default_rng(5)
+    for nq, K, r in ((1, 1, 1), (3, 40, 10), (5, 300, 25), (2, 7, 12), (4, 0, 3)):
+        sc = rng.integers(0, 6, size=(nq, K)).astype(np.int32)
+        ix = np.stack([rng.permutation(100000)[:K] for _ in range(nq)]).astype(np.int64) if K else np.zeros((nq, 0), np.int64)
+        empty = rng.random((nq, K)) < 0.2
+        ix[empty] = -1
+        got_s, got_i = capi.merge_candidates(np.where(empty, -1, sc), np.where(empty, 0, ix).astype(np.uint32), r)
+        want_s, want_i = dblayout.merge_topr_rows(sc, ix, r)
+        np.testing.assert_array_equal(got_s, want_s)
+        np.testing.assert_array_equal(np.where(got_s < 0, -1, got_i.astype(np.int64)), want_i)
+        assert ((got_i == 0xFFFFFFFF) == (got_s < 0)).all()

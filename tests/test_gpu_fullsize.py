@@ -163,7 +163,7 @@ def test_c4_database_on_one_gpu_chunked(hip_ctx, oracle):
     per-chunk device top-r merged to the global top-10 (positions in the globally sorted database)."""
     qs = synth.make_queries(synth.default_query_lengths())
     plan = synth.DatabasePlan(1000000, qs, synth.SEED_DB, 12)
-    shard = multigpu.ShardedDatabase(plan, 16, 134217728, 1, 0)
+    shard = multigpu.ShardedDatabase(plan, 16, 134217728, 1, 0, "reference")
     assert len(shard.mine) >= 3
     a, m, ad = pack_queries(qs)
     sm = submat.load("blosum62")

@@ -589,3 +589,62 @@ def test_many_queries_in_one_set(hip_ctx, oracle, bits):
     got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2, cell_bits=bits)
     want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("dealt", [False, True])
+def test_context_level_topr_over_chunks_and_devices(oracle, dealt):
+    """oswald_hip_topr (reference FPGAsearch.c:236-237 merge, :312-321 + utils.c:71-86 sort): two context
+    devices, five chunks in three rounds (slots re-used: the lists are collected at search time), r larger than some
+    chunks; the merged list equals the top r of the whole score table in the reference's order -- with chunks that are
+    contiguous runs (first_index) and with chunks dealt block-wise (index map).  Ties are plentiful (short sequences)."""
+    from oswald_amd import capi, multigpu
+    qs = synth.make_queries([33, 60, 61, 150], seed=141)
+    NSEQ = 1400
+    L, R, O = random_db(NSEQ, seed=143, max_len=70, queries=qs[-1:], homologs=3)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    whole = expect(oracle, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
+    if dealt:   # five "ranks'" shares of the database as five chunks: none is a contiguous run
+        pieces = [multigpu.dealt_positions(NSEQ, 5, k) for k in range(5)]
+    else:
+        plan = dblayout.chunk_plan(nfull, 16, 16 * int(nfull.sum()) // 5 + 1, 1)
+        assert len(plan) >= 5
+        pieces = [np.arange(g0 * 16, min(g1 * 16, NSEQ)) for g0, g1 in plan]
+    r = 300
+    with capi.Context(2, [0, 0]) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        for rep in range(2):   # a second collection starts from scratch
+            ctx.topr_begin(r)
+            for k in range(0, len(pieces), 2):
+                live = []
+                for d in range(min(2, len(pieces) - k)):
+                    pos = pieces[k + d]
+                    ls = sl[pos]
+                    off = np.zeros(len(pos) + 1, np.int64)
+                    np.cumsum(ls, out=off[1:])
+                    res = np.concatenate([sr[so[p]:so[p + 1]] for p in pos])
+                    b, n, disp = dblayout.interleave(ls, res, off, 16)
+                    h = ctx.chunk_upload(b, n, disp.astype(np.uint32), 16, dev=d, wait=False)
+                    if dealt:
+                        ctx.chunk_set_index(h, 0, len(pos), pos, dev=d)
+                    else:
+                        ctx.chunk_set_index(h, int(pos[0]), len(pos), None, dev=d)
+                    live.append((d, h, b, n, disp))
+                for d, h, *_ in live:
+                    ctx.chunk_search(h, None, dev=d)
+                for d, h, *_ in live:
+                    ctx.chunk_release(h, dev=d)
+            for rr in (r, 10):
+                sc, ix = ctx.topr(rr)
+                for q in range(len(qs)):
+                    ws, wi = dblayout.topr_reference_order(whole[q, :NSEQ], rr)
+                    np.testing.assert_array_equal(sc[q], ws)
+                    np.testing.assert_array_equal(ix[q], wi)
+        with pytest.raises(capi.OswaldHipError):
+            ctx.topr(r + 1)            # more than was collected
+        with pytest.raises(capi.OswaldHipError):
+            ctx.topr_begin(5000)       # the device selection stops at 1024
+    assert len(np.unique(whole[0, :NSEQ])) < NSEQ // 4   # ties are present
