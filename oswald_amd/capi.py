@@ -14,6 +14,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboswald_hip.so")
+# tools/ only: OSWALD_HIP_USE_DIAG_LIB=1 loads the -DOSW_DIAG build (`make -C oswald_amd/csrc diag`), which also reads the
+# planner sweep knobs and the kernel timing diagnostics from the environment; tests and bench.py's records never set it
+if os.environ.get("OSWALD_HIP_USE_DIAG_LIB"):
+    LIB_PATH = os.path.join(_HERE, "liboswald_hip_diag.so")
 
 # every symbol include/oswald_hip.h declares
 SYMBOLS = (

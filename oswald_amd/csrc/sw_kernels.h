@@ -131,8 +131,8 @@ struct OswSearchArgs {
     uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves; column-frame kernels: (open, extend)
     uint32_t goe_fb, ge_fb;    // column-frame kernels: (open+extend, extend) for the plain cell
     int32_t goe, ge;
-    uint32_t debug_nospill;    // diagnostics: every round reads the constant top row and stores to the trash page (WRONG scores; timing only)
-    unsigned long long *wg_times; // diagnostics (or null): per workgroup {start, end of phase 1, end, end} in 100 MHz ticks
+    uint32_t debug_nospill;    // -DOSW_DIAG builds only: every round reads the constant top row and stores to the trash page (WRONG scores; timing only)
+    unsigned long long *wg_times; // -DOSW_DIAG builds only (or null): per workgroup {start, end of phase 1, end, end} in 100 MHz ticks
 };
 
 // host-side launchers, defined in sw_kernels.hip

@@ -889,6 +889,17 @@ static __device__ __forceinline__ void fill_profile_slice(const E *prof_q, uint3
     }
 }
 
+// Diagnostics that exist only in the -DOSW_DIAG build of the library (liboswald_hip_diag.so, tools/): per-workgroup
+// time stamps, and a timing experiment that makes every round read the constant top row and store to the trash page
+// (WRONG scores, same instruction stream, no spill traffic).  The shipped library contains neither.
+#ifdef OSW_DIAG
+#define OSW_DIAG_NOSPILL(p) ((p).debug_nospill != 0)
+#define OSW_DIAG_STAMP(cond, slot) do { if (p.wg_times && (cond)) p.wg_times[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define OSW_DIAG_NOSPILL(p) false
+#define OSW_DIAG_STAMP(cond, slot) do { } while (0)
+#endif
+
 // One work item: all rounds of (query q, block B, sub-block sigma) at geometry G.
 // Returns the lane's best score (valid in the lanes of group 0 after the
 // cross-group reduction).
@@ -932,14 +943,17 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
         if (wg) {
-            // (diagnostics, OSWALD_HIP_DEBUG_TIMES: core-clock cycles this wave spends in the slice reload incl. both barriers)
+#ifdef OSW_DIAG // (OSWALD_HIP_DEBUG_TIMES: core-clock cycles this wave spends in the slice reload incl. both barriers)
             const unsigned long long tb = p.wg_times ? __builtin_readcyclecounter() : 0ull;
+#endif
             __syncthreads(); // every wave is done with the previous slice
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
             fill_profile_slice<Entry>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
             __syncthreads();
+#ifdef OSW_DIAG
             if (p.wg_times && lane == 0) atomicAdd(&p.counters_ovf[4], (uint32_t)((__builtin_readcyclecounter() - tb) >> 10));
+#endif
         } else {
             // only this wave touches its region; LDS operations of one wave execute in order, the wave barriers
             // only pin the compiler's order
@@ -949,7 +963,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             __builtin_amdgcn_wave_barrier();
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
-        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, p.top_pages, rho == 0 || p.debug_nospill, rho + 1 == plan.rounds || p.debug_nospill, G, gl, lane, half, goe, ge, score);
+        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, p.top_pages, rho == 0 || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
     // addresses are computed here instead of being kept in registers across all the rounds)
@@ -1046,8 +1060,8 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
 
-    // optional diagnostics: when each workgroup started, left phase 1 and finished (100 MHz ticks)
-    if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    // (-DOSW_DIAG: when each workgroup started, left phase 1 and finished, 100 MHz ticks)
+    OSW_DIAG_STAMP(threadIdx.x == 0, blockIdx.x * 4 + 0);
 
     // Which end of the (cost-sorted) queues this workgroup eats from: the first workgroup to
     // arrive on a CU takes the heavy end, later arrivals the light end, so that a long item
@@ -1085,7 +1099,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
             __syncthreads();
             if (it >= p.nitems_wg) { // all four waves see this together
                 phase1 = false;
-                if (p.wg_times && threadIdx.x == 0) p.wg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+                OSW_DIAG_STAMP(threadIdx.x == 0, blockIdx.x * 4 + 1);
                 continue;
             }
             item = p.items[(size_t)it * 4 + wv];
@@ -1120,7 +1134,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         }
         set_wave_prio(0);
     }
-    if (p.wg_times && lane == 0) p.wg_times[blockIdx.x * 4 + 2 + (wv & 1)] = __builtin_amdgcn_s_memrealtime(); // waves 0/1 (or 2/3) race: any is fine
+    OSW_DIAG_STAMP(lane == 0, blockIdx.x * 4 + 2 + (wv & 1)); // waves 0/1 (or 2/3) race: any is fine
 }
 
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16B, CellPK16B, false>(p); }
