@@ -252,7 +252,15 @@ int bias8_of(const oswald_hip_ctx *ctx)
     for (int i = 0; i < 24 * 32; ++i) { mn = std::min<int>(mn, ctx->submat[i]); mx = std::max<int>(mx, ctx->submat[i]); }
     return (mx - mn <= 127 && ctx->open_gap <= 127 && ctx->extend_gap <= 127) ? -mn : -1;
 }
-bool first_pass_is_q8(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 8 && bias8_of(ctx) >= 0; }
+// ... and the cell's offset c = max(open + extend, bias) must leave room for scores (q8_cell.h: CellQ8::offset_for)
+int offset8_of(const oswald_hip_ctx *ctx)
+{
+    const int bias = bias8_of(ctx);
+    if (bias < 0) return -1;
+    const int c = std::max(ctx->open_gap + ctx->extend_gap, bias);
+    return c <= 64 ? c : -1;
+}
+bool first_pass_is_q8(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 8 && offset8_of(ctx) >= 0; }
 
 // Pair up queries of similar length (sorted by length, neighbours): a pair costs 7.5 instructions per row of
 // the LONGER query for one sequence, two singles 8.5 per row for two sequences, so pairing pays when the
@@ -404,7 +412,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     const Kind kinds[2] = {
         {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16,
          i32 ? 24.0 : first_pass_is_frame(ctx) ? 7.5 : 8.5, 1.0},
-        q8 ? Kind{OSW_RMAX8, OSW_LDS_ROWS8, 50.0, 1.0} // SWAR 8-bit pairs: ~50 instructions per row of a 2 x 2 tile, one pass, wave items only
+        q8 ? Kind{OSW_RMAX8, OSW_LDS_ROWS8, 26.0, 1.0} // SWAR 8-bit pairs: 44 instructions per row of a 2 x 2 tile, most of them at ~2.4 cycles: as 26 full-cost ones; one pass, wave items only
            : Kind{OSW_RMAX16, OSW_LDS_ROWS16 / 2, first_pass_is_frame(ctx) ? 6.5 : 7.5, 2.0}};
     struct Entity { uint32_t m, id, kind; };
     std::vector<Entity> ents;
@@ -1083,10 +1091,10 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             aq.pair_q = (const uint32_t *)d.pair_q.p;
             aq.counters = (uint32_t *)d.counters.p + OSW_CTR_COUNT;
             aq.ovf8_items = (uint2 *)c.ovf8.p;
-            const uint32_t b8 = (uint32_t)bias8_of(ctx), go8 = (uint32_t)ctx->open_gap, ge8 = (uint32_t)ctx->extend_gap;
-            aq.bias8 = b8 * 0x01010101u;
-            aq.go8 = go8 * 0x01010101u;
-            aq.ge8 = ge8 * 0x01010101u;
+            aq.bias8 = (uint32_t)bias8_of(ctx);
+            aq.go8 = (uint32_t)ctx->open_gap;
+            aq.ge8 = (uint32_t)ctx->extend_gap;
+            aq.off8 = (uint32_t)offset8_of(ctx);
             HIP_TRY(osw_launch_q8(aq, std::min<uint32_t>(d.grid, (c.nitems_q + 3) / 4), d.stream));
         }
         if (c.nitems + c.nitems_wg > 0) HIP_TRY(osw_launch_pk16(as, grid, d.stream));

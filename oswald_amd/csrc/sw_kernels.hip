@@ -535,6 +535,16 @@ struct CellI32 {
     static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
     static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
+    // (the compiler-scheduled round asks the cell for its representation of "zero": the 8-bit cell's depends on the scoring system)
+    static __device__ __forceinline__ uint32_t zero_bits(GapT) { return 0u; }
+    static __device__ __forceinline__ T score_init(GapT) { return 0; }
+    template <int R>
+    static __device__ __forceinline__ void init_state(T (&D)[R], T (&E)[R], T &top_prev, GapT)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { D[r] = 0; E[r] = 0; }
+        top_prev = 0;
+    }
 
     template <int R>
     static __device__ __forceinline__ void column(uint32_t base, uint32_t codes, int half, T (&D)[R], T (&E)[R],
@@ -560,82 +570,8 @@ struct CellI32 {
     }
 };
 
-// ---------------------------------------------------------------------------
-// 8-bit cells (BASELINE configs[2]: "int8 packed cells with int16 overflow re-run"; the reference's first
-// pass is 16 x int8 with saturation at 127, sw.cl:60-78, HybridSearch.c:1618-1633, and everything that reaches
-// 127 is redone in int16, :1670-1680).  gfx950 has no packed 8-bit maximum or saturating add, so four 7-bit
-// values ride in the four bytes of a register, bit 7 of every byte is a guard, and maximum / saturating
-// subtract are SWAR sequences of plain 32-bit operations (6 each).  A lane works on a 2 x 2 tile: the two
-// queries of a pair against its two sequences, bytes {A.s0, B.s0, A.s1, B.s1}.  The profile stores S + bias
-// (bias = -min S, so every entry is a 7-bit non-negative byte); a diagonal sum D + S + bias >= 128 sets the
-// guard bit, which is OR-ed into a sticky flag per byte: a flagged (query, sequence) has left the 7-bit range
-// at some point and is queued for the packed-int16 kernel; one that was never flagged is exact.  About three
-// times the instructions per cell of the packed-int16 cell: this mode exists for the configuration, not for
-// speed.  Compiler-scheduled (sw_round_plain).
-// ---------------------------------------------------------------------------
-struct CellQ8 {
-    typedef uint32_t T;
-    struct GapT { uint32_t go, ge, bias; }; // gap OPEN, gap extend and the profile bias, each replicated in the four bytes
-    static constexpr bool kFast = false;
-    static constexpr uint32_t kFloorBits = 0;
-    static constexpr bool kShifted = false;
-    static constexpr int kRows = OSW_RMAX8;
-    static constexpr int kLdsRows = OSW_LDS_ROWS8;
-    static constexpr int kRowBytes = 64; // 32 codes x 2 queries x 1 byte
-    typedef uint2 Entry;                 // one code: 4 rows x (S_A, S_B) bytes
-    static constexpr uint32_t G = 0x80808080u, L = 0x7f7f7f7fu;
-    static __device__ __forceinline__ T zero() { return 0u; }
-    static __device__ __forceinline__ T from_bits(uint32_t x) { return x; }
-    static __device__ __forceinline__ uint32_t to_bits(T x) { return x; }
-    // per byte, operands 7-bit: 0x7f where a >= b, else 0
-    static __device__ __forceinline__ uint32_t ge_mask(uint32_t a, uint32_t b)
-    {
-        const uint32_t m = ((a | G) - b) & G;
-        return m - (m >> 7);
-    }
-    static __device__ __forceinline__ uint32_t max7(uint32_t a, uint32_t b)
-    {
-        const uint32_t k = ge_mask(a, b);
-        return (a & k) | (b & ~k);
-    }
-    static __device__ __forceinline__ uint32_t satsub7(uint32_t a, uint32_t c) // max(a - c, 0)
-    {
-        const uint32_t d = (a | G) - c, m = d & G;
-        return d & (m - (m >> 7));
-    }
-    // running score: low 7 bits of every byte the best score, bit 7 the sticky "left the 7-bit range" flag
-    static __device__ __forceinline__ T vmax(T a, T b) { return max7(a & L, b & L) | ((a | b) & G); }
-
-    template <int R>
-    static __device__ __forceinline__ void column(uint32_t base, uint32_t codes, int /*half*/, T (&D)[R], T (&E)[R],
-                                                  T top_prev, T &f, T &hl, GapT gp, GapT /*same*/, T &score)
-    {
-        const uint32_t go = gp.go, ge = gp.ge, bias = gp.bias;
-        const lds_cp l0 = (lds_cp)(uintptr_t)(base + (codes & 0xffu)), l1 = (lds_cp)(uintptr_t)(base + ((codes >> 8) & 0xffu));
-        T diag = top_prev, sc = score & L, fl = score;
-#pragma unroll
-        for (int rb = 0; rb < R / 4; ++rb) {
-            const u32x2 p0 = *(lds_u2p)(l0 + rb * 256), p1 = *(lds_u2p)(l1 + rb * 256);
-            const uint32_t s[4] = {__builtin_amdgcn_perm(p1.x, p0.x, 0x05040100u), __builtin_amdgcn_perm(p1.x, p0.x, 0x07060302u),
-                                   __builtin_amdgcn_perm(p1.y, p0.y, 0x05040100u), __builtin_amdgcn_perm(p1.y, p0.y, 0x07060302u)};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = rb * 4 + k;
-                uint32_t y = diag + s[k];         // D + S + bias: at most 127 + 127, no carry between the bytes
-                fl |= y;                          // guard bit set: out of range from here on (sticky)
-                y &= L;
-                const uint32_t x = satsub7(y, bias);
-                const uint32_t h = max7(max7(x, E[r]), f);
-                const uint32_t u = satsub7(h, go); // H - gap open
-                E[r] = satsub7(max7(E[r], u), ge);
-                f = satsub7(max7(f, u), ge);
-                sc = max7(sc, h);
-                if (r + 1 < R) { diag = D[r + 1]; D[r + 1] = h; } else { hl = h; }
-            }
-        }
-        score = sc | (fl & G);
-    }
-};
+// The 8-bit cell of cell_bits = 8 (SWAR: four 7-bit cells per register, offset domain): q8_cell.h.
+#include "q8_cell.h"
 
 static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 {
@@ -806,21 +742,20 @@ static __device__ __forceinline__ void sw_round_plain(const uint16_t *tcol, uint
                                                       typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
     typedef typename C::T T;
-    T D[R], E[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { D[r] = C::zero(); E[r] = C::zero(); }
-    T top_prev = C::zero();
+    T D[R], E[R], top_prev;
+    C::template init_state<R>(D, E, top_prev, goe);
+    const uint32_t zb = C::zero_bits(goe); // H / F of a row above that does not exist, as they travel between strips
     const bool g0 = (uint32_t)lane < gl;
     const bool glast = (uint32_t)lane >= 64u - gl;
     const int src = ((lane - (int)gl) & 63) << 2;
     const uint16_t *tb = tcol + u;
     uint2 *col = bnd + OSW_SCRATCH_DATA + u;
     const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
-    uint32_t hand_h = 0, hand_f = 0, hand_c = dummy;
+    uint32_t hand_h = zb, hand_f = zb, hand_c = dummy;
     const uint32_t nsteps = ncols + G - 1;
 #pragma unroll 1
     for (uint32_t t = 0; t < nsteps; ++t) {
-        uint32_t codes = dummy, topb = 0, fb = 0;
+        uint32_t codes = dummy, topb = zb, fb = zb;
         if (t < ncols) {
             codes = tb[(size_t)t * 64];
             if (!first) { const uint2 b = col[(size_t)t * gl]; topb = b.x; fb = b.y; }
@@ -937,8 +872,10 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             pad[k] = make_uint2(z, z);
         }
     }
-    T score = C::zero();
-    if constexpr (C::kShifted) score = C::from_bits(0u); // the column-frame cell keeps a true (unbiased) running score
+    T score;
+    if constexpr (!C::kFast) score = C::score_init(goe);   // compiler-scheduled cells: "zero" may depend on the scoring system (8-bit cell)
+    else if constexpr (C::kShifted) score = C::from_bits(0u); // the column-frame cell keeps a true (unbiased) running score
+    else score = C::zero();
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
@@ -1185,9 +1122,11 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
 }
 
 // ---------------------------------------------------------------------------
-// 8-bit first pass (cell_bits = 8): query-pair items of the wave queue, one 2 x 2 tile per lane (CellQ8).
-// Every (query, sequence) that left the 7-bit range is queued for the packed-int16 kernel, which re-runs the
-// two lanes (four sequences) around it at geometry 32 and queues what reaches ITS ceiling for the int32 kernel.
+// 8-bit first pass (cell_bits = 8): query-pair items of the wave queue, one 2 x 2 tile per lane (CellQ8, q8_cell.h).
+// Every (query, sequence) that left the cell's range is queued for the packed-int16 kernel, which re-runs the two
+// lanes (four sequences) around it at geometry 32 and queues what reaches ITS ceiling for the int32 kernel.  A re-run
+// item covers the lane pair (2j, 2j+1): the two lanes combine their flags (homologous sequences sit next to each other
+// in a sorted database and usually flag together) and the even one queues the item once.
 // ---------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_q8(OswSearchArgs p)
 {
@@ -1197,7 +1136,8 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_q8(OswSea
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
     const uint2 *items = p.items + (size_t)p.nitems_wg * 4;
-    const CellQ8::GapT gp = {p.go8, p.ge8, p.bias8};
+    const CellQ8::GapT gp = CellQ8::make_gap(p.go8, p.ge8, p.bias8, p.off8);
+    const int off = (int)p.off8;
     for (;;) {
         uint32_t it = 0;
         if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK], 1u);
@@ -1208,24 +1148,29 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_q8(OswSea
         const OswBlock blk = p.blocks[B];
         const uint32_t gl = 64u >> lg;
         const uint32_t score = run_item<CellQ8>(p, p.prof, pair, B, blk, sigma, lg, lane, 0, false, lds_prof[wv], bnd_wave, gp, gp);
-        if ((uint32_t)lane < gl) {
+        const bool mine = (uint32_t)lane < gl;            // the lanes of group 0 hold the sub-block's scores
+        uint32_t flags = mine ? score & 0x80808080u : 0u; // which of the lane's four (query, sequence) left the range
+        if (gl >= 2) flags |= (uint32_t)__builtin_amdgcn_ds_swizzle((int)flags, 0x041F); // | the other lane of the pair (lane ^ 1); gl = 1: no such lane here
+        if (mine) {
             const uint32_t lam = sigma * gl + lane; // lane of the block = sequence pair
             const uint32_t qa = p.pair_q[2 * pair], qb = p.pair_q[2 * pair + 1];
             const size_t seq = (size_t)blk.seq0 + 2 * lam;
-            int2 ra, rb;
-            ra.x = (int)(score & 0x7fu);         // A . s0
-            rb.x = (int)((score >> 8) & 0x7fu);  // B . s0
-            ra.y = (int)((score >> 16) & 0x7fu); // A . s1
-            rb.y = (int)((score >> 24) & 0x7fu); // B . s1
+            int2 ra, rb; // offset scores back to true ones (a flagged one is garbage and will be overwritten by the re-run)
+            ra.x = (int)(score & 0x7fu) - off;         // A . s0
+            rb.x = (int)((score >> 8) & 0x7fu) - off;  // B . s0
+            ra.y = (int)((score >> 16) & 0x7fu) - off; // A . s1
+            rb.y = (int)((score >> 24) & 0x7fu) - off; // B . s1
             *(int2 *)(p.scores + (size_t)qa * p.score_stride + seq) = ra;
             *(int2 *)(p.scores + (size_t)qb * p.score_stride + seq) = rb;
-            if (score & 0x00800080u) { // query A, either sequence
-                const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
-                p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam >> 1, 5u, 3u), B);
-            }
-            if (score & 0x80008000u) {
-                const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
-                p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qb, lam >> 1, 5u, 3u), B);
+            if (gl < 2 || !(lane & 1)) {
+                if (flags & 0x00800080u) { // query A, any of the (up to) four sequences of the lane pair
+                    const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
+                    p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam >> 1, 5u, 3u), B);
+                }
+                if (flags & 0x80008000u) {
+                    const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
+                    p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qb, lam >> 1, 5u, 3u), B);
+                }
             }
         }
     }
