@@ -196,6 +196,7 @@ struct Device {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
+    uint32_t grid_q8 = 0;            // ... of the 8-bit kernel (more workgroups per CU; at most 2 x grid: it runs alone and may use both halves of the spill scratch)
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
     std::vector<uint32_t> top_pages_host; // source of the asynchronous upload of top_pages
@@ -470,7 +471,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
         for (uint32_t b = 0; b < c.nblocks; ++b)
             total += (double)(1u << def[k].lg) * item_cost(ents[k], def[k].lg, c.ncols4_alloc[b] * 4, def[k].wg);
     }
-    const double nwaves = (double)d.grid * wgx;
+    const double nwaves = (double)(q8 ? d.grid_q8 : d.grid) * wgx; // (8-bit mode: the pairs, the bulk of the work, run on the 8-bit kernel's larger grid)
     const double target = std::max(total / nwaves / tun.target_div, 4.0e4);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
@@ -778,6 +779,9 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "bring-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
         if (per_cu < 1) per_cu = 1;
         d.grid = (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu;
+        int per_cu8 = 0;
+        if (osw_occupancy_q8(&per_cu8) != (int)hipSuccess || per_cu8 < 1) per_cu8 = per_cu;
+        d.grid_q8 = std::min<uint32_t>(2 * d.grid, (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu8);
         r = d.counters.reserve((OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
@@ -799,6 +803,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_i32(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_q8(a, 1, d.stream);
             if (r == hipSuccess) r = hipStreamSynchronize(d.stream);
             scratch.release();
             if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "warm-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
@@ -1095,7 +1100,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             aq.go8 = (uint32_t)ctx->open_gap;
             aq.ge8 = (uint32_t)ctx->extend_gap;
             aq.off8 = (uint32_t)offset8_of(ctx);
-            HIP_TRY(osw_launch_q8(aq, std::min<uint32_t>(d.grid, (c.nitems_q + 3) / 4), d.stream));
+            HIP_TRY(osw_launch_q8(aq, std::min<uint32_t>(d.grid_q8, (c.nitems_q + 3) / 4), d.stream));
         }
         if (c.nitems + c.nitems_wg > 0) HIP_TRY(osw_launch_pk16(as, grid, d.stream));
         if (c.nitems_q > 0) {

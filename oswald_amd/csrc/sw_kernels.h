@@ -11,9 +11,10 @@
 #define OSW_RMAX32 16        // query rows per strip, int32 kernel
 #define OSW_LDS_ROWS16 128   // profile rows a wave keeps in LDS per round (8 KB), packed int16 kernel
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
-#define OSW_RMAX8 16         // query rows per strip, SWAR 8-bit kernel (compiler-scheduled)
-#define OSW_LDS_ROWS8 128    // profile rows a wave keeps in LDS per round, SWAR 8-bit kernel (8 KB)
+#define OSW_RMAX8 12         // query rows per strip, SWAR 8-bit kernel (compiler-scheduled; 12 rows keep it within the 80 VGPRs of six waves per SIMD)
+#define OSW_LDS_ROWS8 96     // profile rows a wave keeps in LDS per round, SWAR 8-bit kernel (6 KB: six workgroups per CU)
 #define OSW_LDS_SKEW8 128    // extra 8-byte units per wave region: group g's slice sits g entries (<= 16 B) further on, G <= 64
+#define OSW_LDS_SKEW_Q8 64  // the same for the 8-bit kernel (8-byte entries)
 #define OSW_BLOCK_SEQS 128   // database sequences per wave block (2 per lane)
 #define OSW_SCRATCH_PAD_COLS 72  // spill scratch columns past the longest block (prefetch + drain of G <= 64), kept zero
 // (a wave's spill region holds (columns + OSW_SCRATCH_PAD_COLS) x 32 {H,F} entries, sized from the longest sequence by
@@ -156,5 +157,6 @@ uint32_t osw_topr_parts(uint32_t nvalid); // partitions per score row; `cand` ho
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
                            unsigned long long *cand, int32_t *out_scores, uint32_t *out_index, hipStream_t s);
 int osw_occupancy_pk16(int *blocks_per_cu);
+int osw_occupancy_q8(int *blocks_per_cu);
 
 #endif

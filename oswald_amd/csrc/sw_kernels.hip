@@ -787,8 +787,14 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
         OSW_ROUND_CASE(4);
         OSW_ROUND_CASE(8);
         OSW_ROUND_CASE(12);
-        OSW_ROUND_CASE(16);
     default:
+        if constexpr (C::kRows >= 16) {
+            if (R == 16) {
+                if constexpr (C::kFast) sw_round_fast<C, 16>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);
+                else sw_round_plain<C, 16>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);
+                break;
+            }
+        }
         if constexpr (C::kRows > 16) {
             switch (R) {
                 OSW_ROUND_CASE(20);
@@ -1128,9 +1134,9 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
 // item covers the lane pair (2j, 2j+1): the two lanes combine their flags (homologous sequences sit next to each other
 // in a sorted database and usually flag together) and the even one queues the item once.
 // ---------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_q8(OswSearchArgs p)
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) void osw_sw_q8(OswSearchArgs p)
 {
-    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS8 * 8 + OSW_LDS_SKEW8];
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS8 * 8 + OSW_LDS_SKEW_Q8];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
@@ -1511,6 +1517,11 @@ hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_
     hipLaunchKernelGGL(osw_topr_merge, dim3(nq), dim3(256), 0, s, (const unsigned long long *)cand, P * r, r, out_scores, out_index);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
+}
+
+int osw_occupancy_q8(int *blocks_per_cu)
+{
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, osw_sw_q8, OSW_WG_THREADS, 0);
 }
 
 int osw_occupancy_pk16(int *blocks_per_cu)

@@ -21,6 +21,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH --steps
 echo "write pass done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/sq" -- $BENCH --steps 2 --warmup 0 > "$OUT/sq.log" 2>&1
 echo "sq pass done"
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d "$OUT/sq2" -- $BENCH --steps 2 --warmup 0 > "$OUT/sq2.log" 2>&1 || echo "sq2 pass failed (counters not available?)"
+echo "sq2 pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -- $REPO/tools/ubench calib > "$OUT/calib_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -- $REPO/tools/ubench calib > "$OUT/calib_write.log" 2>&1
 echo "calibration passes done"

@@ -6,7 +6,7 @@ import csv, glob, hashlib, json, os, sys
 
 out, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/oswald_hip.cpp")  # = bench.py
+KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/q8_cell.h", "oswald_amd/csrc/oswald_hip.cpp")  # = bench.py
 
 
 def source_digest():
@@ -16,7 +16,7 @@ def source_digest():
             h.update(f.read())
     return h.hexdigest()[:16]
 
-DP = ("osw_sw_s16q", "osw_sw_s16", "osw_sw_pk16q", "osw_sw_pk16")  # first-pass DP kernels (fp16 / int16 mode)
+DP = ("osw_sw_s16q", "osw_sw_s16", "osw_sw_pk16q", "osw_sw_pk16", "osw_sw_q8")  # first-pass DP kernels (int16 cells; 8-bit cells + their int16 re-run)
 KERNELS = DP + ("osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
 
 
@@ -89,6 +89,7 @@ def calib(sub, counter, kernel):
 summary["pmc_fetch"] = pmc("fetch")
 summary["pmc_write"] = pmc("write")
 summary["pmc_sq"] = pmc("sq")
+summary["pmc_sq2"] = pmc("sq2")
 try:
     fs = sum(summary["pmc_fetch"].get(k, {}).get("FETCH_SIZE", {}).get("per_dispatch", 0.0) for k in DP + ("osw_sw_i32",))
     ws = sum(summary["pmc_write"].get(k, {}).get("WRITE_SIZE", {}).get("per_dispatch", 0.0) for k in DP + ("osw_sw_i32",))
@@ -110,7 +111,7 @@ try:
                           "correction": "bytes = KiB * 1024 * factor; factor = 1 GiB / counter value of a 1-GiB stream of 8-B entries accessed as 2 dwords per lane (the DP kernels' spill access)"}
     # what bench.py reads for roofline.traffic: tied to the kernel sources it was measured on
     t = dict(summary["traffic"], workload=wl, nseq=int(nseq), source_digest=source_digest(),
-             source=f"tools/profile_gpu.sh {wl} {nseq} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), int16 cells (bench.py default)")
+             source=f"tools/profile_gpu.sh {wl} {nseq} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), bench.py's default cells for the workload")
     with open(os.path.join(out, f"traffic_{wl}_{nseq}.json"), "w") as f:
         json.dump(t, f, indent=1)
 except KeyError:
