@@ -612,7 +612,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     const size_t ovf_bytes = (size_t)ctx->nq * c.nblocks * 128 * sizeof(uint2) + 16;
     if (ovf_bytes > (64ull << 30)) return fail(OSWALD_HIP_EINVAL, "%u queries x %u sequence blocks in one chunk need a %zu-byte overflow queue; search in smaller chunks or query sets", ctx->nq, c.nblocks, ovf_bytes);
     HIP_TRY(c.ovf.reserve(ovf_bytes));
-    if (q8) HIP_TRY(c.ovf8.reserve(ovf_bytes)); // worst case: every lane of every pair item queues both of its queries
+    if (q8) HIP_TRY(c.ovf8.reserve(ovf_bytes)); // worst case: every quad of lanes queues both of its queries, four slots each
     HIP_TRY(c.scores.reserve((size_t)ctx->nq * c.score_stride * sizeof(int32_t) + 16));
     if (!flat[0].empty()) HIP_TRY(hipMemcpyAsync(c.items.p, flat[0].data(), flat[0].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
     if (!flat[1].empty()) HIP_TRY(hipMemcpyAsync(c.items_q.p, flat[1].data(), flat[1].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
@@ -1108,7 +1108,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             ar.items = (const uint2 *)c.ovf8.p;
             ar.nitems = 0;
             ar.nitems_wg = 0;
-            ar.nitems_dev = a.counters_ovf + 1;
+            ar.nitems_dev = a.counters_ovf + 1; // workgroup entries (four waves on the four lanes of a flagged quad, geometry 64)
             ar.counters = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
             HIP_TRY(osw_launch_pk16(ar, std::min<uint32_t>(d.grid, 512u), d.stream));
         }

@@ -124,7 +124,7 @@ struct OswSearchArgs {
     uint32_t score_stride;
     uint32_t *counters;        // this launch's queue counters (OSW_CTR_*)
     uint32_t *counters_ovf;    // shared by all launches of a search: [0] = items queued for the int32 kernel, [1] = for the int16 re-run
-    const uint32_t *nitems_dev;// packed-int16 kernels: if set, the length of the wave-item queue is read from the device (re-run queue)
+    const uint32_t *nitems_dev;// packed-int16 kernels: if set, the number of workgroup entries is read from the device (re-run queue of the 8-bit pass)
     uint2 *ovf8_items;         // 8-bit kernel: the queue it fills for the int16 re-run
     uint32_t bias8, go8, ge8, off8; // 8-bit kernel: profile bias, gap open, gap extend and the cell's offset c (q8_cell.h), plain values
     const uint32_t *pair_q;    // query-pair kernel: the two queries of pair i (rows of the score table)

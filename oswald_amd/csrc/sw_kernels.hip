@@ -1024,9 +1024,10 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     // Phase 1: workgroup entries, heaviest first -- the workgroup's four waves on four sub-blocks of one item
     // (shared profile slice, rounds in step), or on a quad of four independent heavy wave items.  Phase 2: every
     // wave on its own, light wave items.  One loop, so that the (large, fully unrolled) round code exists once.
-    const uint2 *wave_items = p.items + (size_t)p.nitems_wg * 4;
-    // (the re-run queue of the 8-bit pass was filled by the previous kernel on this stream)
-    const uint32_t nitems = p.nitems_dev ? __builtin_amdgcn_readfirstlane(*p.nitems_dev) : p.nitems;
+    // (the re-run queue of the 8-bit pass -- workgroup entries only -- was filled by the previous kernel on this stream)
+    const uint32_t nitems_wg = p.nitems_dev ? __builtin_amdgcn_readfirstlane(*p.nitems_dev) : p.nitems_wg;
+    const uint2 *wave_items = p.items + (size_t)nitems_wg * 4;
+    const uint32_t nitems = p.nitems;
     bool phase1 = true;
     for (;;) {
         uint2 item;
@@ -1034,13 +1035,13 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         if (phase1) {
             if (threadIdx.x == 0) {
                 uint32_t t = atomicAdd(&p.counters[OSW_CTR_WORK_WG], 1u);
-                if (t < p.nitems_wg) t = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT_WG], 1u) : p.nitems_wg - 1 - atomicAdd(&p.counters[OSW_CTR_BACK_WG], 1u);
+                if (t < nitems_wg) t = heavy_end ? atomicAdd(&p.counters[OSW_CTR_FRONT_WG], 1u) : nitems_wg - 1 - atomicAdd(&p.counters[OSW_CTR_BACK_WG], 1u);
                 wg_item = t;
             }
             __syncthreads();
             const uint32_t it = wg_item;
             __syncthreads();
-            if (it >= p.nitems_wg) { // all four waves see this together
+            if (it >= nitems_wg) { // all four waves see this together
                 phase1 = false;
                 OSW_DIAG_STAMP(threadIdx.x == 0, blockIdx.x * 4 + 1);
                 continue;
@@ -1129,10 +1130,10 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
 
 // ---------------------------------------------------------------------------
 // 8-bit first pass (cell_bits = 8): query-pair items of the wave queue, one 2 x 2 tile per lane (CellQ8, q8_cell.h).
-// Every (query, sequence) that left the cell's range is queued for the packed-int16 kernel, which re-runs the two
-// lanes (four sequences) around it at geometry 32 and queues what reaches ITS ceiling for the int32 kernel.  A re-run
-// item covers the lane pair (2j, 2j+1): the two lanes combine their flags (homologous sequences sit next to each other
-// in a sorted database and usually flag together) and the even one queues the item once.
+// Every (query, sequence) that left the cell's range is queued for the packed-int16 kernel, which re-runs the aligned
+// quad of lanes (eight sequences) around it as ONE workgroup entry at geometry 64 and queues what reaches ITS ceiling
+// for the int32 kernel.  The four lanes combine their flags (homologous sequences sit next to each other in a sorted
+// database and usually flag together) and the first one queues the entry once.
 // ---------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) void osw_sw_q8(OswSearchArgs p)
 {
@@ -1156,7 +1157,9 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) void osw_sw_q8(OswSea
         const uint32_t score = run_item<CellQ8>(p, p.prof, pair, B, blk, sigma, lg, lane, 0, false, lds_prof[wv], bnd_wave, gp, gp);
         const bool mine = (uint32_t)lane < gl;            // the lanes of group 0 hold the sub-block's scores
         uint32_t flags = mine ? score & 0x80808080u : 0u; // which of the lane's four (query, sequence) left the range
-        if (gl >= 2) flags |= (uint32_t)__builtin_amdgcn_ds_swizzle((int)flags, 0x041F); // | the other lane of the pair (lane ^ 1); gl = 1: no such lane here
+        // a re-run entry covers an aligned quad of lanes (eight sequences): combine the quad's flags
+        flags |= (uint32_t)__builtin_amdgcn_ds_swizzle((int)flags, 0x041F); // | lane ^ 1
+        flags |= (uint32_t)__builtin_amdgcn_ds_swizzle((int)flags, 0x081F); // | lane ^ 2
         if (mine) {
             const uint32_t lam = sigma * gl + lane; // lane of the block = sequence pair
             const uint32_t qa = p.pair_q[2 * pair], qb = p.pair_q[2 * pair + 1];
@@ -1168,14 +1171,17 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) void osw_sw_q8(OswSea
             rb.y = (int)((score >> 24) & 0x7fu) - off; // B . s1
             *(int2 *)(p.scores + (size_t)qa * p.score_stride + seq) = ra;
             *(int2 *)(p.scores + (size_t)qb * p.score_stride + seq) = rb;
-            if (gl < 2 || !(lane & 1)) {
-                if (flags & 0x00800080u) { // query A, any of the (up to) four sequences of the lane pair
+            if (!(lane & 3)) { // (gl < 4: the other lanes of the quad belong to other items, which queue it again if they flag: harmless)
+                // one workgroup entry of the packed-int16 kernel: its four waves take the four lanes of the quad at
+                // geometry 64 (every lane group 1/64 of the query: the shortest critical path the kernel offers)
+                const uint32_t first = lam & ~3u;
+                if (flags & 0x00800080u) { // query A, any sequence of the quad
                     const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
-                    p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam >> 1, 5u, 3u), B);
+                    for (uint32_t w = 0; w < 4; ++w) p.ovf8_items[4 * k + w] = make_uint2(OSW_ITEM_PACK(qa, first + w, 6u, 3u) | (3u << 30), B | OSW_ITEM_WG_FLAG);
                 }
                 if (flags & 0x80008000u) {
                     const uint32_t k = atomicAdd(&p.counters_ovf[1], 1u);
-                    p.ovf8_items[k] = make_uint2(OSW_ITEM_PACK(qb, lam >> 1, 5u, 3u), B);
+                    for (uint32_t w = 0; w < 4; ++w) p.ovf8_items[4 * k + w] = make_uint2(OSW_ITEM_PACK(qb, first + w, 6u, 3u) | (3u << 30), B | OSW_ITEM_WG_FLAG);
                 }
             }
         }

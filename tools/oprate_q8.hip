@@ -1,7 +1,7 @@
 // tools/oprate_q8.hip -- issue cost of the 8-bit cell (oswald_amd/csrc/q8_cell.h) on one gfx950 SIMD: the bitwise /
 // shift instructions it consists of, how a few slow (VOP3) instructions mix into a stream of fast ones, and the cell's
-// own column step (CellQ8::column<16>: 16 query rows x 4 cells per lane), in core-clock cycles per SIMD at 2 / 4 / 8
-// waves per SIMD.  bench.py's ROW_CYCLES[8] comes from the last line.
+// own column step (CellQ8::column<OSW_RMAX8>: the kernel's strip of query rows x 4 cells per lane), in core-clock cycles per SIMD at 2 / 4 / 6
+// waves per SIMD (six is what osw_sw_q8 runs at).  bench.py's ROW_CYCLES[8] comes from the last line.
 // Build: hipcc --offload-arch=gfx950 -O3 -I oswald_amd/csrc -I include -o tools/oprate_q8 tools/oprate_q8.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -82,27 +82,27 @@ __global__ __launch_bounds__(256) void mix_probe(unsigned long long *out, uint32
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (acc == 0x12345678u);
 }
 
-// the cell's column step on a made-up profile in LDS: 16 rows per call
+// the cell's column step on a made-up profile in LDS: OSW_RMAX8 rows per call
 __global__ __launch_bounds__(256) void cell_probe(unsigned long long *out, uint32_t go, uint32_t ge, uint32_t bias, uint32_t codes0, int iters)
 {
     extern __shared__ uint32_t lds[];
     for (int i = threadIdx.x; i < 4 * 32 * 2 * 4; i += 256) lds[i] = 0x04030201u * ((i * 7) & 7) + 0x01010101u * bias; // 16 rows x 32 codes x 8 B / 4
     __syncthreads();
     const CellQ8::GapT g = CellQ8::make_gap(go, ge, bias, go + ge > bias ? go + ge : bias);
-    uint32_t D[16], E[16], top_prev, f = CellQ8::zero_bits(g), hl = 0, score = CellQ8::score_init(g);
-    CellQ8::init_state<16>(D, E, top_prev, g);
+    uint32_t D[OSW_RMAX8], E[OSW_RMAX8], top_prev, f = CellQ8::zero_bits(g), hl = 0, score = CellQ8::score_init(g);
+    CellQ8::init_state<OSW_RMAX8>(D, E, top_prev, g);
     uint32_t codes = (codes0 + threadIdx.x * 8) & 0xf8f8u;
     const uint32_t base = 0; // LDS byte address of the slice
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
-        CellQ8::column<16>(base, codes, 0, D, E, top_prev, f, hl, g, g, score);
+        CellQ8::column<OSW_RMAX8>(base, codes, 0, D, E, top_prev, f, hl, g, g, score);
         top_prev = hl;
         codes = (codes + 0x0808u) & 0xf8f8u;
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     uint32_t acc = score ^ f ^ hl;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc ^= D[i] ^ E[i];
+    for (int i = 0; i < OSW_RMAX8; ++i) acc ^= D[i] ^ E[i];
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (acc == 0x12345678u);
 }
 
@@ -122,7 +122,7 @@ template <class K, class... A>
 static void sweep(const char *name, K kern, double per, int iters, int cus, unsigned long long *o, A... args)
 {
     printf("%-44s", name);
-    for (int wps : {2, 4, 8}) {
+    for (int wps : {2, 4, 6}) {
         const int nb = cus * wps;
         const size_t lds = (size_t)(160 * 1024 / wps) - 1024;
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -140,7 +140,7 @@ int main()
     const int cus = p.multiProcessorCount, iters = 20000;
     unsigned long long *o;
     (void)hipMalloc(&o, (size_t)cus * 8 * 8);
-    printf("device %s, %d CUs; core-clock cycles per wave instruction per SIMD (slowest workgroup) at 2 / 4 / 8 waves per SIMD\n", p.gcnArchName, cus);
+    printf("device %s, %d CUs; core-clock cycles per wave instruction per SIMD (slowest workgroup) at 2 / 4 / 6 waves per SIMD\n", p.gcnArchName, cus);
 #define ONE(T, label) sweep(label, op_probe<T>, 32.0, iters, cus, o, 0x7f7f7f7fu, 0x05040100u)
     ONE(OpAndV, "v_and_b32 vgpr,vgpr (VOP2)");
     ONE(OpOrV, "v_or_b32 vgpr,vgpr (VOP2)");
@@ -167,7 +167,7 @@ int main()
     sweep("  NS = 4   [76.5]", mix_probe<4>, 1.0, iters, cus, o, 0x7f7f7f7fu, 0x05040100u);
     sweep("  NS = 8   [85.0]", mix_probe<8>, 1.0, iters, cus, o, 0x7f7f7f7fu, 0x05040100u);
     printf("the 8-bit cell (q8_cell.h), cycles per query row of a 2 x 2 tile (= per 256 cells of a wave) per SIMD:\n");
-    sweep("  CellQ8::column<16>, PAM250 14/2 (bias 8)", cell_probe, 16.0, iters / 8, cus, o, 14u, 2u, 8u, 0x1830u);
-    sweep("  CellQ8::column<16>, BLOSUM62 10/2 (bias 4)", cell_probe, 16.0, iters / 8, cus, o, 10u, 2u, 4u, 0x1830u);
+    sweep("  CellQ8::column<OSW_RMAX8>, PAM250 14/2 (bias 8)", cell_probe, (double)OSW_RMAX8, iters / 8, cus, o, 14u, 2u, 8u, 0x1830u);
+    sweep("  CellQ8::column<OSW_RMAX8>, BLOSUM62 10/2 (bias 4)", cell_probe, (double)OSW_RMAX8, iters / 8, cus, o, 10u, 2u, 4u, 0x1830u);
     return 0;
 }
