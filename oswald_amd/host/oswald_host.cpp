@@ -9,6 +9,7 @@
 #include <fstream>
 #include <numeric>
 #include <stdexcept>
+#include <nmmintrin.h>
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -188,11 +189,43 @@ DbInfo read_info(const std::string &sequences_filename)
     int c = 0;
     if (fscanf(f, "%ld %ld %d", &a, &b, &c) != 3) { fclose(f); throw std::runtime_error("OSWALD: malformed info file."); }
     fclose(f);
+    if (a < 0 || b < 0 || c < 0) throw std::runtime_error("OSWALD: malformed info file (negative count).");
     DbInfo r;
     r.count = (uint64_t)a;
     r.D = (uint64_t)b;
     r.max_title_length = c;
     return r;
+}
+
+int64_t mtime_ns_of(const struct stat &st) { return (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec; }
+
+// The length table of <db>.seq, checked against <db>.info and the file BEFORE anything is sized from them: the files
+// are input (possibly truncated, possibly not written by this tool).  <db>.seq must be exactly count x uint16 + D
+// bytes, the lengths must add up to D, be sorted ascending (what preprocessing guarantees and the group layout relies
+// on: a group is as long as its LAST sequence) and stay within the format's limit.
+std::vector<uint16_t> read_length_table(const std::string &sequences_filename, const DbInfo &info, struct stat *seq_stat)
+{
+    const std::string path = sequences_filename + ".seq";
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
+    if (info.count > (1ull << 40) || info.D > (1ull << 46) || (uint64_t)st.st_size != info.count * sizeof(uint16_t) + info.D)
+        throw std::runtime_error((uint64_t)st.st_size < info.count * sizeof(uint16_t) + info.D ? "OSWALD: sequence file is shorter than its info file says."
+                                                                                               : "OSWALD: sequence file does not have the size its info file says.");
+    std::vector<uint16_t> len(info.count);
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
+    f.read((char *)len.data(), (std::streamsize)(len.size() * sizeof(uint16_t)));
+    if (!f) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
+    uint64_t sum = 0;
+    for (size_t i = 0; i < len.size(); ++i) {
+        sum += len[i];
+        if (i > 0 && len[i] < len[i - 1]) throw std::runtime_error("OSWALD: sequence file is not sorted by length (not a preprocessed database?).");
+    }
+    if (sum != info.D) throw std::runtime_error("OSWALD: the sequence lengths do not add up to the residue count of the info file.");
+    if (!len.empty() && len.back() > kMaxSequenceLength) // a .seq written by the reference may hold such a sequence; its padded length wraps there
+        throw std::runtime_error("OSWALD: database holds a sequence of " + std::to_string(len.back()) + " residues (limit " + std::to_string(kMaxSequenceLength) + ")");
+    if (seq_stat) *seq_stat = st;
+    return len;
 }
 
 // padded group lengths: the longest (= last) sequence of the group, rounded up to a multiple of 28
@@ -227,26 +260,34 @@ void interleave_groups(const std::vector<uint16_t> &len, const uint8_t *residues
     }
 }
 
-// CRC-32 of 256 evenly spaced 4 KiB pieces of the residue area of <db>.seq (all of it when it is smaller): cheap
-// enough for every search, and a database rebuilt with the same sequence lengths but other residues is caught
-uint32_t residue_sample_crc(const std::string &seq_path, uint64_t count, uint64_t D)
+// CRC-32C (Castagnoli) with the SSE4.2 instruction, three interleaved streams would be faster still; ~5 GB/s is enough
+// for a check that runs only when <db>.seq was touched after its cache was written.
+uint32_t crc32c_of(const uint8_t *p, size_t n, uint32_t crc = 0)
+{
+    uint64_t c = crc ^ 0xFFFFFFFFu;
+    while (n && ((uintptr_t)p & 7)) { c = _mm_crc32_u8((uint32_t)c, *p++); --n; }
+    for (; n >= 8; n -= 8, p += 8) c = _mm_crc32_u64(c, *(const uint64_t *)p);
+    while (n--) c = _mm_crc32_u8((uint32_t)c, *p++);
+    return (uint32_t)c ^ 0xFFFFFFFFu;
+}
+
+// CRC-32C of the residue area of <db>.seq, streamed; false if the file cannot be read to the end
+bool residues_crc32c_of_file(const std::string &seq_path, uint64_t count, uint64_t D, uint32_t *out)
 {
     FILE *f = fopen(seq_path.c_str(), "rb");
-    if (!f) return 0;
-    const uint64_t base = count * sizeof(uint16_t), piece = 4096, pieces = 256;
-    std::vector<uint8_t> buf;
-    if (D <= piece * pieces) {
-        buf.resize(D);
-        if (fseek(f, (long)base, SEEK_SET) != 0 || fread(buf.data(), 1, buf.size(), f) != buf.size()) buf.clear();
-    } else {
-        buf.resize(piece * pieces);
-        for (uint64_t k = 0; k < pieces; ++k) {
-            const uint64_t off = base + (D - piece) / (pieces - 1) * k;
-            if (fseek(f, (long)off, SEEK_SET) != 0 || fread(buf.data() + k * piece, 1, piece, f) != piece) { buf.clear(); break; }
-        }
+    if (!f) return false;
+    std::vector<uint8_t> buf(4u << 20);
+    bool ok = fseek(f, (long)(count * sizeof(uint16_t)), SEEK_SET) == 0;
+    uint32_t crc = 0;
+    for (uint64_t left = D; ok && left > 0;) {
+        const size_t want = (size_t)std::min<uint64_t>(left, buf.size());
+        ok = fread(buf.data(), 1, want, f) == want;
+        if (ok) crc = crc32c_of(buf.data(), want, crc);
+        left -= want;
     }
     fclose(f);
-    return buf.empty() ? 0u : crc32_of(buf.data(), buf.size());
+    *out = crc;
+    return ok;
 }
 
 size_t cache_payload_offset(uint64_t groups) { return (sizeof(GroupCacheHeader) + groups * sizeof(uint16_t) + 63) / 64 * 64; }
@@ -257,16 +298,16 @@ void write_group_cache(const std::string &sequences_filename)
 {
     const int W = kFpgaVectorLength;
     const DbInfo info = read_info(sequences_filename);
-    std::vector<uint16_t> len(info.count);
+    struct stat seq_stat;
+    const std::vector<uint16_t> len = read_length_table(sequences_filename, info, &seq_stat);
     std::vector<uint8_t> s(info.D);
-    uint64_t seq_bytes = 0;
+    const uint64_t seq_bytes = len.size() * sizeof(uint16_t) + s.size();
     {
         std::ifstream f(sequences_filename + ".seq", std::ios::binary);
         if (!f) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
-        f.read((char *)len.data(), (std::streamsize)(len.size() * sizeof(uint16_t)));
+        f.seekg((std::streamoff)(len.size() * sizeof(uint16_t)));
         f.read((char *)s.data(), (std::streamsize)s.size());
         if (!f) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
-        seq_bytes = len.size() * sizeof(uint16_t) + s.size();
     }
     const std::vector<uint16_t> n = group_lengths(len, W);
     const uint64_t N = info.count, G = n.size();
@@ -276,7 +317,7 @@ void write_group_cache(const std::string &sequences_filename)
     GroupCacheHeader h;
     memset(&h, 0, sizeof h);
     memcpy(h.magic, "OSWG16\0\0", 8);
-    h.version = 1;
+    h.version = 2;
     h.vector_length = (uint32_t)W;
     h.sequences_count = N;
     h.D = info.D;
@@ -284,7 +325,8 @@ void write_group_cache(const std::string &sequences_filename)
     h.vD = gdisp[G];
     h.seq_file_bytes = seq_bytes;
     h.lengths_crc32 = crc32_of((const uint8_t *)len.data(), len.size() * sizeof(uint16_t));
-    h.residues_crc32 = residue_sample_crc(sequences_filename + ".seq", N, info.D);
+    h.residues_crc32c = crc32c_of(s.data(), s.size());
+    h.seq_mtime_ns = mtime_ns_of(seq_stat);
     const std::string tmp = sequences_filename + ".g16.tmp";
     {
         std::ofstream f(tmp, std::ios::binary);
@@ -315,11 +357,8 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
     db.sequences_count = info.count;
     db.D = info.D;
     db.max_title_length = info.max_title_length;
-    std::vector<uint16_t> len(db.sequences_count);
-    std::ifstream fseq(sequences_filename + ".seq", std::ios::binary);
-    if (!fseq) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
-    fseq.read((char *)len.data(), (std::streamsize)(len.size() * sizeof(uint16_t)));
-    if (!fseq) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
+    struct stat seq_stat;
+    const std::vector<uint16_t> len = read_length_table(sequences_filename, info, &seq_stat);
     if (db.sequences_count == 0) return db;
     db.sequences_db_max_length = len.back();
     const uint64_t N = db.sequences_count, G = (N + W - 1) / W;
@@ -336,13 +375,16 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
         if (mf && mf->bytes >= sizeof(GroupCacheHeader)) {
             GroupCacheHeader h;
             memcpy(&h, mf->p, sizeof h);
-            struct stat st;
-            const bool seq_ok = stat((sequences_filename + ".seq").c_str(), &st) == 0 && (uint64_t)st.st_size == h.seq_file_bytes;
-            const bool ok = !memcmp(h.magic, "OSWG16\0\0", 8) && h.version == 1 && h.vector_length == (uint32_t)W && h.sequences_count == N &&
-                            h.D == db.D && h.groups == G && h.vD == db.vD && seq_ok && mf->bytes == cache_payload_offset(G) + db.vD &&
-                            h.lengths_crc32 == crc32_of((const uint8_t *)len.data(), len.size() * sizeof(uint16_t)) &&
-                            h.residues_crc32 == residue_sample_crc(sequences_filename + ".seq", N, db.D) &&
-                            !memcmp(mf->p + sizeof h, n.data(), n.size() * sizeof(uint16_t));
+            bool ok = !memcmp(h.magic, "OSWG16\0\0", 8) && h.version == 2 && h.vector_length == (uint32_t)W && h.sequences_count == N &&
+                      h.D == db.D && h.groups == G && h.vD == db.vD && (uint64_t)seq_stat.st_size == h.seq_file_bytes &&
+                      mf->bytes == cache_payload_offset(G) + db.vD &&
+                      h.lengths_crc32 == crc32_of((const uint8_t *)len.data(), len.size() * sizeof(uint16_t)) &&
+                      !memcmp(mf->p + sizeof h, n.data(), n.size() * sizeof(uint16_t));
+            if (ok && h.seq_mtime_ns != mtime_ns_of(seq_stat)) {
+                // <db>.seq was touched after the cache was written (same size, same lengths): its residues decide
+                uint32_t crc = 0;
+                ok = residues_crc32c_of_file(sequences_filename + ".seq", N, db.D, &crc) && crc == h.residues_crc32c;
+            }
             if (ok) {
                 db.cache = mf;
                 cached_b = mf->p + cache_payload_offset(G);
@@ -356,6 +398,9 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
     std::vector<uint64_t> seq_off;
     if (!cached_b) {
         s.resize(db.D);
+        std::ifstream fseq(sequences_filename + ".seq", std::ios::binary);
+        if (!fseq) throw std::runtime_error("OSWALD: An error occurred while opening sequence file.");
+        fseq.seekg((std::streamoff)(len.size() * sizeof(uint16_t)));
         fseq.read((char *)s.data(), (std::streamsize)s.size());
         if (!fseq) throw std::runtime_error("OSWALD: sequence file is shorter than its info file says.");
         seq_off.assign(N + 1, 0);

@@ -50,18 +50,23 @@ PreprocessStats preprocess_db(const std::string &input_filename, const std::stri
 // 16 length-sorted sequences interleaved column by column and padded with the dummy residue to the group
 // length (reference host/src/sequences.c:457-498).  The layout does not depend on the chunk plan (a chunk is a
 // run of whole groups), so a search maps the file and hands slices of it to the device, whatever -k / -f say.
-// <db>.seq stays the canonical database; the cache is used only if it matches it (count, D, size of the .seq
-// file, CRC-32 of its length table and of a sample of its residues), else it is ignored and the groups are interleaved from <db>.seq.
+// <db>.seq stays the canonical database; the cache is used only if it belongs to it: count, D, group lengths and the
+// CRC-32 of the length table must match, and then either <db>.seq still has the size AND modification time it had when
+// the cache was written (the cheap test, no residue is read), or -- the file was touched or rewritten -- the CRC-32C of
+// ALL its residues matches.  Anything else (including a .seq that cannot be read) is a mismatch: the cache is ignored
+// with a warning and the groups are interleaved from <db>.seq.
 struct GroupCacheHeader {
     char magic[8];          // "OSWG16\0\0"
-    uint32_t version;       // 1
+    uint32_t version;       // 2
     uint32_t vector_length; // 16
     uint64_t sequences_count, D, groups, vD;
     uint64_t seq_file_bytes;
     uint32_t lengths_crc32; // of the uint16 length table of <db>.seq
-    uint32_t residues_crc32;// of a sample of its residues: 256 evenly spaced 4 KiB pieces
+    uint32_t residues_crc32c;// CRC-32C of the whole residue area of <db>.seq
+    int64_t seq_mtime_ns;   // modification time of <db>.seq when the cache was written
+    uint64_t reserved;
 };                          // followed by uint16 n[groups], zero padding to a multiple of 64 B, then uint8 b[vD]
-static_assert(sizeof(GroupCacheHeader) == 64, "on-disk header");
+static_assert(sizeof(GroupCacheHeader) == 80, "on-disk header");
 // Writes <db>.g16 from <db>.info / <db>.seq (also usable on a database preprocessed by the reference).
 void write_group_cache(const std::string &sequences_filename);
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""tools/collect_prof.py ROUND WORKLOAD NSEQ [LABEL] -- copy what tools/profile_gpu.sh left under gpurun_out/prof_<workload>/
+(scratch) into profiles/ (tracked): r<ROUND>_<label>_summary.json, ..._kernel_stats.csv, ..._domain_stats.csv and
+traffic_<workload>_<nseq>.json (the file bench.py reads for roofline.traffic)."""
+import glob, json, os, shutil, sys
+
+rnd, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
+label = sys.argv[4] if len(sys.argv) > 4 else wl
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{wl}")
+dst = os.path.join(root, "profiles")
+text = open(os.path.join(src, "summary.txt")).read()
+summary = json.loads(text[text.index("{"):])
+with open(os.path.join(dst, f"r{rnd}_{label}_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+if stats:
+    shutil.copy(stats[-1], os.path.join(dst, f"r{rnd}_{label}_kernel_stats.csv"))
+    dom = stats[-1].replace("_kernel_stats.csv", "_domain_stats.csv")
+    if os.path.exists(dom):
+        shutil.copy(dom, os.path.join(dst, f"r{rnd}_{label}_domain_stats.csv"))
+t = os.path.join(src, f"traffic_{wl}_{nseq}.json")
+if os.path.exists(t):
+    shutil.copy(t, os.path.join(dst, f"traffic_{wl}_{nseq}.json"))
+print("collected", label, "->", dst)
