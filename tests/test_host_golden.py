@@ -228,3 +228,29 @@ def test_cli_preprocess_and_loud_search_failure(tmp_path):
         s = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-q", str(tmp_path / "q.fasta"), "-d", str(tmp_path / "db")],
                            capture_output=True, text=True)
         assert s.returncode != 0 and "no CPU path" in s.stderr
+
+
+def test_group_cache_of_a_large_database_sees_every_residue(tmp_path):
+    """A database of more than 1 MiB of residues (round 2 hashed only 256 sampled 4 KiB windows of such a file): ONE
+    changed residue anywhere makes the cache stale -- <db>.seq was rewritten, so its modification time differs and all
+    residues are re-checked (CRC-32C) -- while a .seq that was merely touched keeps its cache."""
+    db, (L, R, O) = _make_db(tmp_path, 4000, 21)
+    D, n = int(L.sum()), 4000
+    assert D > (1 << 20) + 8192
+    hostlib.assemble(db, 16, 134217728, 1)
+    assert hostlib.from_cache()
+    st = os.stat(db + ".seq")
+    os.utime(db + ".seq", ns=(st.st_atime_ns, st.st_mtime_ns + 5_000_000_000))     # touched, same bytes
+    hostlib.assemble(db, 16, 134217728, 1)
+    assert hostlib.from_cache()
+    piece, pieces = 4096, 256
+    sampled = [(D - piece) // (pieces - 1) * k for k in range(pieces)]
+    off = next(o for o in range(5000, D) if all(not (s <= o < s + piece) for s in sampled))   # outside every window of the old sampler
+    with open(db + ".seq", "r+b") as f:
+        f.seek(2 * n + off)
+        b = f.read(1)
+        f.seek(2 * n + off)
+        f.write(bytes([(b[0] + 1) % 23]))
+    changed = hostlib.assemble(db, 16, 134217728, 1)
+    assert not hostlib.from_cache()
+    np.testing.assert_array_equal(changed["chunks"][0]["b"], plain_first(db))
