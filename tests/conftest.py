@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the native pieces live in the tree (git-ignored); build whatever a fresh checkout lacks
-    need = [os.path.join(ROOT, "oswald_amd", f) for f in ("liboswald_hip.so", "liboswald_host.so", "oswald")]
+    need = [os.path.join(ROOT, "oswald_amd", f) for f in ("liboswald_hip.so", "liboswald_host.so", "oswald", "liboswald_hip.isa.json")]
     need.append(os.path.join(ROOT, "oracle", "liboswald_oracle.so"))
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__

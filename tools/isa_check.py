@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""tools/isa_check.py -- ISA check of the packed-int16 kernels and the stamp that ties the shipped library to it.
+
+The column loop of osw_sw_pk16 / osw_sw_pk16q / osw_sw_s16 / osw_sw_s16q loads straight into fixed physical registers
+from inline asm, two columns ahead (sw_kernels.hip, "Input registers of a column step").  The compiler does not know
+about those loads, so the design rests on it never touching these registers itself, on there being no scratch spills
+and on no compiler-issued vector-memory operation inside the loops that contain the asm loads (their waits are counted
+by hand).  check() compiles the kernels to assembly with the hipcc at hand and verifies exactly that
+(tests/test_isa_inflight.py runs it on CPUs).
+
+The library that RUNS is the one built in this tree and shipped to the GPU box.  stamp() records, next to it, the
+SHA-256 of the liboswald_hip.so whose sources passed the check, the digest of those sources and the compiler version;
+tests/test_gpu_isa_guard.py (-m gpu) verifies on the GPU box that the library the process actually mapped is that file,
+bit for bit -- a library rebuilt there by another compiler would not be."""
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "oswald_amd", "csrc")
+SRC = os.path.join(CSRC, "sw_kernels.hip")
+LIB = os.path.join(ROOT, "oswald_amd", "liboswald_hip.so")
+STAMP = os.path.join(ROOT, "oswald_amd", "liboswald_hip.isa.json")
+KERNELS = ("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q")
+SOURCES = ("sw_kernels.hip", "sw_kernels.h", "q8_cell.h", "oswald_hip.cpp")
+
+
+def hipcc_path():
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return p if os.path.exists(p) else None
+
+
+def reserved_registers():
+    m = re.search(r'#define OSW_INFLIGHT (.*)', open(SRC).read())
+    regs = [int(x) for x in re.findall(r'"v(\d+)"', m.group(1))]
+    assert len(regs) == 8
+    return set(regs)
+
+
+def compile_to_asm():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "sw_kernels.s")
+        subprocess.check_call([hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + CSRC, "-o", out, SRC], stderr=subprocess.DEVNULL)
+        return open(out).read().split("\n")
+
+
+def _touches(code, reserved):
+    for m in re.finditer(r'\bv(\d+)\b', code):
+        if int(m.group(1)) in reserved:
+            return True
+    for m in re.finditer(r'\bv\[(\d+):(\d+)\]', code):
+        if any(r in reserved for r in range(int(m.group(1)), int(m.group(2)) + 1)):
+            return True
+    return False
+
+
+def check_inflight_registers(isa):
+    """-> (instructions of the asm blocks that use the fixed registers, [(line, code)] of compiler-scheduled ones that do)"""
+    reserved = reserved_registers()
+    fn, inasm, bad, seen_asm_use = None, False, [], 0
+    for i, line in enumerate(isa):
+        m = re.match(r'^(osw_\w+):', line)
+        if m:
+            fn = m.group(1)
+        if "#ASMSTART" in line:
+            inasm = True
+            continue
+        if "#ASMEND" in line:
+            inasm = False
+            continue
+        if fn not in KERNELS or not line.startswith("\t"):
+            continue
+        code = line.split(";")[0].strip()
+        if not code or code.startswith("."):
+            continue
+        if _touches(code, reserved):
+            if inasm:
+                seen_asm_use += 1
+            else:
+                bad.append((i + 1, code))
+    return seen_asm_use, bad
+
+
+def check_register_budget(isa):
+    """4 waves per SIMD need <= 128 VGPRs; a spill of a loop-invariant value outside the column loops is tolerated (a
+    few bytes), spill traffic inside them is ruled out by check_vmem_windows.  -> list of complaints"""
+    text, bad = "\n".join(isa), []
+    for k in KERNELS:
+        m = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)' % k, text)
+        m2 = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)' % k, text)
+        if not m or int(m.group(1)) > 128:
+            bad.append("%s needs more than 128 VGPRs (4 waves per SIMD)" % k)
+        if not m2 or int(m2.group(1)) > 32:
+            bad.append("%s spills %s bytes per lane" % (k, m2.group(1) if m2 else "?"))
+    return bad
+
+
+def check_vmem_windows(isa):
+    """Inside the column loops (between the prologue's asm loads and the final `s_waitcnt vmcnt(0)` of a round) every
+    vector-memory instruction must come from the asm blocks: a compiler-issued one would shift the hand-counted waits."""
+    fn, inasm, window, bad = None, False, False, []
+    for i, line in enumerate(isa):
+        m = re.match(r'^(osw_\w+):', line)
+        if m:
+            fn, window = m.group(1), False
+        if "#ASMSTART" in line:
+            inasm = True
+            continue
+        if "#ASMEND" in line:
+            inasm = False
+            continue
+        if fn not in KERNELS or not line.startswith("\t"):
+            continue
+        code = line.split(";")[0].strip()
+        if inasm and code.startswith("global_load_ushort"):
+            window = True
+        if inasm and code.startswith("s_waitcnt vmcnt(0) lgkmcnt(0)"):
+            window = False
+        if window and not inasm and re.match(r'(global_|buffer_|flat_|scratch_)', code):
+            bad.append((i + 1, code))
+    return bad
+
+
+def check(isa=None):
+    """All three checks; raises AssertionError with the findings."""
+    isa = isa or compile_to_asm()
+    seen, bad = check_inflight_registers(isa)
+    assert seen > 1000, "the asm blocks that use the fixed registers were not found"
+    assert not bad, "compiler-scheduled instructions touch in-flight registers: %r" % bad[:8]
+    budget = check_register_budget(isa)
+    assert not budget, "; ".join(budget)
+    vm = check_vmem_windows(isa)
+    assert not vm, "compiler-issued vector memory inside an asm load window: %r" % vm[:8]
+    return isa
+
+
+def sha256_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def source_digest():
+    h = hashlib.sha256()
+    for rel in SOURCES:
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def stamp():
+    """Check the ISA of the current sources, make sure liboswald_hip.so is built from them (make is a no-op when it is
+    up to date) and write the stamp."""
+    check()
+    subprocess.check_call(["make", "-s", "-C", CSRC])
+    ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout.strip().split("\n")
+    info = {"library_sha256": sha256_file(LIB), "source_digest": source_digest(), "hipcc": ver[0] if ver else "", "kernels": list(KERNELS),
+            "checks": ["in-flight registers untouched by compiler-scheduled code", "<= 128 VGPRs, <= 32 B of scratch", "no compiler-issued vector memory inside the asm load windows"]}
+    with open(STAMP, "w") as f:
+        json.dump(info, f, indent=1)
+    return info
+
+
+if __name__ == "__main__":
+    if not hipcc_path():
+        sys.exit("hipcc not available")
+    print(json.dumps(stamp(), indent=1))
