@@ -16,6 +16,14 @@ def pytest_configure(config):
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__
         __graft_entry__.build()
+    else:
+        # a library rebuilt by hand (make) after the last ISA check: check and stamp it again (tools/isa_check.py)
+        import hashlib
+        import json
+        stamp = json.load(open(need[3]))
+        if stamp.get("library_sha256") != hashlib.sha256(open(need[0], "rb").read()).hexdigest():
+            import subprocess
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "isa_check.py")], stdout=subprocess.DEVNULL)
 
 
 def pytest_generate_tests(metafunc):
