@@ -59,7 +59,7 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 1.03, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
-    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, two_ended = 0;
+    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, two_ended = 0, one_ended_wg = 1;
     bool no_prio = false, one_stream = false;
     bool debug_times = false, debug_nospill = false; // -DOSW_DIAG only
     void refresh();
@@ -89,6 +89,7 @@ void Tunables::refresh()
     wg_wide_cols = (uint32_t)num("OSWALD_HIP_WG_WIDECOLS", wg_wide_cols);
     wg_min_rounds = (uint32_t)num("OSWALD_HIP_WG_MINROUNDS", wg_min_rounds);
     two_ended = (uint32_t)num("OSWALD_HIP_TWO_ENDED", 0);
+    one_ended_wg = (uint32_t)num("OSWALD_HIP_ONE_ENDED_WG", one_ended_wg);
     no_prio = flag("OSWALD_HIP_NO_PRIO");
     one_stream = flag("OSWALD_HIP_ONE_STREAM");
     debug_times = flag("OSWALD_HIP_DEBUG_TIMES");
@@ -1032,6 +1033,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.nitems = c.nitems;
     a.nitems_wg = c.nitems_wg;
     a.two_ended_waves = ctx->tun.two_ended;
+    a.one_ended_wg = ctx->tun.one_ended_wg;
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
     a.debug_nospill = ctx->tun.debug_nospill ? 1u : 0u; // -DOSW_DIAG builds only (timing experiment: results are wrong); always 0 otherwise
     a.prof = (const uint2 *)d.prof.p;
@@ -1062,8 +1064,8 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
 
     const bool dbg_times = ctx->tun.debug_times; // -DOSW_DIAG builds only
     if (dbg_times) {
-        HIP_TRY(d.wg_times.reserve((size_t)d.grid * 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(d.wg_times.p, 0, (size_t)d.grid * 4 * sizeof(unsigned long long), d.stream));
+        HIP_TRY(d.wg_times.reserve((size_t)d.grid * 5 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d.wg_times.p, 0, (size_t)d.grid * 5 * sizeof(unsigned long long), d.stream));
         a.wg_times = (unsigned long long *)d.wg_times.p;
     }
     EventPair ev{};
@@ -1150,7 +1152,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     if (dbg_times) {
         // diagnostics only: when did the workgroups of the DP launch start / leave phase 1 / finish
         HIP_TRY(hipStreamSynchronize(d.stream));
-        std::vector<unsigned long long> t((size_t)grid * 4);
+        std::vector<unsigned long long> t((size_t)grid * 5);
         HIP_TRY(hipMemcpy(t.data(), d.wg_times.p, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0;
         for (uint32_t g = 0; g < grid; ++g) { if (t[g * 4]) t0 = std::min(t0, t[g * 4]); t1 = std::max(t1, std::max(t[g * 4 + 2], t[g * 4 + 3])); }
@@ -1177,6 +1179,31 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         fprintf(stderr, "\n[oswald_hip]   finishes by decile:    ");
         for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_end[k]);
         fprintf(stderr, "\n");
+        {
+            // per CU: when its LAST workgroup finished, and the time-integral of its resident workgroups (4 = full)
+            std::vector<std::pair<unsigned long long, std::vector<double>>> cus; // (cu id, finish times of its workgroups)
+            for (uint32_t g = 0; g < grid; ++g) {
+                const unsigned long long cu = t[(size_t)grid * 4 + g];
+                const double e = (double)(std::max(t[g * 4 + 2], t[g * 4 + 3]) - t0) / 100.0;
+                auto it = std::find_if(cus.begin(), cus.end(), [&](const auto &x) { return x.first == cu; });
+                if (it == cus.end()) { cus.push_back({cu, {}}); it = cus.end() - 1; }
+                it->second.push_back(e);
+            }
+            uint32_t hist_last[10] = {0}, hist_n[8] = {0};
+            double sum_last = 0, occ = 0;
+            for (auto &c2 : cus) {
+                const double last = *std::max_element(c2.second.begin(), c2.second.end());
+                hist_last[std::min(9, (int)(last / span * 10))]++;
+                hist_n[std::min<size_t>(7, c2.second.size())]++;
+                sum_last += last;
+                for (double e : c2.second) occ += e;
+            }
+            fprintf(stderr, "[oswald_hip]   %zu CUs; last finish per CU by decile:", cus.size());
+            for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_last[k]);
+            fprintf(stderr, "; mean last finish %.0f%% of span; workgroups per CU histogram:", 100.0 * sum_last / cus.size() / span);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %u", hist_n[k]);
+            fprintf(stderr, "; mean resident workgroups per CU over the span %.2f\n", occ / cus.size() / span);
+        }
     }
     if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: kernels"); }
     if (scores_out) {

@@ -111,6 +111,7 @@ struct OswSearchArgs {
     uint32_t nitems;
     uint32_t nitems_wg;
     uint32_t two_ended_waves;  // wave items: eat the queue from both ends (see osw_sw_pk16) or heaviest-first only
+    uint32_t one_ended_wg;     // phase-1 entries: every workgroup takes the heaviest entry left (else: the first workgroup of a CU the heaviest, the others the lightest)
     uint32_t force_all;        // int32 kernel: run `items` instead of the overflow queue
     const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16 (column-frame kernels: S + ge)
     const uint2 *prof_fb;      // column-frame kernels: the plain profile of the same queries / pairs (blocks run on the plain cell)

@@ -1016,9 +1016,12 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); // HW_REG_XCC_ID[3:0]
         const uint32_t cu = ((xcc & 15u) << 8) | (hw & 255u);
         wg_item = atomicAdd(&p.counters[OSW_CTR_CU0 + (cu & (OSW_CTR_CUS - 1))], 1u);
+#ifdef OSW_DIAG
+        if (p.wg_times) p.wg_times[(size_t)gridDim.x * 4 + blockIdx.x] = cu; // (behind the time stamps: which CU the workgroup ran on)
+#endif
     }
     __syncthreads();
-    const bool heavy_end = wg_item == 0;
+    const bool heavy_end = wg_item == 0 || p.one_ended_wg != 0;
     __syncthreads();
 
     // Phase 1: workgroup entries, heaviest first -- the workgroup's four waves on four sub-blocks of one item
