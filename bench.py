@@ -265,6 +265,7 @@ def main():
             "reference_traffic_model": {"bytes_per_cell": 1.0, "roofline_gcups": HBM_PEAK_GBS, "frac": round(gcups / world / HBM_PEAK_GBS, 4)},
             "rerun_items_int32": int(rerun), "rerun_items_int16": int(ctx.rerun_counts()[0]), "work_items": int(sum(ctx.chunk_geometry(c["h"])["work_items"] for c in chunks)),
             "max_log2_geometry": int(max([ctx.chunk_geometry(c["h"])["max_log2_geometry"] for c in chunks] or [0])),
+            "planned_spill_bytes_per_step": int(sum(ctx.chunk_geometry(c["h"])["planned_spill_bytes"] for c in chunks)),
             "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
             "setup_s": round(t_gen, 1),
         }

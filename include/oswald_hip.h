@@ -184,8 +184,11 @@ int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2);
  * out[0] = wave blocks, out[1] = stored 4-column groups, out[2] = 4-column
  * groups after trimming all-dummy tail columns, out[3] = bytes of re-tiled
  * residues the DP kernel reads per query, out[4] = work items of the last
- * search's queue, out[5] = log2 of the widest wave geometry in it. */
-int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out6);
+ * search's queue, out[5] = log2 of the widest wave geometry in it, out[6] = bytes the
+ * strip-boundary spill of one search writes and reads back according to its plan
+ * (long queries do not fit the registers + LDS of a wave: SURVEY 8d "long-query
+ * spill"), out[7] = 0 (reserved). */
+int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out8);
 
 #ifdef __cplusplus
 }

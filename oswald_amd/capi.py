@@ -222,7 +222,7 @@ class Context:
         return int(out[0]), int(out[1])
 
     def chunk_geometry(self, chunk: int, dev: int = 0):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         _chk(self.lib.oswald_hip_chunk_geometry(self.h, dev, chunk, out))
         return {"blocks": out[0], "col4_stored": out[1], "col4_live": out[2], "residue_bytes_per_query": out[3],
-                "work_items": out[4], "max_log2_geometry": out[5]}
+                "work_items": out[4], "max_log2_geometry": out[5], "planned_spill_bytes": out[6]}

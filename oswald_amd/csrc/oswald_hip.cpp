@@ -59,7 +59,7 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 1.03, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
-    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, two_ended = 0, one_ended_wg = 1;
+    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1;
     bool no_prio = false, one_stream = false;
     bool debug_times = false, debug_nospill = false; // -DOSW_DIAG only
     void refresh();
@@ -88,6 +88,7 @@ void Tunables::refresh()
     wg_min_cols = (uint32_t)num("OSWALD_HIP_WG_MINCOLS", wg_min_cols);
     wg_wide_cols = (uint32_t)num("OSWALD_HIP_WG_WIDECOLS", wg_wide_cols);
     wg_min_rounds = (uint32_t)num("OSWALD_HIP_WG_MINROUNDS", wg_min_rounds);
+    wg_min_cols_long = (uint32_t)num("OSWALD_HIP_WG_MINCOLS_LONG", wg_min_cols_long);
     two_ended = (uint32_t)num("OSWALD_HIP_TWO_ENDED", 0);
     one_ended_wg = (uint32_t)num("OSWALD_HIP_ONE_ENDED_WG", one_ended_wg);
     no_prio = flag("OSWALD_HIP_NO_PRIO");
@@ -147,6 +148,7 @@ struct Chunk {
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
     int items_bits = 0;                 // cell width it was planned for
     uint32_t max_lg = 0;                // widest geometry in the item list
+    uint64_t planned_spill_bytes = 0;   // strip-boundary spill traffic (written + read back) one search of the chunk causes, from the plan
     bool searched = false;
     bool upload_pending = false;        // uploaded with _async: the device's stream has not been synchronised since
     // the chunk's place in the database (oswald_hip_chunk_set_index): database index of its k-th sequence =
@@ -482,6 +484,13 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     struct It { double cost; uint32_t x, b; };
     std::vector<It> its[2], its_wg[2];
     c.max_lg = 0;
+    c.planned_spill_bytes = 0;
+    // strip-boundary spill of an item: every round boundary writes and reads back {H, F} = 8 B per column and lane of a group
+    auto spill_bytes = [&](const Entity &e, uint32_t lg, uint32_t ncols, bool wg) {
+        const Kind &kd = kinds[e.kind];
+        const OswPlan pl = osw_plan(e.m, 1u << lg, wg ? kd.ldsr * wgx : kd.ldsr, kd.rmax);
+        return kd.passes * (double)(pl.rounds - 1) * (double)ncols * (double)(64u >> lg) * 8.0 * 2.0;
+    };
     for (uint32_t k = 0; k < ne; ++k)
         for (uint32_t b = 0; b < c.nblocks; ++b) {
             const Entity &e = ents[k];
@@ -491,7 +500,11 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             // the block's boundary row must fit the wave's spill region: (columns + pad) x lanes per group
             uint32_t lg_scratch = 0;
             while (lg_scratch < 6 && ((uint64_t)ncols + OSW_SCRATCH_PAD_COLS) * (64u >> lg_scratch) > d.bnd_stride) ++lg_scratch;
-            if (wg && ncols < wg_min_cols) {
+            // (-DOSW_DIAG sweep, OSWALD_HIP_WG_MINROUNDS: entities whose wave plan would spill at wg_min_rounds - 1 or more round
+            // boundaries stay workgroup items also on short blocks, down to OSWALD_HIP_WG_MINCOLS_LONG columns)
+            const bool many_rounds = tun.wg_min_rounds > 0 && ncols >= tun.wg_min_cols_long &&
+                                     osw_plan(e.m, 1u << lg_full_wave[k], kinds[e.kind].ldsr, kinds[e.kind].rmax).rounds >= tun.wg_min_rounds;
+            if (wg && ncols < wg_min_cols && !many_rounds) {
                 // short block: the pipeline fill of a wide geometry (G columns per round) would cost more
                 // than the spill it saves; run as wave items at the widest full-height geometry (G = 4; 2 for pairs)
                 wg = false;
@@ -533,6 +546,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             const uint16_t *sc = c.sub_cols.data() + (size_t)b * 128 + (G - 1);
             if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg[e.kind].push_back({item_cost(e, lg, std::max(std::max(sc[s], sc[s + 1]), std::max(sc[s + 2], sc[s + 3])), wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
             else for (uint32_t s = 0; s < G; ++s) its[e.kind].push_back({item_cost(e, lg, sc[s], wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
+            for (uint32_t s = 0; s < G; ++s) c.planned_spill_bytes += (uint64_t)spill_bytes(e, lg, sc[s], wg);
         }
     auto by_cost = [](const It &x, const It &y) { return x.cost > y.cost; };
     // issue priority of the long items (see set_wave_prio in sw_kernels.hip)
@@ -1406,12 +1420,13 @@ int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2)
     return 0;
 }
 
-int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out6)
+int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out8)
 {
     if (int r = check_dev(ctx, dev)) return r;
     Device &d = ctx->dev[dev];
     if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
-    if (!out6) return fail(OSWALD_HIP_EINVAL, "null output");
+    if (!out8) return fail(OSWALD_HIP_EINVAL, "null output");
+    uint64_t *out6 = out8;
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
     HIP_TRY(hipStreamSynchronize(d.stream));
@@ -1426,6 +1441,8 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
     out6[3] = live * 64 * sizeof(uint2);
     out6[4] = c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg; // wave-level work items (a phase-1 entry is four)
     out6[5] = c.max_lg;
+    out8[6] = c.planned_spill_bytes;
+    out8[7] = 0;
     return 0;
 }
 
