@@ -59,7 +59,7 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 1.03, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
-    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1;
+    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1, grid_per_cu = 0;
     bool no_prio = false, one_stream = false;
     bool debug_times = false, debug_nospill = false; // -DOSW_DIAG only
     void refresh();
@@ -91,6 +91,7 @@ void Tunables::refresh()
     wg_min_cols_long = (uint32_t)num("OSWALD_HIP_WG_MINCOLS_LONG", wg_min_cols_long);
     two_ended = (uint32_t)num("OSWALD_HIP_TWO_ENDED", 0);
     one_ended_wg = (uint32_t)num("OSWALD_HIP_ONE_ENDED_WG", one_ended_wg);
+    grid_per_cu = (uint32_t)num("OSWALD_HIP_GRID_PER_CU", 0);
     no_prio = flag("OSWALD_HIP_NO_PRIO");
     one_stream = flag("OSWALD_HIP_ONE_STREAM");
     debug_times = flag("OSWALD_HIP_DEBUG_TIMES");
@@ -474,7 +475,8 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
         for (uint32_t b = 0; b < c.nblocks; ++b)
             total += (double)(1u << def[k].lg) * item_cost(ents[k], def[k].lg, c.ncols4_alloc[b] * 4, def[k].wg);
     }
-    const double nwaves = (double)(q8 ? d.grid_q8 : d.grid) * wgx; // (8-bit mode: the pairs, the bulk of the work, run on the 8-bit kernel's larger grid)
+    const uint32_t grid_eff = tun.grid_per_cu ? std::min<uint32_t>(d.grid, (uint32_t)d.prop.multiProcessorCount * tun.grid_per_cu) : d.grid; // (-DOSW_DIAG sweep)
+    const double nwaves = (double)(q8 ? d.grid_q8 : grid_eff) * wgx; // (8-bit mode: the pairs, the bulk of the work, run on the 8-bit kernel's larger grid)
     const double target = std::max(total / nwaves / tun.target_div, 4.0e4);
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
@@ -1090,7 +1092,8 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         } else { ev = d.ev_pool.back(); d.ev_pool.pop_back(); }
     }
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, (OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
-    const uint32_t grid = std::min<uint32_t>(d.grid, std::max<uint32_t>(1, (c.nitems + 3) / 4 + c.nitems_wg));
+    const uint32_t grid_cap = ctx->tun.grid_per_cu ? std::min<uint32_t>(d.grid, (uint32_t)d.prop.multiProcessorCount * ctx->tun.grid_per_cu) : d.grid; // (-DOSW_DIAG sweep)
+    const uint32_t grid = std::min<uint32_t>(grid_cap, std::max<uint32_t>(1, (c.nitems + 3) / 4 + c.nitems_wg));
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
     const bool frame = first_pass_is_frame(ctx);
     const auto launch_single = frame ? osw_launch_s16 : osw_launch_pk16;
@@ -1140,7 +1143,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         aq.qlen = (const uint16_t *)d.pair_len.p;
         aq.pair_q = (const uint32_t *)d.pair_q.p;
         aq.counters = (uint32_t *)d.counters.p + OSW_CTR_COUNT;
-        const uint32_t gq = std::min<uint32_t>(d.grid, (c.nitems_q + 3) / 4 + c.nitems_q_wg);
+        const uint32_t gq = std::min<uint32_t>(grid_cap, (c.nitems_q + 3) / 4 + c.nitems_q_wg);
         if (c.nitems + c.nitems_wg > 0 && !ctx->tun.one_stream) {
             // the single-query launch goes to a second stream so that its workgroups fill the slots the
             // pair launch frees while it drains (both are persistent grids pulling from their own queues)

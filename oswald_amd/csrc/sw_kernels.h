@@ -7,9 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #define OSW_WG_THREADS 256   // 4 waves per workgroup, each wave independent
-#define OSW_RMAX16 32        // query rows per strip, packed int16 kernel
+#define OSW_RMAX16 48        // query rows per strip, packed int16 kernels (2 state registers per row; 168 VGPRs = three waves per SIMD)
 #define OSW_RMAX32 16        // query rows per strip, int32 kernel
-#define OSW_LDS_ROWS16 128   // profile rows a wave keeps in LDS per round (8 KB), packed int16 kernel
+#define OSW_LDS_ROWS16 192   // profile rows a wave keeps in LDS per round (12 KB; three workgroups of four waves per CU), packed int16 kernels
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
 #define OSW_RMAX8 12         // query rows per strip, SWAR 8-bit kernel (compiler-scheduled; 12 rows keep it within the 80 VGPRs of six waves per SIMD)
 #define OSW_LDS_ROWS8 96     // profile rows a wave keeps in LDS per round, SWAR 8-bit kernel (6 KB: six workgroups per CU)

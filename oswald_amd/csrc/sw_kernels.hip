@@ -19,9 +19,12 @@
 //       - sequences that reach the ceiling are queued for the int32 kernel
 //     (the reference's int8->int16->int32 escalation, host/src/HybridSearch.c:
 //     1670-1680,:1774-1784, yields exact scores; so does this).
-//   * the query is cut into strips of R <= 32 rows held in registers (E and
-//     the diagonal H of every row, 2 VGPRs per row); database columns stream
-//     through.  The strip's slice of the query profile lives in a wave-private
+//   * the query is cut into strips of R <= 48 rows held in registers (E and
+//     the diagonal H of every row, 2 VGPRs per row; three waves per SIMD: 168
+//     VGPRs and a 12 KB profile slice in LDS per wave -- round 3; it was 32 rows,
+//     four waves and 8 KB, which cost a third more round boundaries and gained
+//     nothing: a gfx950 SIMD issues these instruction streams at the same rate
+//     from three waves as from four); database columns stream through.  The strip's slice of the query profile lives in a wave-private
 //     LDS region and is read with conflict-free ds_read_b64 (4 rows per read,
 //     address = 8*residue + imm; `tiled` stores 8*residue).
 //   * "wave geometry" G (1,2,4,...,64): the 64 lanes form G groups of 64/G
@@ -85,15 +88,21 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // written by name inside the asm text only.  tests/test_isa_inflight.py checks
 // the generated ISA: no compiler-scheduled instruction touches them.
 // ---------------------------------------------------------------------------
-#define OSW_VH "v120"   // H of the row above: handed over at the end of a step, read at the end of the next
-#define OSW_VF "v121"   // F of the row above, then the F chain of the step (in place), then handed on
-#define OSW_VC0 "v122"  // residues, even / odd column (loaded two columns ahead)
-#define OSW_VC1 "v123"
-#define OSW_VLH0 "v124" // boundary row of the previous round, group 0, even / odd column (loaded two ahead)
-#define OSW_VLF0 "v125"
-#define OSW_VLH1 "v126"
-#define OSW_VLF1 "v127"
-#define OSW_INFLIGHT "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define OSW_VH "v160"   // H of the row above: handed over at the end of a step, read at the end of the next
+#define OSW_VF "v161"   // F of the row above, then the F chain of the step (in place), then handed on
+#define OSW_VC0 "v162"  // residues, even / odd column (loaded two columns ahead)
+#define OSW_VC1 "v163"
+#define OSW_VLH0 "v164" // boundary row of the previous round, group 0, even / odd column (loaded two ahead)
+#define OSW_VLF0 "v165"
+#define OSW_VLH1 "v166"
+#define OSW_VLF1 "v167"
+#define OSW_INFLIGHT "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+// ... and the compiler is given v0..v159 only (amdgpu_num_vgpr caps what its register allocator may use; the kernel's
+// register count still comes out as 168 -- three waves per SIMD -- because the asm statements clobber v160..v167): the
+// fixed registers are out of its reach by construction, not by the luck of an allocation order (round 2 had them at
+// v120..v127 inside the compiler's range; with a larger budget the allocator did park temporaries there between asm
+// statements).  tools/isa_check.py verifies it on the ISA.
+#define OSW_COMPILER_VGPRS __attribute__((amdgpu_num_vgpr(160)))
 
 // ---------------------------------------------------------------------------
 // The cell, hand-scheduled.  State per row r: E[r] and D[r] = H(i0+r-1, j-1),
@@ -801,6 +810,10 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
                 OSW_ROUND_CASE(24);
                 OSW_ROUND_CASE(28);
                 OSW_ROUND_CASE(32);
+                OSW_ROUND_CASE(36);
+                OSW_ROUND_CASE(40);
+                OSW_ROUND_CASE(44);
+                OSW_ROUND_CASE(48);
             default: break;
             }
         }
@@ -1084,16 +1097,16 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     OSW_DIAG_STAMP(lane == 0, blockIdx.x * 4 + 2 + (wv & 1)); // waves 0/1 (or 2/3) race: any is fine
 }
 
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16B, CellPK16B, false>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16B, CellPK16B, false>(p); }
 
 // Query pairs: `items` / `qlen` / `prof` / `prof_off` describe pairs (length = the longer query,
 // profile = packed (A, B) scores); pair_q maps a pair to its two query rows of the score table.
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true>(p); }
 
 // Column-frame cell (6.5 instructions per row) with the plain biased cell for the blocks it cannot take:
 // `prof` holds S + ge, goe_pk the gap OPEN penalty; prof_fb / goe_fb / ge_fb serve the plain cell.
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_s16(OswSearchArgs p) { pk16_body<CellPK16S, CellPK16B, false>(p); }
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 4) void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16(OswSearchArgs p) { pk16_body<CellPK16S, CellPK16B, false>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
 
 // ---------------------------------------------------------------------------
 // Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at
