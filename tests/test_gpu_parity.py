@@ -648,3 +648,41 @@ def test_context_level_topr_over_chunks_and_devices(oracle, dealt):
         with pytest.raises(capi.OswaldHipError):
             ctx.topr_begin(5000)       # the device selection stops at 1024
     assert len(np.unique(whole[0, :NSEQ])) < NSEQ // 4   # ties are present
+
+
+def test_api_misuse_of_the_round3_entry_points(hip_ctx):
+    """oswald_hip_topr / _topr_begin / _chunk_set_index / _merge_candidates report misuse through the return code."""
+    from oswald_amd import capi
+    sm = submat.load("blosum62")
+    qs = synth.make_queries([40, 41], seed=2)
+    a, m, ad = pack_queries(qs)
+    L, R, O = random_db(50, seed=3, max_len=60)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    hip_ctx.set_scoring(sm, 10, 2)
+    hip_ctx.set_queries(a, m, ad)
+    hip_ctx.topr_begin(0)                                       # collection switched off
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.topr(5)                                         # nothing was being collected
+    h = hip_ctx.chunk_upload(b, n, disp, 16)
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_set_index(h, 0, len(n) * 16 + 1)          # more sequences than the chunk has lanes
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_set_index(h + 7, 0, 50)                   # no such chunk
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_set_index(h, 0xFFFFFFF0, 50)              # database indices must fit 32 bits
+    hip_ctx.topr_begin(5)
+    hip_ctx.chunk_search(h, None)                               # no index given: the chunk is searched but not collected
+    sc, ix = hip_ctx.topr(5)
+    assert (sc == -1).all() and (ix == 0xFFFFFFFF).all()
+    hip_ctx.chunk_set_index(h, 1000, 50)
+    hip_ctx.chunk_search(h, None)
+    hip_ctx.chunk_search(h, None)                               # searched twice: collected twice, duplicates and all (the caller's business)
+    sc, ix = hip_ctx.topr(4)
+    assert (ix[:, 0] == ix[:, 1]).all() and (ix >= 1000).all() and (ix < 1050).all() and (sc[:, 0] == sc[:, 1]).all()
+    hip_ctx.set_queries(a[:40], m[:1], ad[:1])                  # the query set changes under a collection
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.topr(4)
+    hip_ctx.topr_begin(0)
+    hip_ctx.chunk_release(h)
+    s2, i2 = capi.merge_candidates(np.array([[5, -1, 5, 7]], np.int32), np.array([[3, 0, 9, 1]], np.uint32), 3)
+    assert s2.tolist() == [[7, 5, 5]] and i2.tolist() == [[1, 9, 3]]
