@@ -61,9 +61,10 @@ SIMD_PER_CU = 4
 PK_OPS_PER_ROW = {16: (7.5, 6.5), 32: (24.0, 24.0), 8: (22.0, 22.0)}  # 8: 44 SWAR instructions per row of a 2 x 2 tile = 256 cells (q8_cell.h)
 # ... and what such a row costs in core-clock cycles per SIMD at 4 waves per SIMD.  int16: MEASURED on the cell's own
 # instruction mix (tools/oprate2.hip, profiles/r02_oprate2_valu_mix.txt: 3.5 VOP3P + 3 VOP2 = 25.3 cycles for the query-pair
-# row; the sequence-pair row keeps the packed add and has a v_perm_b32: 26.3 + 4.25); int32 / int8: instructions x 4.25
-# resp. x 3 (mostly 2-cycle VOP2 in a mix), estimates.
-ROW_CYCLES = {16: (30.5, 25.3), 32: (102.0, 102.0), 8: (80.0, 80.0)}
+# row; the sequence-pair row keeps the packed add and has a v_perm_b32: 26.3 + 4.25); int8: MEASURED on the cell's own column
+# step at the six waves per SIMD osw_sw_q8 runs at (tools/oprate_q8.hip, profiles/r03_oprate_q8.txt: 129.5 cycles per row of
+# a 2 x 2 tile = 256 cells); int32: instructions x 4.25, an estimate.
+ROW_CYCLES = {16: (30.5, 25.3), 32: (102.0, 102.0), 8: (64.75, 64.75)}
 DTYPE = {16: "int16", 32: "int32", 8: "int8"}
 CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells",
               8: "int8 cells (four 7-bit SWAR cells per register) with int16 re-run of what leaves their range, int32 above"}

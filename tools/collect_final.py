@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""tools/collect_final.py ROUND -- copy what tools/final_validation.sh left under gpurun_out/final/ (scratch) into profiles/
+(tracked): the bench lines, the shard-balance prediction, the CLI phases, the microbenchmark, the rocprofv3 summaries."""
+import json, os, shutil, subprocess, sys
+
+rnd = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profiles")
+for f in sorted(os.listdir(src)):
+    if f.startswith("bench_") and f.endswith(".json"):
+        lines = [l for l in open(os.path.join(src, f)).read().split("\n") if l.startswith("{")]
+        if lines:
+            with open(os.path.join(dst, f"r{rnd}_{f}"), "w") as o:
+                json.dump(json.loads(lines[-1]), o, indent=1)
+for a, b in (("shard_balance.txt", f"r{rnd}_shard_balance_1gpu.txt"), ("cli_1m.txt", f"r{rnd}_cli_1m_phases.txt"), ("oprate_q8.txt", f"r{rnd}_oprate_q8.txt")):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+with open(os.path.join(dst, f"r{rnd}_pytest_gpu_tail.txt"), "w") as o:
+    o.write("".join(open(os.path.join(src, "pytest_gpu.log")).readlines()[-3:]))
+for wl, nseq, label in (("c2", "1000000", "c4_1gpu"), ("c3", "100000", "c3_int8"), ("c5", "100000", "c5")):
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "collect_prof.py"), rnd, wl, nseq, label])
