@@ -5,7 +5,9 @@
 // (query, database sequence)"; the formulation here is its own: sixteen database sequences of a group side by side
 // in the sixteen int16 lanes of one AVX2 register, the database streamed column by column, a per-column score
 // profile (24 vectors, two byte shuffles each), H and E of every query row in two arrays, saturating int16
-// arithmetic, and an exact scalar int32 pass for the few sequences whose score reaches the int16 ceiling.
+// arithmetic, and an exact scalar int32 pass for the few sequences whose score reaches the int16 ceiling.  `-v 32`
+// selects that AVX2 kernel; `-v 16` (the reference's default: its SSE path, BASELINE configs[0]) the same formulation
+// on SSE4.1 -- the sixteen sequences in two 8 x int16 registers.
 #include "oswald_host.h"
 
 #include <immintrin.h>
@@ -91,14 +93,64 @@ __attribute__((target("avx2"))) void simd_group(const uint8_t *a, uint32_t m, co
     _mm256_storeu_si256((__m256i *)out, best);
 }
 
+// the same on SSE4.1: the sixteen lanes in two 128-bit registers (lanes 0..7 and 8..15)
+__attribute__((target("sse4.1"))) void simd_group_sse41(const uint8_t *a, uint32_t m, const uint8_t *grp, uint32_t ncols, const int8_t *submat, int goe, int ge,
+                                                       Scratch &s, int16_t out[16])
+{
+    s.H.assign((size_t)m * 16, 0);
+    s.E.assign((size_t)m * 16, 0);
+    __m128i *H = (__m128i *)s.H.data(), *E = (__m128i *)s.E.data(); // two per query row; unaligned accesses below
+    const __m128i vgoe = _mm_set1_epi16((short)std::min(goe, 32767)), vge = _mm_set1_epi16((short)std::min(ge, 32767)), zero = _mm_setzero_si128();
+    __m128i best0 = zero, best1 = zero;
+    __m128i lo[24], hi[24];
+    for (int c = 0; c < 24; ++c) {
+        lo[c] = _mm_loadu_si128((const __m128i *)(submat + c * 32));
+        hi[c] = _mm_loadu_si128((const __m128i *)(submat + c * 32 + 16));
+    }
+    __m128i P0[24], P1[24];
+    const __m128i fifteen = _mm_set1_epi8(15);
+    for (uint32_t j = 0; j < ncols; ++j) {
+        const __m128i r = _mm_and_si128(_mm_loadu_si128((const __m128i *)(grp + (size_t)j * 16)), _mm_set1_epi8(31));
+        const __m128i upper = _mm_cmpgt_epi8(r, fifteen);
+        for (int c = 0; c < 24; ++c) {
+            const __m128i s8 = _mm_blendv_epi8(_mm_shuffle_epi8(lo[c], r), _mm_shuffle_epi8(hi[c], _mm_and_si128(r, fifteen)), upper);
+            P0[c] = _mm_cvtepi8_epi16(s8);
+            P1[c] = _mm_cvtepi8_epi16(_mm_srli_si128(s8, 8));
+        }
+        __m128i diag0 = zero, diag1 = zero, f0 = zero, f1 = zero;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t ai = a[i] < 24 ? a[i] : 23;
+            const __m128i e0 = _mm_loadu_si128(E + 2 * i), e1 = _mm_loadu_si128(E + 2 * i + 1);
+            __m128i h0 = _mm_max_epi16(_mm_max_epi16(_mm_adds_epi16(diag0, P0[ai]), e0), _mm_max_epi16(f0, zero));
+            __m128i h1 = _mm_max_epi16(_mm_max_epi16(_mm_adds_epi16(diag1, P1[ai]), e1), _mm_max_epi16(f1, zero));
+            diag0 = _mm_loadu_si128(H + 2 * i);
+            diag1 = _mm_loadu_si128(H + 2 * i + 1);
+            _mm_storeu_si128(H + 2 * i, h0);
+            _mm_storeu_si128(H + 2 * i + 1, h1);
+            best0 = _mm_max_epi16(best0, h0);
+            best1 = _mm_max_epi16(best1, h1);
+            const __m128i u0 = _mm_subs_epi16(h0, vgoe), u1 = _mm_subs_epi16(h1, vgoe);
+            _mm_storeu_si128(E + 2 * i, _mm_max_epi16(_mm_subs_epi16(e0, vge), u0));
+            _mm_storeu_si128(E + 2 * i + 1, _mm_max_epi16(_mm_subs_epi16(e1, vge), u1));
+            f0 = _mm_max_epi16(_mm_subs_epi16(f0, vge), u0);
+            f1 = _mm_max_epi16(_mm_subs_epi16(f1, vge), u1);
+        }
+    }
+    _mm_storeu_si128((__m128i *)out, best0);
+    _mm_storeu_si128((__m128i *)(out + 8), best1);
+}
+
 } // namespace
 
 void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int W, const int8_t *submat, int open_gap, int extend_gap,
-                        int threads, int32_t *scores, uint64_t row_stride, uint64_t col0)
+                        int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length)
 {
     if (W != kFpgaVectorLength) throw std::runtime_error("OSWALD: the host path works on groups of 16 sequences.");
     const int goe = open_gap + extend_gap, ge = extend_gap;
-    const bool avx2 = __builtin_cpu_supports("avx2");
+    // -v 32: the AVX2 kernel, -v 16: the SSE4.1 kernel (the reference's two host paths); whichever the CPU lacks falls
+    // to the next one down, the scalar kernel last
+    const bool avx2 = cpu_vector_length != 16 && __builtin_cpu_supports("avx2");
+    const bool sse41 = !avx2 && __builtin_cpu_supports("sse4.1");
     const uint64_t nq = q.m.size();
     if (threads < 1) threads = 1;
 #pragma omp parallel num_threads(threads)
@@ -115,8 +167,9 @@ void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t 
                 int32_t *dst = scores + qi * row_stride + col0 + (g - g0) * W;
                 int16_t lane16[16];
                 if (avx2) simd_group(a, m, grp, ncols, submat, goe, ge, s, lane16);
+                else if (sse41) simd_group_sse41(a, m, grp, ncols, submat, goe, ge, s, lane16);
                 for (int lane = 0; lane < W; ++lane) {
-                    if (avx2 && lane16[lane] < 32767) dst[lane] = lane16[lane];
+                    if ((avx2 || sse41) && lane16[lane] < 32767) dst[lane] = lane16[lane];
                     else dst[lane] = scalar_score(a, m, grp, ncols, W, lane, submat, goe, ge, s.h32, s.e32); // at the int16 ceiling: exact int32
                 }
             }

@@ -559,6 +559,18 @@ const uint16_t *oswald_host_chunk_nbb(unsigned c) { return g_db.chunks[c].nbb.da
 const uint32_t *oswald_host_chunk_disp(unsigned c) { return g_db.chunks[c].disp.data(); }
 
 // the host compute path on chunk c of the assembled database, for the queries loaded last (all groups)
+int oswald_host_search_chunk_v(unsigned c, const char *submat_name, int open_gap, int extend_gap, int threads, int cpu_vector_length, int32_t *scores)
+{
+    try {
+        const int8_t *sm = oswald::submat_by_name(submat_name);
+        if (!sm) throw std::runtime_error("unknown substitution matrix");
+        const oswald::Chunk &ch = g_db.chunks.at(c);
+        oswald::host_search_groups(g_q, ch, 0, ch.n.size(), oswald::kFpgaVectorLength, sm, open_gap, extend_gap, threads, scores,
+                                   ch.n.size() * oswald::kFpgaVectorLength, 0, cpu_vector_length);
+        return 0;
+    } catch (const std::exception &e) { g_host_err = e.what(); return -1; }
+}
+
 int oswald_host_search_chunk(unsigned c, const char *submat_name, int open_gap, int extend_gap, int threads, int32_t *scores)
 {
     try {

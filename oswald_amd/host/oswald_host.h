@@ -105,8 +105,9 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
 // groups [g0, g1) of a chunk, written to scores[qi * row_stride + col0 + (g - g0) * 16 + lane].  A mode of its own,
 // never a fallback of the accelerator path.  Stands where the reference has its host SIMD kernels
 // (host/src/HybridSearch.c:1540-1880, :790-1140).
+// cpu_vector_length: the command line's -v -- 16 selects the SSE4.1 kernel (the reference's default host path), 32 the AVX2 one.
 void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int vector_length, const int8_t *submat, int open_gap,
-                        int extend_gap, int threads, int32_t *scores, uint64_t row_stride, uint64_t col0);
+                        int extend_gap, int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length = 32);
 
 std::vector<std::string> load_database_headers(const std::string &sequences_filename, uint64_t sequences_count);
 // The titles of the given sequences only (any order, duplicates allowed): one pass over the mapped file instead of

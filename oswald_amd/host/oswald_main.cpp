@@ -249,7 +249,7 @@ int do_search_host_only(Options &o)
     const double tick = dwalltime();
     for (const oswald::Chunk &c : db.chunks)
         oswald::host_search_groups(q, c, 0, c.n.size(), (int)W, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, o.cpu_threads, scores.data(),
-                                   db.vect_sequences_count * W, c.accum * W);
+                                   db.vect_sequences_count * W, c.accum * W, o.cpu_vector_length);
     const double work_time = dwalltime() - tick;
     std::vector<std::vector<int32_t>> top_s;
     std::vector<std::vector<uint64_t>> top_i;
@@ -335,7 +335,7 @@ int do_search_hybrid(Options &o)
     auto cpu_groups = [&](uint64_t g0, uint64_t g1, int32_t *dst, uint64_t dst_row, uint64_t dst_g0) {
         for (const oswald::Chunk &c : db.chunks) {
             const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
-            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, o.cpu_threads, dst, dst_row, (a0 - dst_g0) * W);
+            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, o.cpu_threads, dst, dst_row, (a0 - dst_g0) * W, o.cpu_vector_length);
         }
     };
     // Test portion.  The host searches the first -p of the groups, as in the reference.  The accelerator's speed
@@ -519,7 +519,7 @@ int main(int argc, char *argv[])
         {"gap_extend", 'e', "<integer>", 0, "Gap extend penalty (default: 2).", 3},
         {"execution_mode", 'm', "<integer>", 0, "0 for accelerator mode, 1 for hybrid mode (host + accelerator), 2 or host-only for host mode (default: 1).", 3},
         {"cpu_threads", 'c', "<integer>", 0, "Number of CPU threads (default: 4).", 3},
-        {"vector_length", 'v', "<integer>", 0, "Vector length in host: 16 or 32 (accepted for compatibility) (default: 16).", 3},
+        {"vector_length", 'v', "<integer>", 0, "Vector length in host: 16 (SSE4.1 kernel) or 32 (AVX2 kernel) (default: 16).", 3},
         {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (accepted for compatibility) (default: 256).", 3},
         {"num_fpgas", 'f', "<integer>", 0, "Number of GPUs (the reference's number of FPGAs) (default: 1).", 3},
         {"max_chunk_size", 'k', "<integer>", 0, "Maximum chunk size on the accelerator (bytes, default: 134217728).", 3},

@@ -73,11 +73,11 @@ def assemble(dbname, W=16, max_chunk=134217728, ndev=1):
     return r
 
 
-def host_search_chunk(chunk, nq, groups, matrix, go, ge, threads=4):
+def host_search_chunk(chunk, nq, groups, matrix, go, ge, threads=4, vector_length=32):
     """oswald::host_search_groups (the `-m 2` / hybrid host kernel) on a chunk of the database assembled last, for
-    the queries loaded last: int32 [nq][groups*16]."""
+    the queries loaded last: int32 [nq][groups*16].  vector_length: the command line's -v (16: SSE4.1 kernel, 32: AVX2)."""
     out = np.zeros((nq, groups * 16), np.int32)
-    if load().oswald_host_search_chunk(chunk, matrix.encode(), go, ge, threads, out.ctypes.data_as(C.c_void_p)):
+    if load().oswald_host_search_chunk_v(chunk, matrix.encode(), go, ge, threads, vector_length, out.ctypes.data_as(C.c_void_p)):
         raise RuntimeError(load().oswald_host_last_error().decode())
     return out
 

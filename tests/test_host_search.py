@@ -26,13 +26,15 @@ def _write_db(tmp_path, qs, nseq, **kw):
     return L, R, O
 
 
-def test_c1_host_kernel_equals_reference_scores(tmp_path):
+@pytest.mark.parametrize("v", [16, 32])
+def test_c1_host_kernel_equals_reference_scores(tmp_path, v):
+    """BASELINE configs[0] on both host kernels: -v 16 (SSE4.1, the path configs[0] names) and -v 32 (AVX2)."""
     g = np.load(os.path.join(GOLD, "scores.npz"))
     q1 = synth.make_queries([375])
     _write_db(tmp_path, q1, 1000, homologs_per_query=12)
     hostlib.load_queries(str(tmp_path / "q.fasta"))
     r = hostlib.assemble(str(tmp_path / "db"), 16, 134217728, 1)
-    got = hostlib.host_search_chunk(0, 1, r["chunks"][0]["groups"], "blosum62", 10, 2)
+    got = hostlib.host_search_chunk(0, 1, r["chunks"][0]["groups"], "blosum62", 10, 2, vector_length=v)
     np.testing.assert_array_equal(got, g["c1/scores"])
     assert got.max() > 127
 
@@ -46,7 +48,7 @@ def test_host_kernel_equals_oracle(tmp_path, oracle, matrix, go, ge):
     assert r["chunk_count"] >= 2
     order, sl, sr, so = dblayout.sort_by_length(L, R, O)
     for ci, c in enumerate(r["chunks"]):
-        got = hostlib.host_search_chunk(ci, 3, c["groups"], matrix, go, ge)
+        got = hostlib.host_search_chunk(ci, 3, c["groups"], matrix, go, ge, vector_length=16 if ci % 2 else 32)
         want = oracle.search_chunk_scalar(q["a"], q["m"], q["disp"][:-1].astype(np.uint32), c["b"], c["n"], c["disp"], 16, submat.load(matrix), go, ge)
         np.testing.assert_array_equal(got, want)
 
@@ -62,6 +64,7 @@ def test_host_kernel_int16_ceiling(tmp_path, oracle):
     hostlib.load_queries(str(tmp_path / "q.fasta"))
     r = hostlib.assemble(str(tmp_path / "db"), 16, 134217728, 1)
     got = hostlib.host_search_chunk(0, 1, r["chunks"][0]["groups"], "blosum62", 10, 2)
+    np.testing.assert_array_equal(hostlib.host_search_chunk(0, 1, r["chunks"][0]["groups"], "blosum62", 10, 2, vector_length=16), got)   # SSE4.1 kernel: the same ceiling handling
     assert sorted(got[0][got[0] > 0].tolist())[-4:] == [11 * 2977, 11 * 2978, 11 * 2979, 11 * 3100]
 
 
