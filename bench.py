@@ -132,10 +132,17 @@ def main():
     dist = None
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
+    backend_note = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            try:
+                dist.init_process_group(backend="nccl", device_id=dev)
+            except Exception as e:  # noqa: BLE001 -- the scaling series must not die on the bring-up of a 1.6 kB gather: say so loudly and go on over gloo
+                backend_note = f"RCCL bring-up failed ({type(e).__name__}: {str(e)[:200]}); top-r gather over gloo instead"
+                print("bench.py: " + backend_note, file=sys.stderr, flush=True)
+                backend = "gloo"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -253,7 +260,8 @@ def main():
             "config": {"workload": f"{cfg_name}: " + wl["label"].format(nseq=nseq_total) + ", " + CELL_LABEL[cell_bits] + "; database resident in HBM (re-tiled) before the timed region",
                        "queries": nq, "query_residues": sum_m, "db_sequences_total": nseq_total * (1 if strong else world),
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
-                       "top": args.top, "sharding": shard_note, "shard_rule": args.shard_rule, "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
+                       "top": args.top, "sharding": shard_note, "shard_rule": args.shard_rule, "collective_backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else None,
+                       "collective_note": backend_note, "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
