@@ -59,7 +59,7 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 1.03, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
-    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1, grid_per_cu = 0;
+    uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_cols_single = 0, wg_wide_cols_single = 0, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1, grid_per_cu = 0;
     bool no_prio = false, one_stream = false;
     bool debug_times = false, debug_nospill = false; // -DOSW_DIAG only
     void refresh();
@@ -87,6 +87,8 @@ void Tunables::refresh()
     quad_frac = num("OSWALD_HIP_QUAD_FRAC", quad_frac);
     wg_min_cols = (uint32_t)num("OSWALD_HIP_WG_MINCOLS", wg_min_cols);
     wg_wide_cols = (uint32_t)num("OSWALD_HIP_WG_WIDECOLS", wg_wide_cols);
+    wg_min_cols_single = (uint32_t)num("OSWALD_HIP_WG_MINCOLS_SINGLE", wg_min_cols_single);
+    wg_wide_cols_single = (uint32_t)num("OSWALD_HIP_WG_WIDECOLS_SINGLE", wg_wide_cols_single);
     wg_min_rounds = (uint32_t)num("OSWALD_HIP_WG_MINROUNDS", wg_min_rounds);
     wg_min_cols_long = (uint32_t)num("OSWALD_HIP_WG_MINCOLS_LONG", wg_min_cols_long);
     two_ended = (uint32_t)num("OSWALD_HIP_TWO_ENDED", 0);
@@ -481,7 +483,13 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
     // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
     int force_lg = tun.force_lg, force_wg = tun.force_wg;
-    const uint32_t wg_min_cols = tun.wg_min_cols, wg_wide_cols = tun.wg_wide_cols;
+    // below wg_min_cols columns a workgroup item becomes wave items, below wg_wide_cols it keeps G <= 8 -- for query
+    // PAIRS (two barriers per round and the wider pipeline fill cost more than the spill they save on short blocks:
+    // C2 -6 % with every block a workgroup item).  SINGLE queries take workgroup items for every block (round 3): their
+    // wave items hold a quarter of a block each -- with one query and 100 000 sequences that is half of a wave's whole
+    // share of the launch, far too coarse for the end of it -- and at G = 4 a long query needs four times the rounds
+    // (C5 8 700 -> 9 220, Q1 7 400 -> 7 800 GCUPS; profiles/r03_sweep_queue_order.txt).
+    const uint32_t wg_min_cols_kind[2] = {tun.wg_min_cols_single, tun.wg_min_cols}, wg_wide_cols_kind[2] = {tun.wg_wide_cols_single, tun.wg_wide_cols};
     if (i32) force_wg = 0; // the int32 kernel has no workgroup phase
     struct It { double cost; uint32_t x, b; };
     std::vector<It> its[2], its_wg[2];
@@ -506,6 +514,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             // boundaries stay workgroup items also on short blocks, down to OSWALD_HIP_WG_MINCOLS_LONG columns)
             const bool many_rounds = tun.wg_min_rounds > 0 && ncols >= tun.wg_min_cols_long &&
                                      osw_plan(e.m, 1u << lg_full_wave[k], kinds[e.kind].ldsr, kinds[e.kind].rmax).rounds >= tun.wg_min_rounds;
+            const uint32_t wg_min_cols = wg_min_cols_kind[e.kind], wg_wide_cols = wg_wide_cols_kind[e.kind];
             if (wg && ncols < wg_min_cols && !many_rounds) {
                 // short block: the pipeline fill of a wide geometry (G columns per round) would cost more
                 // than the spill it saves; run as wave items at the widest full-height geometry (G = 4; 2 for pairs)
