@@ -14,6 +14,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -143,7 +144,8 @@ __attribute__((target("sse4.1"))) void simd_group_sse41(const uint8_t *a, uint32
 } // namespace
 
 void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int W, const int8_t *submat, int open_gap, int extend_gap,
-                        int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length)
+                        int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length, const std::atomic<bool> *cancel,
+                        std::atomic<uint64_t> *padded_residues_done)
 {
     if (W != kFpgaVectorLength) throw std::runtime_error("OSWALD: the host path works on groups of 16 sequences.");
     const int goe = open_gap + extend_gap, ge = extend_gap;
@@ -159,6 +161,7 @@ void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t 
 #pragma omp for schedule(dynamic, 1)
         for (int64_t gi = (int64_t)g1 - 1; gi >= (int64_t)g0; --gi) { // longest groups first
             const uint64_t g = (uint64_t)gi;
+            if (cancel && cancel->load(std::memory_order_relaxed)) continue; // (the caller no longer needs the rest: hybrid calibration)
             const uint8_t *grp = c.b + c.disp[g];
             const uint32_t ncols = c.n[g];
             for (uint64_t qi = 0; qi < nq; ++qi) {
@@ -173,6 +176,7 @@ void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t 
                     else dst[lane] = scalar_score(a, m, grp, ncols, W, lane, submat, goe, ge, s.h32, s.e32); // at the int16 ceiling: exact int32
                 }
             }
+            if (padded_residues_done) padded_residues_done->fetch_add((uint64_t)ncols * W, std::memory_order_relaxed);
         }
     }
 }

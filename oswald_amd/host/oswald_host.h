@@ -12,6 +12,7 @@
 #ifndef OSWALD_HOST_H
 #define OSWALD_HOST_H
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -107,7 +108,10 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
 // (host/src/HybridSearch.c:1540-1880, :790-1140).
 // cpu_vector_length: the command line's -v -- 16 selects the SSE4.1 kernel (the reference's default host path), 32 the AVX2 one.
 void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int vector_length, const int8_t *submat, int open_gap,
-                        int extend_gap, int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length = 32);
+                        int extend_gap, int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length = 32,
+                        const std::atomic<bool> *cancel = nullptr, std::atomic<uint64_t> *padded_residues_done = nullptr);
+// cancel: when it becomes true the groups not yet started are skipped (their scores stay untouched); padded_residues_done
+// accumulates n[g] x 16 of every group finished (what the hybrid mode's calibration measures the host's speed on).
 
 std::vector<std::string> load_database_headers(const std::string &sequences_filename, uint64_t sequences_count);
 // The titles of the given sequences only (any order, duplicates allowed): one pass over the mapped file instead of
