@@ -58,7 +58,7 @@ struct Tunables {
     bool debug_phases = false;         // OSWALD_HIP_DEBUG_PHASES=1: wall time of the host-side phases
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
-    double pair_margin = 1.03, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
+    double pair_margin = 0.95, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
     uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_cols_single = 0, wg_wide_cols_single = 0, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1, grid_per_cu = 0;
     bool no_prio = false, one_stream = false;
     bool debug_times = false, debug_nospill = false; // -DOSW_DIAG only
@@ -271,7 +271,11 @@ bool first_pass_is_q8(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 8 &&
 
 // Pair up queries of similar length (sorted by length, neighbours): a pair costs 7.5 instructions per row of
 // the LONGER query for one sequence, two singles 8.5 per row for two sequences, so pairing pays when the
-// shorter one is longer than ~0.8 of the longer one.
+// shorter one is longer than ~0.8 of the longer one -- in instructions.  In cycles the pair row is cheaper still
+// (25.3 against 30.5 per row: the single-query cell keeps a packed add and a v_perm_b32), and every single query costs
+// a second launch beside the pair launch: the margin on the pair's cost is 0.95 since round 3 (was 1.03), which pairs
+// all twenty queries of the BASELINE set -- 100 000 sequences: 11 360 -> 11 540 GCUPS, 1 M: 11 790 -> 11 760
+// (tools/sweep_pairs.sh).
 // OSWALD_HIP_PAIRS=0 disables it, =2 pairs every neighbour (test hook).
 void plan_pairs(oswald_hip_ctx *ctx)
 {
