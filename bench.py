@@ -87,6 +87,11 @@ def parse():
                          "8 = SWAR 8-bit first pass with int16 re-run (configs[2]); default: 8 for --workload c3 (the cell mode that configuration names), else 16")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--cpu-lanes", type=int, default=32, choices=[16, 32], help="16 = SSE4.1 port, 32 = AVX2 port")
+    ap.add_argument("--gather", default="auto", choices=["auto", "lib", "torch"],
+                    help="who carries the top-r gather between the ranks: lib = the C ABI itself (ncclAllGather inside oswald_hip_topr on a communicator "
+                         "made by oswald_hip_comm_init_rank; torch.distributed only hands the id round and keeps time), torch = torch.distributed.all_gather "
+                         "of the ranks' lists; auto = lib over RCCL, torch for the gloo rehearsal")
+    ap.add_argument("--comm", action="store_true", help="N = 1: give the one rank a process-level RCCL communicator all the same (the gather path of N > 1 at world size 1)")
     ap.add_argument("--write-top-golden", action="store_true", help="N = 1 only: write tests/golden/bench_top_<workload>_<nseq>.json")
     return ap.parse_args()
 
@@ -125,29 +130,26 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path is HIP only (no CPU fallback)")
-    # one rank per GPU over RCCL ("nccl").  OSWALD_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer
-    # GPUs than ranks: ranks share the visible GPUs and the top-r gather runs over gloo on host tensors.
+    # one rank per GPU over RCCL ("nccl").  OSWALD_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
+    # ranks, to be asked for by name: ranks share the visible GPUs and the top-r gather runs over gloo on host tensors.
+    # A failed RCCL bring-up ends the run non-zero (multigpu.init_collective): there is no fallback.
+    from oswald_amd import multigpu
     backend = os.environ.get("OSWALD_BENCH_BACKEND", "nccl")
     gpu = local_rank % torch.cuda.device_count()
     dist = None
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
-    backend_note = None
     if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            try:
-                dist.init_process_group(backend="nccl", device_id=dev)
-            except Exception as e:  # noqa: BLE001 -- the scaling series must not die on the bring-up of a 1.6 kB gather: say so loudly and go on over gloo
-                backend_note = f"RCCL bring-up failed ({type(e).__name__}: {str(e)[:200]}); top-r gather over gloo instead"
-                print("bench.py: " + backend_note, file=sys.stderr, flush=True)
-                backend = "gloo"
-                dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend=backend)
+        if backend == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit(f"bench.py: {world} ranks over RCCL need a GPU each, {torch.cuda.device_count()} visible "
+                             "(OSWALD_BENCH_BACKEND=gloo rehearses the sharding with ranks sharing a GPU)")
+        dist = multigpu.init_collective(backend, dev)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    gather = args.gather if args.gather != "auto" else ("lib" if (world > 1 and backend == "nccl") or args.comm else "torch")
+    if gather == "lib" and world > 1 and backend != "nccl":
+        raise SystemExit("--gather lib needs one GPU per rank (RCCL); the gloo rehearsal gathers through torch.distributed")
 
-    from oswald_amd import capi, dblayout, multigpu, submat, synth
+    from oswald_amd import capi, dblayout, submat, synth
 
     wl = workload(args.workload)
     qlens = wl["qlens"] or synth.default_query_lengths()
@@ -176,6 +178,12 @@ def main():
     index_base = 0 if strong else rank * nseq_total      # weak mode: global index = shard base + sorted position
 
     ctx = capi.Context(1, [gpu])
+    if gather == "lib":
+        # the gather lives in the C ABI: rank 0 makes the id, torch.distributed hands it round, every rank joins
+        ident = [capi.comm_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(ident, src=0, device=coll_dev)
+        ctx.comm_init_rank(ident[0], world, rank)
     cell_bits = args.cell_bits or (8 if args.workload == "c3" else 16)
     ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
     ctx.set_queries(a, m, a_disp)
@@ -186,7 +194,8 @@ def main():
         if c["b"].size >= 2**32:
             raise SystemExit("chunk too large; lower --max-chunk")
         c["h"] = ctx.chunk_upload(c["b"], c["n"], c["disp"], 16)
-        ctx.chunk_set_index(c["h"], 0, c["nseq"], c["gpos"])   # the chunk's sequences -> positions in the sorted database
+        # the chunk's sequences -> positions in the sorted database (--weak: every rank's database has its own range)
+        ctx.chunk_set_index(c["h"], 0, c["nseq"], c["gpos"] + (index_base if gather == "lib" else 0))
         chunks.append(c)
         d_local += int(c["off"][-1])
     t_gen = time.time() - t0
@@ -199,14 +208,30 @@ def main():
         torch.cuda.synchronize(dev)
 
     def step():
-        # every chunk's search queues the selection of its top r behind it (oswald_hip_topr_begin); oswald_hip_topr
-        # waits for the device once and merges the rank's lists in the library
+        # every chunk's search queues the selection of its top r behind it and folds it into the GPU's running list
+        # (oswald_hip_topr_begin); oswald_hip_topr waits for the device once.  gather == "lib": it also all-gathers the
+        # ranks' lists over RCCL and folds them on the GPU -- the list it returns is the job's; "torch": it returns the
+        # rank's list and torch.distributed.all_gather carries the lists between the ranks
         ctx.topr_begin(args.top)
+        if gather == "lib":
+            for c in chunks:
+                ctx.chunk_search(c["h"], None)
+            sc, ix = ctx.topr(args.top)
+            return sc, np.where(ix == 0xFFFFFFFF, -1, ix.astype(np.int64))
         return multigpu.rank_step(chunks, lambda c: ctx.chunk_search(c["h"], None), None, nq, args.top, index_base, dist,
                                   coll_dev if dist is not None else None, collect_rank=lambda: ctx.topr(args.top))
 
+    coll_ranks = None
     if dist is not None:  # the first collective of a process group sets up its channels: not part of any step
-        multigpu.gather_topr(np.full((nq, args.top), -1, np.int32), np.full((nq, args.top), -1, np.int64), args.top, dist, coll_dev)
+        seen = torch.zeros(1, dtype=torch.int64, device=coll_dev) + 1
+        dist.all_reduce(seen)                      # how many ranks the torch.distributed group really carries
+        coll_ranks = int(seen.item())
+        if gather == "torch":
+            multigpu.gather_topr(np.full((nq, args.top), -1, np.int32), np.full((nq, args.top), -1, np.int64), args.top, dist, coll_dev)
+    if gather == "lib":
+        coll_ranks = ctx.comm_info()["process_ranks"]   # ... and how many the library's communicator reports (ncclCommCount)
+    if world > 1 and coll_ranks != world:
+        raise SystemExit(f"bench.py: the collective carries {coll_ranks} ranks, the job has {world}")
     for _ in range(args.warmup):
         step()
     ctx.set_profiling(True)
@@ -250,7 +275,7 @@ def main():
             cfg_name = "C4 database on one GPU"
         rule_note = "128-sequence wave blocks dealt to the GPUs in alternating order" if args.shard_rule == "deal" else f"the reference's chunk rule (chunk c -> GPU c mod {world})"
         shard_note = (f"one database sharded over {world} GPUs by {rule_note}, "
-                      f"{'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}") if world > 1 and strong else \
+                      f"{'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top} ({'inside the C ABI: oswald_hip_topr' if gather == 'lib' else 'torch.distributed'})") if world > 1 and strong else \
                      (f"independent {nseq_total}-sequence database per GPU x{world}, {'RCCL' if backend == 'nccl' else backend} all_gather of top-{args.top}" if world > 1 else "single GPU")
         result = {
             "metric": "GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -260,8 +285,10 @@ def main():
             "config": {"workload": f"{cfg_name}: " + wl["label"].format(nseq=nseq_total) + ", " + CELL_LABEL[cell_bits] + "; database resident in HBM (re-tiled) before the timed region",
                        "queries": nq, "query_residues": sum_m, "db_sequences_total": nseq_total * (1 if strong else world),
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
-                       "top": args.top, "sharding": shard_note, "shard_rule": args.shard_rule, "collective_backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else None,
-                       "collective_note": backend_note, "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
+                       "top": args.top, "sharding": shard_note, "shard_rule": args.shard_rule, "collective_backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 or gather == "lib" else None,
+                       "collective_note": None, "collective_ranks": coll_ranks,
+                       "collective_via": ("liboswald_hip.so: ncclAllGather of nq x r tagged keys inside oswald_hip_topr, folded on the GPU (RCCL %d)" % ctx.comm_info()["rccl_version"]) if gather == "lib"
+                                         else ("torch.distributed.all_gather" if world > 1 else None), "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
@@ -279,23 +306,14 @@ def main():
             "setup_s": round(t_gen, 1),
         }
         result["top_equals_single_gpu_golden"] = check_top_golden(args, nseq_total, strong, world, top)
-        # not `value`: the same pass when the boundary hands over host buffers (H2D of the interleaved
-        # chunks + re-tile + search + D2H of the full int32 score table), the reference's timed region
-        outs = [np.zeros((nq, len(c["n"]) * 16), np.int32) for c in chunks]
-        t0 = time.perf_counter()  # (rank 0's chunks; the other ranks idle at the final barrier meanwhile)
-        hs = []
-        for c, o in zip(chunks, outs):
-            h2 = ctx.chunk_upload(c["b"], c["n"], c["disp"], 16)
-            ctx.chunk_search(h2, o)
-            hs.append(h2)
-        ctx.wait()
-        t_pcie = time.perf_counter() - t0
-        for h2 in hs:
-            ctx.chunk_release(h2)
-        result["pcie_inclusive"] = {"gcups": round(sum_m * d_local / t_pcie / 1e9, 1), "ms": round(t_pcie * 1e3, 2),
-                                    "what": "SURVEY 8(d)'s timed region on rank 0's chunks: chunk_upload (H2D + re-tile) + search + D2H of all scores, pageable host memory"}
+        # not `value`: the same pass when the boundary hands over host buffers -- the reference's timed region
+        # (FPGAsearch.c:80 -> :276: uploads + kernels + download of the score table).  The host buffers are pinned
+        # (the reference allocates its own 64-byte aligned "for DMA", sequences.h:15, FPGAsearch.c:69-74), and the
+        # upload of chunk k+1 is queued while chunk k is being searched (the library's upload stream), as the CLI does.
+        result["pcie_inclusive"] = pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=True)
+        result["pcie_inclusive_pageable"] = pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=False)["gcups"]
         if args.cpu_seconds > 0 and world == 1 and chunks:  # reported at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(args, a, m, a_disp, chunks[0], outs[0], sm, wl, sum_m)
+            result["cpu_baseline"] = cpu_baseline(args, a, m, a_disp, chunks, ctx, sm, wl, sum_m)
     for c in chunks:
         ctx.chunk_release(c["h"])
     ctx.close()
@@ -306,6 +324,44 @@ def main():
         print(json.dumps(result), flush=True)
         if result.get("top_equals_single_gpu_golden") is False:
             raise SystemExit("bench.py: the merged top list differs from the single-GPU golden result (tests/golden/bench_top_*.json)")
+
+
+def pinned_like(x):
+    """A copy of the numpy array in page-locked host memory (torch's allocator = hipHostMalloc)."""
+    import torch
+    t = torch.empty(x.shape, dtype=torch.from_numpy(x[:0]).dtype).pin_memory()
+    v = t.numpy()
+    v[...] = x
+    return t, v
+
+
+def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned):
+    """SURVEY 8(d)'s timed region on rank 0's chunks: H2D of the interleaved chunk + re-tile + search + D2H of the
+    whole int32 score table, chunk k+1 uploading while chunk k is searched."""
+    import torch
+    keep, bufs, outs = [], [], []
+    for c in chunks:
+        if pinned:
+            tb, b = pinned_like(c["b"]); tn, n = pinned_like(c["n"]); td, d = pinned_like(c["disp"])
+            to = torch.empty((nq, len(c["n"]) * 16), dtype=torch.int32).pin_memory()
+            keep += [tb, tn, td, to]
+            bufs.append((b, n, d)); outs.append(to.numpy())
+        else:
+            bufs.append((c["b"], c["n"], c["disp"])); outs.append(np.zeros((nq, len(c["n"]) * 16), np.int32))
+    ctx.wait()
+    t0 = time.perf_counter()  # (rank 0's chunks; the other ranks idle at the final barrier meanwhile)
+    h = ctx.chunk_upload(*bufs[0], 16, wait=False) if bufs else None
+    for k in range(len(bufs)):
+        ctx.chunk_search(h, outs[k])                 # waits for ITS upload only; queued behind the search before it
+        nxt = ctx.chunk_upload(*bufs[k + 1], 16, wait=False) if k + 1 < len(bufs) else None
+        ctx.chunk_release(h)                         # the slot is re-used once the device is through with it
+        h = nxt
+    ctx.wait()
+    t = time.perf_counter() - t0
+    pcie_inclusive.last_scores = outs
+    return {"gcups": round(sum_m * d_local / t / 1e9, 1), "ms": round(t * 1e3, 2),
+            "what": "SURVEY 8(d)'s timed region on rank 0's chunks (reference FPGAsearch.c:80-276): H2D of the interleaved chunk + re-tile + search + D2H of "
+                    "all int32 scores; upload of chunk k+1 overlapped with the search of chunk k; " + ("pinned host buffers" if pinned else "pageable host memory")}
 
 
 def golden_path(args, nseq_total):
@@ -353,47 +409,74 @@ def measured_traffic(workload_name, nseq):
     return t.get("hbm_bytes_per_launch"), f"rocprofv3 FETCH_SIZE+WRITE_SIZE, {os.path.relpath(path, ROOT)}"
 
 
-def cpu_baseline(args, a, m, a_disp, chunk, gpu_scores, sm, wl, sum_m):
-    """The oracle's SIMD port of the reference host path (SSE4.1/AVX2
-    int8->int16->int32, OpenMP over groups) timed on this box's host cores on a
-    bounded sample: every k-th W-lane group of rank 0's first chunk, all queries.
-    Its scores are also compared with the GPU's for the sampled sequences."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, a, m, a_disp, chunks, ctx, sm, wl, sum_m):
+    """The oracle's SIMD port of the reference host path (SSE4.1/AVX2 int8->int16->int32, OpenMP over groups) timed on
+    this box's host cores on a bounded sample of THE BENCHED DATABASE: every k-th W-lane group of every chunk of rank 0
+    (the chunks are length-sorted runs, so the sample has the database's own length distribution), all queries.  Its
+    scores are compared with the GPU's for the sampled sequences (the score tables the PCIe-inclusive leg downloaded)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     from oswald_amd import dblayout
     W = args.cpu_lanes
     threads = pyoracle.max_threads()
-    sl, sr, so = chunk["ls"], chunk["res"], chunk["off"]
-    nseq = len(sl)
-    ngroups = (nseq + W - 1) // W
-    # calibrate on a few groups, then size the sample for ~cpu_seconds
+    gpu_tables = pcie_inclusive.last_scores
+
     def sample(stride):
-        gsel = np.arange(0, ngroups, stride)
-        seqs = (gsel[:, None] * W + np.arange(W)[None, :]).reshape(-1)
-        seqs = seqs[seqs < nseq]
-        lens = sl[seqs].astype(np.int64)
-        off = np.zeros(len(seqs) + 1, np.int64)
-        np.cumsum(lens, out=off[1:])
-        idx = np.repeat(so[seqs] - off[:-1], lens) + np.arange(int(off[-1]))
-        res = sr[idx]
-        bb, nn, dd = dblayout.interleave(lens, res, off, W, round_to=1)
-        return seqs, int(lens.sum()), bb, nn, dd.astype(np.uint32)
-    seqs, dres, bb, nn, dd = sample(max(1, ngroups // 64))
+        """every stride-th W-lane group of every chunk -> (per-chunk sequence picks, residues, interleaved sample)"""
+        picks, lens_all, res_all = [], [], []
+        for c in chunks:
+            sl, sr, so = c["ls"], c["res"], c["off"]
+            nseq = len(sl)
+            gsel = np.arange(0, (nseq + W - 1) // W, stride)
+            seqs = (gsel[:, None] * W + np.arange(W)[None, :]).reshape(-1)
+            seqs = seqs[seqs < nseq]
+            lens = sl[seqs].astype(np.int64)
+            off = np.zeros(len(seqs) + 1, np.int64)
+            np.cumsum(lens, out=off[1:])
+            idx = np.repeat(so[seqs] - off[:-1], lens) + np.arange(int(off[-1]))
+            picks.append(seqs); lens_all.append(lens); res_all.append(sr[idx])
+        lens = np.concatenate(lens_all)
+        order = np.argsort(lens, kind="stable")                  # the host path searches a length-sorted database
+        res_cat = np.concatenate(res_all)
+        off_cat = np.zeros(len(lens) + 1, np.int64)
+        np.cumsum(lens, out=off_cat[1:])
+        sl2 = lens[order]
+        off2 = np.zeros(len(lens) + 1, np.int64)
+        np.cumsum(sl2, out=off2[1:])
+        idx = np.repeat(off_cat[:-1][order] - off2[:-1], sl2) + np.arange(int(off2[-1]))
+        bb, nn, dd = dblayout.interleave(sl2, res_cat[idx], off2, W, round_to=1)
+        return picks, order, int(lens.sum()), bb, nn, dd.astype(np.uint32)
+
+    total_groups = sum((len(c["ls"]) + W - 1) // W for c in chunks)
+    total_res = float(sum(int(c["off"][-1]) for c in chunks))
+    picks, order, dres, bb, nn, dd = sample(max(1, total_groups // 64))     # calibrate on a few groups ...
     t0 = time.perf_counter()
     pyoracle.search_chunk_simd(a, m, a_disp, bb, nn, dd, W, sm, wl["go"], wl["ge"], 256, threads)
-    t_cal = time.perf_counter() - t0
-    rate = sum_m * dres / t_cal
-    want_res = rate * args.cpu_seconds / sum_m
-    stride = max(1, int(np.ceil(float(sl.astype(np.int64).sum()) / max(want_res, 1.0))))
-    seqs, dres, bb, nn, dd = sample(stride)
+    rate = sum_m * dres / (time.perf_counter() - t0)
+    want_res = rate * args.cpu_seconds / sum_m                             # ... then size the sample for ~cpu_seconds
+    stride = max(1, int(np.ceil(total_res / max(want_res, 1.0))))
+    picks, order, dres, bb, nn, dd = sample(stride)
     t0 = time.perf_counter()
     sc_cpu, stage = pyoracle.search_chunk_simd(a, m, a_disp, bb, nn, dd, W, sm, wl["go"], wl["ge"], 256, threads)
     t = time.perf_counter() - t0
-    # parity of the sampled sequences against the GPU score table (downloaded by the PCIe-inclusive leg)
-    equal = bool(np.array_equal(gpu_scores[:, seqs], sc_cpu[:, :len(seqs)]))
-    return {"value": round(sum_m * dres / t / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
-            "sample": f"every {stride}-th {W}-lane group of rank 0's first chunk ({len(seqs)} sequences, {dres} residues) x all {len(m)} queries, "
-                      f"{'AVX2' if W == 32 else 'SSE4.1'} int8->int16->int32 port, block 256, {t:.1f} s",
+    # parity of the sampled sequences against the GPU score tables
+    gpu = np.concatenate([tab[:, p] for tab, p in zip(gpu_tables, picks)], axis=1)[:, order]
+    equal = bool(np.array_equal(gpu, sc_cpu[:, :gpu.shape[1]]))
+    nsamp = int(sum(len(p) for p in picks))
+    return {"value": round(sum_m * dres / t / 1e9, 3), "unit": "GCUPS", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"every {stride}-th {W}-lane group of each of rank 0's {len(chunks)} chunks = of the whole benched database ({nsamp} sequences, {dres} residues, "
+                      f"mean length {dres / max(nsamp, 1):.0f}) x all {len(m)} queries, {'AVX2' if W == 32 else 'SSE4.1'} int8->int16->int32 port, block 256, {t:.1f} s",
             "gpu_scores_equal_on_sample": equal,
             "cells_by_precision": {"int8": int(stage[0]), "int16": int(stage[1]), "int32": int(stage[2])}}
 

@@ -43,8 +43,9 @@ extern "C" {
 #define OSWALD_HIP_ERUNTIME (-3) /* HIP runtime call failed */
 #define OSWALD_HIP_ENOMEM (-4)   /* host or device allocation failed */
 #define OSWALD_HIP_ESTATE (-5)   /* call sequence violated (e.g. search before set_queries) */
+#define OSWALD_HIP_ECOMM (-6)    /* an RCCL call failed (multi-GPU top-r gather) */
 
-#define OSWALD_HIP_ABI_VERSION 2
+#define OSWALD_HIP_ABI_VERSION 3
 
 typedef struct oswald_hip_ctx oswald_hip_ctx;
 
@@ -102,9 +103,11 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
                             const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int *chunk);
 
 /* The same, without waiting for the device: returns once the copies and the re-tile kernel are queued on the
- * device's stream.  b / n / disp must stay valid until the chunk has been searched (oswald_hip_chunk_search
- * finishes the upload first) or oswald_hip_wait() has returned.  With several devices this is what lets their
- * uploads overlap: queue all of them, then search each (the reference's four clEnqueueWriteBuffer per device
+ * device's UPLOAD stream -- uploads have a stream of their own, so chunk k+1 comes in while chunk k is being
+ * searched: queue search k, then upload k+1 (the reference uploads and searches strictly in turn,
+ * FPGAsearch.c:180-223).  b / n / disp must stay valid until the chunk has been searched or released
+ * (oswald_hip_chunk_search and _release finish the upload first) or oswald_hip_wait() has returned.  With several
+ * devices this is also what lets their uploads overlap: queue all of them, then search each (the reference's four clEnqueueWriteBuffer per device
  * are asynchronous too and share one clFinish per device, FPGAsearch.c:180-198). */
 int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                                   const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int *chunk);
@@ -115,6 +118,13 @@ int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b
  * chunk before the timed region starts (FPGAsearch.c:85-96). */
 int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length);
 
+/* The largest chunk -- in bytes of b, i.e. padded residues, the unit of the command line's -k -- device dev can hold for
+ * a set of nq queries and sequences of up to max_sequence_length residues: 0.8 of its free memory (less the work
+ * space still to be allocated) over what a byte of chunk costs at worst (staging copy, two resident chunks per device
+ * -- one searched while the next comes in --, re-tiled residues, scores and re-run queues).  Replaces the clamp of
+ * max_chunk_size to the device's global memory in init(), utils.c:162-168 (0.8 x memory / 23 score-profile rows). */
+int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_t max_sequence_length, uint64_t *bytes);
+
 /* All queries against a resident chunk, asynchronously on the device's stream.
  * If scores_out != NULL the int32 scores [nq][ngroups*W] are copied there
  * (valid after oswald_hip_wait).  Replaces the per-query clSetKernelArg +
@@ -122,6 +132,8 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
  * host-side overflow re-computation, FPGAsearch.c:204-274. */
 int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out);
 
+/* Gives the chunk's slot back.  Returns once the chunk's upload has landed (the caller's b / n / disp are free); a
+ * search of the chunk may still be running -- the next upload into the slot waits for it on the device. */
 int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk);
 
 /* Convenience: upload + search + release in one asynchronous call, the exact
@@ -144,29 +156,50 @@ int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nval
                           int32_t *scores, uint32_t *index);
 
 /* Context-level top-r: the r best (score, database index) pairs per query over EVERY chunk searched on EVERY
- * device of the context, in the order sort_scores() produces (descending score, equal scores by DESCENDING
- * database index, host/src/utils.c:3-86).  Replaces the merge of the devices' score tables into the global one
- * (host/src/FPGAsearch.c:236-237), sort_scores() (utils.c:71-86) and the top-r loop (FPGAsearch.c:312-321) -- the
- * "multi-GPU gather" of a process that drives several GPUs through one context.  Use:
- *   oswald_hip_topr_begin(ctx, r)       start collecting (drops what was collected before); r <= 1024;
+ * device of the context -- and, with a process-level communicator (below), of every process of the job -- in the
+ * order sort_scores() produces (descending score, equal scores by DESCENDING database index,
+ * host/src/utils.c:3-86).  Replaces the merge of the devices' score tables into the global one
+ * (host/src/FPGAsearch.c:236-237), sort_scores() (utils.c:71-86) and the top-r loop (FPGAsearch.c:312-321).  This is
+ * the multi-GPU gather of the path, and it runs on the GPUs: every device keeps a running list of r tagged keys per
+ * query, a chunk's r best are selected and folded into it on the device right behind the search, the GPUs of the
+ * context all-gather their lists over RCCL/xGMI (ncclCommInitAll over the context's distinct GPUs at bring-up; a
+ * context on one GPU needs no communicator), GPU 0 folds them, and nq x r pairs come to the host in one copy.  Use:
+ *   oswald_hip_topr_begin(ctx, r)       start collecting (drops what was collected before); r <= 1024; after
+ *                                       oswald_hip_set_queries (a new query set needs a new _begin);
  *   oswald_hip_chunk_set_index(...)     after an upload: the chunk's place in the database -- sequence k of the chunk
  *                                       is database sequence first_index + k, or index_map[k] if a map is given (it is
- *                                       copied; a chunk need not be one contiguous run); nvalid real sequences;
+ *                                       copied, in any order; a chunk need not be one contiguous run); nvalid real sequences;
  *   oswald_hip_chunk_search(...)        of a chunk that has its index now also selects the chunk's r best on its
  *                                       device, queued on the device's stream behind the search: nothing waits, and the
- *                                       chunk may be released (its slot re-used) right after the call;
- *   oswald_hip_topr(ctx, r, ...)        waits for all devices and merges everything collected since _begin
+ *                                       chunk may be released (its slot re-used) right after the call.  (A chunk
+ *                                       searched twice counts once: lists hold distinct database keys.)
+ *   oswald_hip_topr(ctx, r, ...)        gathers, waits for all devices and returns everything collected since _begin
  *                                       (r <= the r given to _begin).  scores / db_index: [nq][r], host memory; slots
  *                                       beyond the number of database sequences seen: score -1, index 0xffffffff.
- * The one merge implementation of the library; oswald_hip_merge_candidates exposes it for callers that combine
- * lists of several contexts or processes (ncand candidates per query, [nq][ncand]; score < 0 = empty slot).  It is
- * host logic and works without a GPU. */
+ * oswald_hip_merge_candidates is the same order as host logic (ncand candidates per query, [nq][ncand]; score < 0 =
+ * empty slot); it works without a GPU.  Nothing in the library falls back to it: it is there for callers that hold
+ * lists of their own, and as the checker of the tests. */
 int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r);
 int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t first_index, uint32_t nvalid,
                                const uint32_t *index_map);
 int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *db_index);
 int oswald_hip_merge_candidates(uint32_t nq, uint64_t ncand, const int32_t *cand_scores, const uint32_t *cand_index,
                                 uint32_t r, int32_t *scores, uint32_t *db_index);
+
+/* Process-level communicator: one rank per process (one process per GPU, or per group of GPUs).  With it
+ * oswald_hip_topr all-gathers the contexts' lists between the processes over RCCL (from context device 0) and every
+ * rank receives the list of the whole job; the call is then COLLECTIVE -- every rank must make it, with the same r and
+ * the same number of queries.  Rank 0 calls oswald_hip_comm_unique_id and hands the id (OSWALD_HIP_COMM_ID_BYTES
+ * bytes) to the other ranks by any means it has (MPI, a file, torch.distributed ...); then every rank calls
+ * oswald_hip_comm_init_rank (collective; wraps ncclCommInitRank on context device 0).  The reference has one process
+ * and one host merge (FPGAsearch.c:236-237); this is what stands there for a job of several processes.
+ * oswald_hip_comm_info: out[0] = ranks of the in-context communicator (distinct GPUs of the context, as RCCL
+ * reports them; 1 = none needed), out[1] = ranks of the process-level communicator as RCCL reports them (0 = none),
+ * out[2] = this process's rank in it (-1 = none), out[3] = RCCL version code. */
+#define OSWALD_HIP_COMM_ID_BYTES 128
+int oswald_hip_comm_unique_id(void *id, size_t id_bytes);
+int oswald_hip_comm_init_rank(oswald_hip_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank);
+int oswald_hip_comm_info(oswald_hip_ctx *ctx, int *out4);
 
 /* Device time spent in the DP kernels since the last reset, measured with HIP
  * events on the device's stream (enabled by oswald_hip_set_profiling). */

@@ -26,7 +26,9 @@ SYMBOLS = (
     "oswald_hip_chunk_release", "oswald_hip_search_chunk_async", "oswald_hip_wait", "oswald_hip_chunk_topr",
     "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry", "oswald_hip_chunk_upload_async", "oswald_hip_reserve", "oswald_hip_rerun_counts",
     "oswald_hip_topr_begin", "oswald_hip_chunk_set_index", "oswald_hip_topr", "oswald_hip_merge_candidates",
+    "oswald_hip_comm_unique_id", "oswald_hip_comm_init_rank", "oswald_hip_comm_info", "oswald_hip_max_chunk_size",
 )
+COMM_ID_BYTES = 128   # OSWALD_HIP_COMM_ID_BYTES
 
 
 class OswaldHipError(RuntimeError):
@@ -67,6 +69,10 @@ def load():
     lib.oswald_hip_chunk_set_index.argtypes = [vp, i32, i32, u32, u32, vp]
     lib.oswald_hip_topr.argtypes = [vp, u32, vp, vp]
     lib.oswald_hip_merge_candidates.argtypes = [u32, u64, vp, vp, u32, vp, vp]
+    lib.oswald_hip_max_chunk_size.argtypes = [vp, i32, u32, u32, C.POINTER(u64)]
+    lib.oswald_hip_comm_unique_id.argtypes = [vp, sz]
+    lib.oswald_hip_comm_init_rank.argtypes = [vp, vp, sz, i32, i32]
+    lib.oswald_hip_comm_info.argtypes = [vp, C.POINTER(i32)]
     lib.oswald_hip_set_profiling.argtypes = [vp, i32]
     lib.oswald_hip_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), i32]
     lib.oswald_hip_chunk_geometry.argtypes = [vp, i32, i32, C.POINTER(u64)]
@@ -97,6 +103,13 @@ def merge_candidates(cand_scores: np.ndarray, cand_index: np.ndarray, r: int):
     out_i = np.empty((cs.shape[0], r), np.uint32)
     _chk(load().oswald_hip_merge_candidates(cs.shape[0], cs.shape[1], _ptr(cs), _ptr(ci), r, _ptr(out_s), _ptr(out_i)))
     return out_s, out_i
+
+
+def comm_unique_id() -> bytes:
+    """oswald_hip_comm_unique_id: the id rank 0 hands to the other ranks (COMM_ID_BYTES bytes)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(load().oswald_hip_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
 
 
 def device_count() -> int:
@@ -206,6 +219,22 @@ class Context:
         ix = np.empty((self.nq, r), dtype=np.uint32)
         _chk(self.lib.oswald_hip_topr(self.h, r, _ptr(sc), _ptr(ix)))
         return sc, ix
+
+    def max_chunk_size(self, nq: int, max_sequence_length: int, dev: int = 0) -> int:
+        out = C.c_uint64(0)
+        _chk(self.lib.oswald_hip_max_chunk_size(self.h, dev, nq, max_sequence_length, C.byref(out)))
+        return int(out.value)
+
+    def comm_init_rank(self, comm_id: bytes, nranks: int, rank: int):
+        """Collective: joins the process-level RCCL communicator; topr() then returns the list of all ranks."""
+        assert len(comm_id) >= COMM_ID_BYTES
+        buf = C.create_string_buffer(bytes(comm_id), len(comm_id))
+        _chk(self.lib.oswald_hip_comm_init_rank(self.h, buf, len(comm_id), nranks, rank))
+
+    def comm_info(self):
+        out = (C.c_int * 4)()
+        _chk(self.lib.oswald_hip_comm_info(self.h, out))
+        return {"context_ranks": int(out[0]), "process_ranks": int(out[1]), "process_rank": int(out[2]), "rccl_version": int(out[3])}
 
     def set_profiling(self, on: bool):
         _chk(self.lib.oswald_hip_set_profiling(self.h, 1 if on else 0))

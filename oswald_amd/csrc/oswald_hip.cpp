@@ -8,6 +8,7 @@
 #include "sw_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -44,6 +45,12 @@ int fail(int code, const char *fmt, ...)
                         hipGetErrorString(e__));                                                              \
     } while (0)
 
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r__ = (expr);                                                                      \
+        if (r__ != ncclSuccess) return fail(OSWALD_HIP_ECOMM, "%s: %s", #expr, ncclGetErrorString(r__)); \
+    } while (0)
+
 // Environment hooks.  They are read when a context is CONFIGURED (oswald_hip_init, oswald_hip_set_scoring,
 // oswald_hip_set_queries), never on the per-search path.  The default build knows the test hooks and the
 // host-side timing prints only -- none of them changes a result.  The planner sweep knobs and the kernel timing
@@ -57,6 +64,7 @@ struct Tunables {
     bool debug_plan = false;           // OSWALD_HIP_DEBUG=1: print the work-queue plan
     bool debug_phases = false;         // OSWALD_HIP_DEBUG_PHASES=1: wall time of the host-side phases
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
+    size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 0.95, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
     uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_cols_single = 0, wg_wide_cols_single = 0, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1, grid_per_cu = 0;
@@ -79,6 +87,7 @@ void Tunables::refresh()
     debug_plan = flag("OSWALD_HIP_DEBUG");
     debug_phases = flag("OSWALD_HIP_DEBUG_PHASES");
     no_pin = flag("OSWALD_HIP_NO_PIN");
+    fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
 #ifdef OSW_DIAG
     pair_margin = num("OSWALD_HIP_PAIR_MARGIN", pair_margin);
@@ -122,13 +131,15 @@ struct DevBuf {
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        // (a failed hipFree / hipMalloc leaves HIP's last error set; callers that recover from the failure must not see it
+        // again in the next launch check: it is cleared here, the code is returned)
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) { (void)hipGetLastError(); return e; } p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (ms > 5.0 && g_debug_slow) fprintf(stderr, "[oswald_hip] slow hipMalloc: %zu bytes took %.1f ms\n", want, ms);
-        if (e != hipSuccess) { p = nullptr; return e; }
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return e; }
         cap = want;
         return hipSuccess;
     }
@@ -153,44 +164,17 @@ struct Chunk {
     uint32_t max_lg = 0;                // widest geometry in the item list
     uint64_t planned_spill_bytes = 0;   // strip-boundary spill traffic (written + read back) one search of the chunk causes, from the plan
     bool searched = false;
-    bool upload_pending = false;        // uploaded with _async: the device's stream has not been synchronised since
+    bool upload_pending = false;        // uploaded with _async: the host has not waited for the upload since
+    uint64_t up_seq = 0;                // position of the upload on the device's upload stream
+    hipEvent_t ev_up = nullptr;         // recorded on the upload stream behind the chunk's upload
+    hipEvent_t ev_use = nullptr;        // recorded on the search stream behind the chunk's last search ...
+    bool use_pending = false;           // ... which an upload into the same slot must wait for
     // the chunk's place in the database (oswald_hip_chunk_set_index): database index of its k-th sequence =
     // index_map[k] if a map was given, else first_index + k; nvalid real sequences
     bool has_index = false;
     uint32_t first_index = 0, nvalid = 0;
-    std::shared_ptr<const std::vector<uint32_t>> index_map;
-};
-
-// One chunk's top list on its way to the context-level merge (oswald_hip_topr): [nq][r] scores and indices-in-chunk in
-// pinned host memory, filled by copies queued on the device's stream right behind the search.
-struct TopPart {
-    int32_t *scores = nullptr;
-    uint32_t *index = nullptr;
-    uint32_t nq = 0, r = 0, first_index = 0;
-    std::shared_ptr<const std::vector<uint32_t>> index_map;
-};
-
-// Pinned host memory for the TopParts, handed out in pieces and recycled by oswald_hip_topr_begin.
-struct PinnedPool {
-    std::vector<std::pair<char *, size_t>> slabs;
-    size_t slab = 0, used = 0;
-    void *take(size_t bytes)
-    {
-        bytes = (bytes + 63) & ~(size_t)63;
-        while (slab < slabs.size() && used + bytes > slabs[slab].second) { ++slab; used = 0; }
-        if (slab == slabs.size()) {
-            const size_t sz = std::max<size_t>(bytes, 1u << 20);
-            void *p = nullptr;
-            if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess) return nullptr;
-            slabs.push_back({(char *)p, sz});
-            used = 0;
-        }
-        void *out = slabs[slab].first + used;
-        used += bytes;
-        return out;
-    }
-    void rewind() { slab = 0; used = 0; }
-    void release() { for (auto &s : slabs) (void)hipHostFree(s.first); slabs.clear(); rewind(); }
+    std::shared_ptr<const std::vector<uint32_t>> index_map; // host copy: source of the (asynchronous) upload below
+    DevBuf index_map_dev;
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -199,6 +183,8 @@ struct Device {
     int id = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second queue: the single-query launch runs beside the query-pair launch
+    hipStream_t stream_up = nullptr; // uploads (H2D + re-tile): the next chunk comes in while the current one is searched
+    uint64_t up_seq = 0;             // uploads queued so far
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
@@ -206,14 +192,25 @@ struct Device {
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
     DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
     std::vector<uint32_t> top_pages_host; // source of the asynchronous upload of top_pages
+    std::vector<std::shared_ptr<const std::vector<uint32_t>>> retired_maps; // index maps of re-used slots whose upload may still be queued
     std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
     uint64_t scoring_version = ~0ull;
     std::vector<Chunk> chunks;
     std::vector<EventPair> ev_pool, ev_used;
-    std::vector<TopPart> top_parts;  // top lists accumulated since oswald_hip_topr_begin
-    PinnedPool top_pool;
+    // context-level top-r (oswald_hip_topr_begin ... oswald_hip_topr): the device's RUNNING list, [nq][r] tagged keys
+    // ((score << 32 | database index) << 1 | 1, 0 = none); every chunk search folds its chunk's r best into it
+    // (top_run[top_cur] -> top_run[top_cur ^ 1]); top_gather receives the lists of the other GPUs (RCCL all-gather)
+    DevBuf top_run[2], top_gather, top_final;
+    int top_cur = 0;
+    bool top_any = false;            // a list has been folded in since _begin
+    hipEvent_t ev_top = nullptr;     // "the running list is complete" (for a sibling entry on the same GPU)
+    // RCCL: one communicator per PHYSICAL GPU of the context, held by the first context device on it (the leader);
+    // further context devices on the same GPU (device_ids {0, 0}: a test configuration) hand their lists to the leader
+    int leader = -1;                 // index of the first context device on this GPU
+    int comm_rank = -1;              // leader: rank in the context's communicator (order of first appearance)
+    ncclComm_t comm = nullptr;       // leader, when the context spans more than one GPU
     double dp_ms = 0;
     uint64_t dp_launches = 0, rerun_items = 0;
 };
@@ -241,6 +238,14 @@ struct oswald_hip_ctx {
     uint64_t queries_version = 0;
     bool profiling = false;
     uint32_t topr_r = 0;             // oswald_hip_topr_begin: every search also selects the chunk's top r (0: off)
+    uint64_t topr_queries_version = 0; // the query set the lists are being collected for
+    int nphys = 0;                   // distinct GPUs of the context (= ranks of the in-context communicator)
+    // process-level communicator (oswald_hip_comm_init_rank): the contexts of several processes, one rank each, held
+    // by context device 0; oswald_hip_topr then returns the list of ALL ranks on every rank
+    ncclComm_t pcomm = nullptr;
+    int pcomm_nranks = 0, pcomm_rank = -1;
+    void *top_host = nullptr;        // pinned: the final list on its way to the caller
+    size_t top_host_bytes = 0;
 };
 
 namespace {
@@ -657,6 +662,7 @@ void release_registered(Device &d)
 {
     for (void *p : d.registered) (void)hipHostUnregister(p);
     d.registered.clear();
+    d.retired_maps.clear();
 }
 
 // Strip-boundary spill scratch: one region per resident wave and launch (two launches run side by side), every region
@@ -687,12 +693,13 @@ int ensure_scratch(Device &d, uint32_t max_cols)
     return 0;
 }
 
-// An upload queued with oswald_hip_chunk_upload_async has landed once the device's stream is drained.
+// An upload queued with oswald_hip_chunk_upload_async has landed once its event on the upload stream has: the host
+// waits for THAT, not for the search stream -- a search of another chunk may be running meanwhile.
 int finish_upload(Device &d, Chunk &c)
 {
     if (!c.upload_pending) return 0;
-    HIP_TRY(hipStreamSynchronize(d.stream));
-    for (Chunk &k : d.chunks) k.upload_pending = false; // one stream: everything queued before is done too
+    HIP_TRY(hipEventSynchronize(c.ev_up));
+    for (Chunk &k : d.chunks) if (k.up_seq <= c.up_seq) k.upload_pending = false; // one in-order stream: everything queued before is done too
     return 0;
 }
 
@@ -717,31 +724,24 @@ int queue_topr(oswald_hip_ctx *ctx, Device &d, Chunk &c, uint32_t nvalid, uint32
     return 0;
 }
 
-// Context-level top-r (oswald_hip_topr_begin): select the top r of the chunk just searched on its device and queue
-// the copy of the list into pinned host memory, all on the device's stream -- the caller is not made to wait, and the
-// device buffers are free for the next chunk's list as soon as the stream gets there.
+// Context-level top-r (oswald_hip_topr_begin): select the top r of the chunk just searched on its device, as tagged
+// DATABASE keys, and fold them into the device's running list -- all queued on the device's stream behind the search:
+// the caller is not made to wait, nothing leaves the device, and the chunk may be released right after.
 int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c)
 {
     if (ctx->topr_r == 0 || !c.has_index || ctx->nq == 0) return 0;
     const uint32_t r = ctx->topr_r;
+    if (ctx->topr_queries_version != ctx->queries_version)
+        return fail(OSWALD_HIP_ESTATE, "the query set changed since oswald_hip_topr_begin: call it again before searching");
     if (c.nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "chunk index: nvalid %u exceeds the chunk's %u lanes", c.nvalid, c.ngroups * c.W);
-    const size_t cnt = (size_t)ctx->nq * r;
-    TopPart part;
-    part.scores = (int32_t *)d.top_pool.take(cnt * sizeof(int32_t));
-    part.index = (uint32_t *)d.top_pool.take(cnt * sizeof(uint32_t));
-    if (!part.scores || !part.index) return fail(OSWALD_HIP_ENOMEM, "pinned host memory for the top lists");
-    part.nq = ctx->nq;
-    part.r = r;
-    part.first_index = c.first_index;
-    part.index_map = c.index_map;
-    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0 || c.nvalid == 0) { // nothing was searched: an empty list
-        for (size_t k = 0; k < cnt; ++k) { part.scores[k] = -1; part.index[k] = 0xffffffffu; }
-    } else {
-        if (int rc = queue_topr(ctx, d, c, c.nvalid, r)) return rc;
-        HIP_TRY(hipMemcpyAsync(part.scores, d.topr_scores.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
-        HIP_TRY(hipMemcpyAsync(part.index, d.topr_index.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    }
-    d.top_parts.push_back(part);
+    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0 || c.nvalid == 0) return 0; // nothing was searched: nothing to add
+    if (!d.top_run[0].p || !d.top_run[1].p) return fail(OSWALD_HIP_ESTATE, "oswald_hip_topr_begin has not prepared device %d", d.id);
+    HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * osw_topr_parts(c.nvalid) * r * sizeof(unsigned long long)));
+    HIP_TRY(osw_launch_topr_fold_chunk((const int32_t *)c.scores.p, c.score_stride, c.nvalid, r, ctx->nq,
+                                       c.index_map ? (const uint32_t *)c.index_map_dev.p : nullptr, c.first_index, (unsigned long long *)d.topr_cand.p,
+                                       (const unsigned long long *)d.top_run[d.top_cur].p, (unsigned long long *)d.top_run[d.top_cur ^ 1].p, d.stream));
+    d.top_cur ^= 1;
+    d.top_any = true;
     return 0;
 }
 
@@ -802,8 +802,10 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         if (r == hipSuccess) r = hipGetDeviceProperties(&d.prop, d.id);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_up, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming);
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_top, hipEventDisableTiming);
         int per_cu = 0;
         if (r == hipSuccess) r = (hipError_t)osw_occupancy_pk16(&per_cu);
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "bring-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
@@ -839,6 +841,24 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "warm-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
         }
     }
+    // one RCCL rank per distinct GPU of the context, in order of first appearance; a context on one GPU needs none
+    for (int i = 0; i < ndev; ++i) {
+        Device &d = ctx->dev[i];
+        for (int k = 0; k < i && d.leader < 0; ++k) if (ctx->dev[k].id == d.id) d.leader = k;
+        if (d.leader < 0) { d.leader = i; d.comm_rank = ctx->nphys++; }
+    }
+    if (ctx->nphys > 1) {
+        std::vector<int> ids;
+        std::vector<ncclComm_t> comms(ctx->nphys, nullptr);
+        for (const Device &d : ctx->dev) if (d.comm_rank >= 0) ids.push_back(d.id);
+        const ncclResult_t nr = ncclCommInitAll(comms.data(), ctx->nphys, ids.data());
+        if (nr != ncclSuccess) {
+            oswald_hip_finalize(ctx);
+            return fail(OSWALD_HIP_ECOMM, "ncclCommInitAll over %d GPUs failed: %s (the top-r gather of a multi-GPU context runs over RCCL; there is no other path)",
+                        ctx->nphys, ncclGetErrorString(nr));
+        }
+        for (Device &d : ctx->dev) if (d.comm_rank >= 0) d.comm = comms[d.comm_rank];
+    }
     *out = ctx;
     return 0;
 }
@@ -850,11 +870,17 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         (void)hipSetDevice(d.id);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         release_registered(d);
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); }
+        if (d.stream2) (void)hipStreamSynchronize(d.stream2);
+        if (d.stream_up) { (void)hipStreamSynchronize(d.stream_up); (void)hipStreamDestroy(d.stream_up); d.stream_up = nullptr; }
+        for (Chunk &c : d.chunks) { if (c.ev_up) (void)hipEventDestroy(c.ev_up); if (c.ev_use) (void)hipEventDestroy(c.ev_use); c.ev_up = c.ev_use = nullptr; }
+        if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
+        if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev.release(); }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
-                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8})
+                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
+                          &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
             b->release();
-        d.top_pool.release();
+        if (d.ev_top) (void)hipEventDestroy(d.ev_top);
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
@@ -862,6 +888,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         if (d.ev_join) (void)hipEventDestroy(d.ev_join);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
+    if (ctx->top_host) (void)hipHostFree(ctx->top_host);
     delete ctx;
     return 0;
 }
@@ -984,22 +1011,33 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     HIP_TRY(d.staging_b.reserve(vD + 64));
     HIP_TRY(d.staging_n.reserve(ngroups * sizeof(uint16_t) + 16));
     HIP_TRY(d.staging_disp.reserve(ngroups * sizeof(uint32_t) + 16));
+    if (!c.ev_up) HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
+    if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
     pt.lap("upload: plan + allocations");
+    // Uploads have a stream of their own: chunk k+1 comes in (DMA + re-tile) while chunk k is searched.  The slot may
+    // still be in use by the search of the chunk it held before (oswald_hip_search_chunk_async, or a release right
+    // behind a search): the upload stream waits for that search.  The staging buffers are shared by the uploads of a
+    // device, which that one stream keeps in order.
+    hipStream_t up = d.stream_up;
+    if (c.use_pending) { HIP_TRY(hipStreamWaitEvent(up, c.ev_use, 0)); c.use_pending = false; }
     if (ngroups > 0) {
-        HIP_TRY(hipMemcpyAsync(d.staging_b.p, b, vD, hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(d.staging_n.p, n, ngroups * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(d.staging_disp.p, disp, ngroups * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(c.blocks.p, blocks.data(), c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemsetAsync(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), d.stream)); // pads = dummy residue
+        HIP_TRY(hipMemcpyAsync(d.staging_b.p, b, vD, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(d.staging_n.p, n, ngroups * sizeof(uint16_t), hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(d.staging_disp.p, disp, ngroups * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(c.blocks.p, blocks.data(), c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemsetAsync(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), up)); // pads = dummy residue
         HIP_TRY(osw_launch_retile((const uint8_t *)d.staging_b.p, (const uint16_t *)d.staging_n.p, (const uint32_t *)d.staging_disp.p,
-                                  ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, (uint16_t *)c.sub_cols_buf.p, d.stream));
+                                  ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, (uint16_t *)c.sub_cols_buf.p, up));
     }
-    if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("upload: H2D + re-tile"); }
+    if (pt.on) { HIP_TRY(hipStreamSynchronize(up)); pt.lap("upload: H2D + re-tile"); }
     c.sub_cols.assign((size_t)c.nblocks * 128, 0);
-    if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols.data(), c.sub_cols_dev(), c.sub_cols.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, d.stream));
+    if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols.data(), c.sub_cols_dev(), c.sub_cols.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, up));
+    HIP_TRY(hipEventRecord(c.ev_up, up));
+    c.up_seq = ++d.up_seq;
     c.items_version = ~0ull;
     c.searched = false;
     c.has_index = false;
+    if (c.index_map) d.retired_maps.push_back(std::move(c.index_map)); // (its copy to the device may still be queued: freed at the next synchronisation)
     c.index_map.reset();
     c.live = true;
     c.upload_pending = true;
@@ -1037,6 +1075,32 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
     return 0;
 }
 
+// Device memory one byte of chunk (one padded residue of the interleaved groups) takes, worst case: the staging copy
+// of the upload (1), and for each of the two chunks a device holds while one is searched and the next comes in: the
+// re-tiled residues (a 128-sequence block is padded to its longest group: <= 1.25), the all-dummy columns behind every
+// block (18 x 512 B per block of >= 128 x 28 B: 2.6), and per sequence -- at most one per 28 bytes, the shortest
+// padded group length -- 4 B of score, 8 B of int32 re-run queue and 8 B of int16 re-run queue per query.
+int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_t max_sequence_length, uint64_t *bytes)
+{
+    if (int r = check_dev(ctx, dev)) return r;
+    if (!bytes) return fail(OSWALD_HIP_EINVAL, "null output");
+    Device &d = ctx->dev[dev];
+    HIP_TRY(hipSetDevice(d.id));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (ctx->tun.fake_free_mem) free_b = std::min<size_t>(free_b, ctx->tun.fake_free_mem);
+    // the spill scratch of the longest sequence, if it is not there yet (ensure_scratch)
+    const uint64_t cols = std::min<uint64_t>(std::max<uint64_t>((uint64_t)max_sequence_length + 28, 1024), 4096);
+    const uint64_t stride = (cols + OSW_SCRATCH_PAD_COLS) * 32u;
+    const uint64_t scratch = 2ull * d.grid * (OSW_WG_THREADS / 64) * (stride + OSW_SCRATCH_DATA) * sizeof(uint2);
+    uint64_t usable = (uint64_t)(0.8 * (double)free_b);
+    if (stride > d.bnd_stride || !d.bnd.p) usable = usable > scratch ? usable - scratch : 0;
+    const double per_byte = 1.0 + 2.0 * (1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
+    const uint64_t fit = (uint64_t)((double)usable / per_byte);
+    *bytes = std::min<uint64_t>(fit, 0xfff00000ull); // (column offsets inside a chunk are 32-bit)
+    return 0;
+}
+
 int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out)
 {
     if (int r = check_dev(ctx, dev)) return r;
@@ -1045,7 +1109,9 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
     PhaseTimer pt(ctx->tun.debug_phases);
-    if (int r = finish_upload(d, c)) return r; // the planner reads the chunk's live extents
+    if (ctx->topr_r && c.has_index && ctx->topr_queries_version != ctx->queries_version)
+        return fail(OSWALD_HIP_ESTATE, "the query set changed since oswald_hip_topr_begin: call it again before searching");
+    if (int r = finish_upload(d, c)) return r; // the planner reads the chunk's live extents; the kernels queued below find the chunk in place
     if (int r = sync_queries(ctx, d)) return r;
     pt.lap("search: queries + profiles");
     if (int r = build_items(ctx, d, c)) return r;
@@ -1179,6 +1245,8 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
     if (int r = topr_after_search(ctx, d, c)) return r;
+    HIP_TRY(hipEventRecord(c.ev_use, d.stream)); // an upload into this slot waits for it
+    c.use_pending = true;
     if (dbg_times) {
         // diagnostics only: when did the workgroups of the DP launch start / leave phase 1 / finish
         HIP_TRY(hipStreamSynchronize(d.stream));
@@ -1271,8 +1339,9 @@ int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
     Device &d = ctx->dev[dev];
     if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
     HIP_TRY(hipSetDevice(d.id));
-    HIP_TRY(hipStreamSynchronize(d.stream));
-    d.chunks[chunk].upload_pending = false;
+    // the caller's b / n / disp are free once the upload has landed; a search of the chunk may still be running -- the
+    // next upload into the slot waits for it on the device (ev_use), the host does not
+    if (int r = finish_upload(d, d.chunks[chunk])) return r;
     d.chunks[chunk].live = false; // buffers are kept for the next upload into this slot
     return 0;
 }
@@ -1295,7 +1364,9 @@ int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
     for (int i = 0; i < (int)ctx->dev.size(); ++i) {
         if (dev >= 0 && i != dev) continue;
         HIP_TRY(hipSetDevice(ctx->dev[i].id));
+        HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_up));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream));
+        for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; }
         release_registered(ctx->dev[i]);
     }
     return 0;
@@ -1329,10 +1400,20 @@ int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t
     Chunk &c = d.chunks[chunk];
     if (nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "nvalid %u exceeds the chunk's %u lanes", nvalid, c.ngroups * c.W);
     if (!index_map && (uint64_t)first_index + nvalid > 0xffffffffull) return fail(OSWALD_HIP_EINVAL, "database indices must fit 32 bits");
+    HIP_TRY(hipSetDevice(d.id));
+    if (c.index_map) { // the old map may still be on its way to the device, into the buffer the new one is about to take
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        c.index_map.reset();
+    }
     c.first_index = first_index;
     c.nvalid = nvalid;
-    c.index_map.reset();
-    if (index_map) c.index_map = std::make_shared<const std::vector<uint32_t>>(index_map, index_map + nvalid);
+    if (index_map && nvalid > 0) {
+        // the map goes to the device (the chunk's top list is selected there, on database keys); the host copy is the
+        // source of that asynchronous upload and lives as long as the chunk's index does
+        c.index_map = std::make_shared<const std::vector<uint32_t>>(index_map, index_map + nvalid);
+        HIP_TRY(c.index_map_dev.reserve((size_t)nvalid * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(c.index_map_dev.p, c.index_map->data(), (size_t)nvalid * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+    }
     c.has_index = true;
     return 0;
 }
@@ -1341,16 +1422,31 @@ int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (r > 1024) return fail(OSWALD_HIP_EINVAL, "top-r on the device supports r <= 1024 (asked for %u): download the score table instead", r);
+    if (r > 0 && !ctx->have_queries) return fail(OSWALD_HIP_ESTATE, "oswald_hip_set_queries has not been called");
+    const size_t bytes = (size_t)ctx->nq * r * sizeof(unsigned long long);
     for (Device &d : ctx->dev) {
         HIP_TRY(hipSetDevice(d.id));
-        HIP_TRY(hipStreamSynchronize(d.stream)); // copies into the lists about to be dropped may still be queued
-        d.top_parts.clear();
-        d.top_pool.rewind();
+        d.top_any = false;
+        d.top_cur = 0;
+        if (bytes == 0) continue;
+        for (int k = 0; k < 2; ++k) {
+            if (bytes > d.top_run[k].cap) HIP_TRY(hipStreamSynchronize(d.stream)); // (growing frees the old list: nothing may still be reading it)
+            HIP_TRY(d.top_run[k].reserve(bytes));
+        }
+        HIP_TRY(hipMemsetAsync(d.top_run[0].p, 0, bytes, d.stream)); // key 0 = none; ordered behind whatever still reads the old list
     }
     ctx->topr_r = r;
+    ctx->topr_queries_version = ctx->queries_version;
     return 0;
 }
 
+// The gather of oswald_hip_topr.  Level 1: context devices that share a GPU hand their running lists to the first of
+// them (plain reads on the same GPU, ordered by an event).  Level 2: the GPUs of the context -- one RCCL rank each,
+// communicator made by ncclCommInitAll at bring-up -- all-gather their lists over xGMI, and GPU 0 of the context folds
+// them.  Level 3: with a process-level communicator (oswald_hip_comm_init_rank) the contexts' lists are all-gathered
+// between the processes and folded again, so every rank ends up with the list of the whole job.  Then ONE copy of
+// nq x r (score, index) pairs to the host.  Every fold is osw_topr_fold on tagged keys: descending score, equal
+// scores by descending database index (utils.c:3-86).
 int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *db_index)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
@@ -1358,35 +1454,126 @@ int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *
     if (!scores || !db_index) return fail(OSWALD_HIP_EINVAL, "null output");
     if (ctx->topr_r == 0) return fail(OSWALD_HIP_ESTATE, "oswald_hip_topr_begin has not been called");
     if (r > ctx->topr_r) return fail(OSWALD_HIP_EINVAL, "r = %u exceeds the %u lists were collected for (oswald_hip_topr_begin)", r, ctx->topr_r);
-    const uint32_t nq = ctx->nq;
-    size_t K = 0;
+    if (ctx->topr_queries_version != ctx->queries_version) return fail(OSWALD_HIP_ESTATE, "the query set changed while top lists were being collected");
+    const uint32_t nq = ctx->nq, R = ctx->topr_r;
+    const size_t cnt = (size_t)nq * R, bytes = cnt * sizeof(unsigned long long);
+    typedef unsigned long long key_t;
+    // level 1: siblings -> leader (the sibling's list is on the same GPU: read in place once its stream got there)
     for (Device &d : ctx->dev) {
+        if (&ctx->dev[d.leader] == &d || !d.top_any) continue;
         HIP_TRY(hipSetDevice(d.id));
-        HIP_TRY(hipStreamSynchronize(d.stream)); // the lists have landed
-        release_registered(d);
-        for (const TopPart &p : d.top_parts) {
-            if (p.nq != nq) return fail(OSWALD_HIP_ESTATE, "the query set changed while top lists were being collected");
-            K += p.r;
+        HIP_TRY(hipEventRecord(d.ev_top, d.stream));
+    }
+    for (Device &d : ctx->dev) {
+        if (&ctx->dev[d.leader] != &d) continue;
+        HIP_TRY(hipSetDevice(d.id));
+        // room for the lists an all-gather brings in, allocated before anything is queued
+        const size_t nlists = (size_t)std::max(ctx->nphys, &d == &ctx->dev[0] ? ctx->pcomm_nranks : 0);
+        if (nlists > 1 || (ctx->pcomm && &d == &ctx->dev[0])) HIP_TRY(d.top_gather.reserve(std::max<size_t>(nlists, 1) * bytes));
+        for (Device &s : ctx->dev) {
+            if (&s == &d || &ctx->dev[s.leader] != &d || !s.top_any) continue;
+            HIP_TRY(hipStreamWaitEvent(d.stream, s.ev_top, 0));
+            HIP_TRY(osw_launch_topr_fold_lists2((const key_t *)s.top_run[s.top_cur].p, (const key_t *)d.top_run[d.top_cur].p, R, nq,
+                                                (key_t *)d.top_run[d.top_cur ^ 1].p, d.stream));
+            d.top_cur ^= 1;
+            d.top_any = true;
         }
     }
-    // all lists side by side, indices-in-chunk turned into database indices; then the one merge
-    std::vector<int32_t> cs((size_t)nq * K, -1);
-    std::vector<uint32_t> ci((size_t)nq * K, 0xffffffffu);
-    size_t k0 = 0;
-    for (const Device &d : ctx->dev)
-        for (const TopPart &p : d.top_parts) {
-            for (uint32_t q = 0; q < nq; ++q)
-                for (uint32_t j = 0; j < p.r; ++j) {
-                    const int32_t sc = p.scores[(size_t)q * p.r + j];
-                    const uint32_t ix = p.index[(size_t)q * p.r + j];
-                    if (sc < 0 || ix == 0xffffffffu) continue;
-                    if (p.index_map && ix >= p.index_map->size()) return fail(OSWALD_HIP_ERUNTIME, "top list index %u outside the chunk's index map", ix);
-                    cs[(size_t)q * K + k0 + j] = sc;
-                    ci[(size_t)q * K + k0 + j] = p.index_map ? (*p.index_map)[ix] : p.first_index + ix;
-                }
-            k0 += p.r;
+    Device &root = ctx->dev[0];
+    // level 2: the GPUs of the context
+    if (ctx->nphys > 1) {
+        NCCL_TRY(ncclGroupStart());
+        for (Device &d : ctx->dev) {
+            if (d.comm_rank < 0) continue;
+            const ncclResult_t nr = ncclAllGather(d.top_run[d.top_cur].p, d.top_gather.p, cnt, ncclUint64, d.comm, d.stream);
+            if (nr != ncclSuccess) { (void)ncclGroupEnd(); return fail(OSWALD_HIP_ECOMM, "ncclAllGather (GPU %d): %s", d.id, ncclGetErrorString(nr)); }
         }
-    merge_candidates(nq, K, cs.data(), ci.data(), r, scores, db_index);
+        NCCL_TRY(ncclGroupEnd());
+        HIP_TRY(hipSetDevice(root.id));
+        HIP_TRY(osw_launch_topr_fold_lists((const key_t *)root.top_gather.p, (uint32_t)ctx->nphys, cnt, R, nq, (key_t *)root.top_run[root.top_cur ^ 1].p, root.stream));
+        root.top_cur ^= 1;
+    }
+    HIP_TRY(hipSetDevice(root.id));
+    // level 3: the ranks of the job
+    if (ctx->pcomm && ctx->pcomm_nranks > 0) {
+        NCCL_TRY(ncclAllGather(root.top_run[root.top_cur].p, root.top_gather.p, cnt, ncclUint64, ctx->pcomm, root.stream));
+        HIP_TRY(osw_launch_topr_fold_lists((const key_t *)root.top_gather.p, (uint32_t)ctx->pcomm_nranks, cnt, R, nq, (key_t *)root.top_run[root.top_cur ^ 1].p, root.stream));
+        root.top_cur ^= 1;
+    }
+    // the first r of every query's R keys -> (score, index), one copy to the host
+    const size_t out_cnt = (size_t)nq * r;
+    HIP_TRY(root.top_final.reserve(out_cnt * 8));
+    if (ctx->top_host_bytes < out_cnt * 8) {
+        if (ctx->top_host) (void)hipHostFree(ctx->top_host);
+        ctx->top_host = nullptr;
+        ctx->top_host_bytes = 0;
+        HIP_TRY(hipHostMalloc(&ctx->top_host, out_cnt * 8, hipHostMallocDefault));
+        ctx->top_host_bytes = out_cnt * 8;
+    }
+    HIP_TRY(osw_launch_topr_untag((const key_t *)root.top_run[root.top_cur].p, nq, R, r, (int32_t *)root.top_final.p, (uint32_t *)root.top_final.p + out_cnt, root.stream));
+    HIP_TRY(hipMemcpyAsync(ctx->top_host, root.top_final.p, out_cnt * 8, hipMemcpyDeviceToHost, root.stream));
+    for (Device &d : ctx->dev) { // everything queued is done: the lists have been folded, downloads of score tables have landed
+        HIP_TRY(hipSetDevice(d.id));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        release_registered(d);
+    }
+    memcpy(scores, ctx->top_host, out_cnt * sizeof(int32_t));
+    memcpy(db_index, (const char *)ctx->top_host + out_cnt * sizeof(int32_t), out_cnt * sizeof(uint32_t));
+    return 0;
+}
+
+int oswald_hip_comm_unique_id(void *id, size_t id_bytes)
+{
+    if (!id || id_bytes < sizeof(ncclUniqueId)) return fail(OSWALD_HIP_EINVAL, "the id buffer must hold %zu bytes", sizeof(ncclUniqueId));
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    memset(id, 0, id_bytes);
+    memcpy(id, &u, sizeof u);
+    return 0;
+}
+
+int oswald_hip_comm_init_rank(oswald_hip_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank)
+{
+    if (!ctx || !id) return fail(OSWALD_HIP_EINVAL, "null argument");
+    if (id_bytes < sizeof(ncclUniqueId)) return fail(OSWALD_HIP_EINVAL, "the id must be the %zu bytes oswald_hip_comm_unique_id wrote", sizeof(ncclUniqueId));
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(OSWALD_HIP_EINVAL, "rank %d of %d", rank, nranks);
+    if (ctx->pcomm) return fail(OSWALD_HIP_ESTATE, "the context already has a process-level communicator");
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    HIP_TRY(hipSetDevice(ctx->dev[0].id));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(ncclCommInitRank(&comm, nranks, u, rank));
+    int count = 0, me = -1;
+    ncclResult_t nr = ncclCommCount(comm, &count);
+    if (nr == ncclSuccess) nr = ncclCommUserRank(comm, &me);
+    if (nr != ncclSuccess || count != nranks || me != rank) {
+        (void)ncclCommDestroy(comm);
+        return fail(OSWALD_HIP_ECOMM, "the communicator reports rank %d of %d, expected %d of %d (%s)", me, count, rank, nranks, ncclGetErrorString(nr));
+    }
+    ctx->pcomm = comm;
+    ctx->pcomm_nranks = nranks;
+    ctx->pcomm_rank = rank;
+    return 0;
+}
+
+int oswald_hip_comm_info(oswald_hip_ctx *ctx, int *out4)
+{
+    if (!ctx || !out4) return fail(OSWALD_HIP_EINVAL, "null argument");
+    int version = 0;
+    NCCL_TRY(ncclGetVersion(&version));
+    out4[0] = ctx->nphys;
+    out4[1] = 0;
+    out4[2] = -1;
+    out4[3] = version;
+    if (ctx->nphys > 1) { // what the in-context communicator itself reports
+        int count = 0;
+        NCCL_TRY(ncclCommCount(ctx->dev[0].comm, &count));
+        out4[0] = count;
+    }
+    if (ctx->pcomm) {
+        NCCL_TRY(ncclCommCount(ctx->pcomm, &out4[1]));
+        NCCL_TRY(ncclCommUserRank(ctx->pcomm, &out4[2]));
+    }
     return 0;
 }
 
@@ -1445,8 +1632,8 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
     uint64_t *out6 = out8;
     Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
+    if (int r = finish_upload(d, c)) return r;
     HIP_TRY(hipStreamSynchronize(d.stream));
-    c.upload_pending = false;
     std::vector<OswBlock> blocks(c.nblocks);
     if (c.nblocks) HIP_TRY(hipMemcpy(blocks.data(), c.blocks.p, c.nblocks * sizeof(OswBlock), hipMemcpyDeviceToHost));
     uint64_t alloc = 0, live = 0;

@@ -157,6 +157,15 @@ hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, co
 uint32_t osw_topr_parts(uint32_t nvalid); // partitions per score row; `cand` holds nq * parts * r tagged keys
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
                            unsigned long long *cand, int32_t *out_scores, uint32_t *out_index, hipStream_t s);
+// context-level top-r (oswald_hip_topr): lists of r tagged keys ((score << 32 | database index) << 1 | 1; 0 = none) per query
+hipError_t osw_launch_topr_fold_chunk(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
+                                      const uint32_t *index_map, uint32_t first_index, unsigned long long *cand,
+                                      const unsigned long long *run_in, unsigned long long *run_out, hipStream_t s);
+hipError_t osw_launch_topr_fold_lists(const unsigned long long *lists, uint32_t L, uint64_t list_stride, uint32_t r, uint32_t nq,
+                                      unsigned long long *out, hipStream_t s);
+hipError_t osw_launch_topr_fold_lists2(const unsigned long long *a, const unsigned long long *b, uint32_t r, uint32_t nq, unsigned long long *out, hipStream_t s);
+hipError_t osw_launch_topr_untag(const unsigned long long *keys, uint32_t nq, uint32_t r, uint32_t r_out, int32_t *out_scores, uint32_t *out_index,
+                                 hipStream_t s);
 int osw_occupancy_pk16(int *blocks_per_cu);
 int osw_occupancy_q8(int *blocks_per_cu);
 

@@ -1403,14 +1403,23 @@ static __device__ __forceinline__ void osw_select_top(KeyAt key_at, uint32_t n, 
     }
 }
 
+// key of score-row element i: index-in-chunk i, or -- for the context-level lists -- its DATABASE index (first + i, or
+// map[i] for a chunk that is not one contiguous run of the database): the selection then breaks ties by database index
+// whatever the order of the map.
 extern "C" __global__ __launch_bounds__(256) void osw_topr_part(const int32_t *__restrict__ scores, uint32_t score_stride, uint32_t nvalid,
-                                                                 uint32_t r, uint32_t part, unsigned long long *__restrict__ cand)
+                                                                 uint32_t r, uint32_t part, const uint32_t *__restrict__ index_map, uint32_t first_index,
+                                                                 unsigned long long *__restrict__ cand)
 {
     const uint32_t q = blockIdx.x, p = blockIdx.y, P = gridDim.y;
     const uint32_t i0 = p * part, n = i0 < nvalid ? (nvalid - i0 < part ? nvalid - i0 : part) : 0;
     const int32_t *row = scores + (size_t)q * score_stride + i0;
-    osw_select_top([&](uint32_t i) { return ((((unsigned long long)(uint32_t)row[i] << 32) | (i0 + i)) << 1) | 1ull; }, n, r,
-                   cand + ((size_t)q * P + p) * r);
+    if (index_map) {
+        const uint32_t *map = index_map + i0;
+        osw_select_top([&](uint32_t i) { return ((((unsigned long long)(uint32_t)row[i] << 32) | map[i]) << 1) | 1ull; }, n, r, cand + ((size_t)q * P + p) * r);
+    } else {
+        const uint32_t base = first_index + i0;
+        osw_select_top([&](uint32_t i) { return ((((unsigned long long)(uint32_t)row[i] << 32) | (base + i)) << 1) | 1ull; }, n, r, cand + ((size_t)q * P + p) * r);
+    }
 }
 
 extern "C" __global__ __launch_bounds__(256) void osw_topr_merge(const unsigned long long *__restrict__ cand, uint32_t ncand, uint32_t r,
@@ -1426,6 +1435,31 @@ extern "C" __global__ __launch_bounds__(256) void osw_topr_merge(const unsigned 
         out_scores[(size_t)q * r + k] = (m & 1ull) ? (int32_t)((m >> 1) >> 32) : -1;
         out_index[(size_t)q * r + k] = (m & 1ull) ? (uint32_t)((m >> 1) & 0xffffffffull) : 0xffffffffu;
     }
+}
+
+// Fold lists of tagged keys into one: query q's candidates are `ncand` keys at cand + q * ncand (may be 0) and L lists
+// of r keys each at lists + l * list_stride + q * r -- a device's running list, the lists of the GPUs an all-gather
+// brought together, ...  The r largest DISTINCT keys go to out + q * r (a key that appears twice -- a chunk searched
+// twice -- counts once: every round takes the largest key below the one before).  `out` must not alias an input.
+extern "C" __global__ __launch_bounds__(256) void osw_topr_fold(const unsigned long long *__restrict__ cand, uint32_t ncand,
+                                                                 const unsigned long long *__restrict__ lists, uint32_t L, uint64_t list_stride,
+                                                                 uint32_t r, unsigned long long *__restrict__ out)
+{
+    const uint32_t q = blockIdx.x;
+    const unsigned long long *c = cand + (size_t)q * ncand, *l0 = lists + (size_t)q * r;
+    osw_select_top([&](uint32_t i) { return i < ncand ? c[i] : l0[(size_t)((i - ncand) / r) * list_stride + (i - ncand) % r]; }, ncand + L * r, r,
+                   out + (size_t)q * r);
+}
+
+// tagged keys -> (score, index); the first r_out of every r keys; empty slots: score -1, index 0xffffffff
+extern "C" __global__ __launch_bounds__(256) void osw_topr_untag(const unsigned long long *__restrict__ keys, uint32_t nq, uint32_t r, uint32_t r_out,
+                                                                  int32_t *__restrict__ out_scores, uint32_t *__restrict__ out_index)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nq * r_out) return;
+    const unsigned long long m = keys[(size_t)(k / r_out) * r + k % r_out];
+    out_scores[k] = (m & 1ull) ? (int32_t)((m >> 1) >> 32) : -1;
+    out_index[k] = (m & 1ull) ? (uint32_t)((m >> 1) & 0xffffffffull) : 0xffffffffu;
 }
 
 // ---------------------------------------------------------------------------
@@ -1534,9 +1568,51 @@ hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_
 {
     if (nq == 0 || r == 0) return hipSuccess;
     const uint32_t P = osw_topr_parts(nvalid), part = (nvalid + P - 1) / P;
-    hipLaunchKernelGGL(osw_topr_part, dim3(nq, P), dim3(256), 0, s, scores, score_stride, nvalid, r, part, cand);
+    hipLaunchKernelGGL(osw_topr_part, dim3(nq, P), dim3(256), 0, s, scores, score_stride, nvalid, r, part, (const uint32_t *)nullptr, 0u, cand);
     OSW_LAUNCH_CHECK();
     hipLaunchKernelGGL(osw_topr_merge, dim3(nq), dim3(256), 0, s, (const unsigned long long *)cand, P * r, r, out_scores, out_index);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// the chunk's r best per query as tagged DATABASE keys, folded into the device's running list: run_out = top r of
+// (run_in, chunk)
+hipError_t osw_launch_topr_fold_chunk(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
+                                      const uint32_t *index_map, uint32_t first_index, unsigned long long *cand,
+                                      const unsigned long long *run_in, unsigned long long *run_out, hipStream_t s)
+{
+    if (nq == 0 || r == 0) return hipSuccess;
+    const uint32_t P = osw_topr_parts(nvalid), part = (nvalid + P - 1) / P;
+    hipLaunchKernelGGL(osw_topr_part, dim3(nq, P), dim3(256), 0, s, scores, score_stride, nvalid, r, part, index_map, first_index, cand);
+    OSW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(osw_topr_fold, dim3(nq), dim3(256), 0, s, (const unsigned long long *)cand, P * r, run_in, 1u, (uint64_t)0, r, run_out);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_topr_fold_lists(const unsigned long long *lists, uint32_t L, uint64_t list_stride, uint32_t r, uint32_t nq,
+                                      unsigned long long *out, hipStream_t s)
+{
+    if (nq == 0 || r == 0) return hipSuccess;
+    hipLaunchKernelGGL(osw_topr_fold, dim3(nq), dim3(256), 0, s, (const unsigned long long *)nullptr, 0u, lists, L, list_stride, r, out);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// two lists of r keys per query, both laid out [nq][r]
+hipError_t osw_launch_topr_fold_lists2(const unsigned long long *a, const unsigned long long *b, uint32_t r, uint32_t nq, unsigned long long *out, hipStream_t s)
+{
+    if (nq == 0 || r == 0) return hipSuccess;
+    hipLaunchKernelGGL(osw_topr_fold, dim3(nq), dim3(256), 0, s, a, r, b, 1u, (uint64_t)0, r, out);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_topr_untag(const unsigned long long *keys, uint32_t nq, uint32_t r, uint32_t r_out, int32_t *out_scores, uint32_t *out_index,
+                                 hipStream_t s)
+{
+    if (nq == 0 || r_out == 0) return hipSuccess;
+    hipLaunchKernelGGL(osw_topr_untag, dim3((nq * r_out + 255) / 256), dim3(256), 0, s, keys, nq, r, r_out, out_scores, out_index);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

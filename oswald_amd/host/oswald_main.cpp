@@ -420,6 +420,102 @@ int do_search_hybrid(Options &o)
     return 0;
 }
 
+// What one device is given in one round of the accelerator-only search: a run of whole groups in the layout the C ABI
+// takes, and where its sequences sit in the database.
+struct Piece {
+    const uint8_t *b = nullptr;
+    uint64_t bytes = 0;
+    const uint16_t *n = nullptr;
+    const uint32_t *disp = nullptr;
+    uint32_t ngroups = 0, first_index = 0, nvalid = 0;
+    std::vector<uint32_t> index_map;          // dealt pieces: database index of every sequence (not one contiguous run)
+    std::vector<uint8_t> owned_b;             // dealt pieces: their groups copied together
+    std::vector<uint16_t> owned_n;
+    std::vector<uint32_t> owned_disp;
+};
+
+// One device: the chunks of the database in order (reference FPGAsearch.c:132-138 with one FPGA).
+std::vector<std::vector<Piece>> contiguous_pieces(const oswald::Database &db)
+{
+    const uint64_t W = oswald::kFpgaVectorLength;
+    std::vector<std::vector<Piece>> per_dev(1);
+    for (const oswald::Chunk &c : db.chunks) {
+        Piece p;
+        p.b = c.b; p.bytes = c.b_size; p.n = c.n.data(); p.disp = c.disp.data(); p.ngroups = (uint32_t)c.n.size();
+        const uint64_t first = c.accum * W, last = std::min<uint64_t>(db.sequences_count, (c.accum + c.n.size()) * W);
+        p.first_index = (uint32_t)first;
+        p.nvalid = (uint32_t)(last - first);
+        per_dev[0].push_back(std::move(p));
+    }
+    return per_dev;
+}
+
+// Several devices: the length-sorted database is DEALT to them in units of 8 consecutive groups (128 sequences, the
+// block one wave of the search kernels works on), counted from the longest end, forwards in even rounds and backwards
+// in odd ones -- every device gets the same length distribution and they finish together (1 M sequences over 8 GPUs:
+// predicted 7.95 x).  The reference cuts contiguous shards of equal padded size instead (sequences.c:510-515, chunk c
+// to device c mod ndev, FPGAsearch.c:132-138): its last shard holds all the longest sequences and takes 1.3 x as long
+// as the mean (6.54 x).  A device's units, in ascending order, are copied together into chunks of at most
+// max_chunk_size bytes; every chunk carries the database indices of its sequences.  Part of the group assembly: before
+// the clock, like assemble_multiple_chunks_db in the reference.
+std::vector<std::vector<Piece>> dealt_pieces(const oswald::Database &db, unsigned ndev, uint64_t max_chunk_size, int threads)
+{
+    const uint64_t W = oswald::kFpgaVectorLength, G = db.vect_sequences_count, N = db.sequences_count, UNIT = 8;
+    struct GroupRef { const uint8_t *b; uint16_t n; };
+    std::vector<GroupRef> groups;
+    groups.reserve(G);
+    for (const oswald::Chunk &c : db.chunks)
+        for (size_t g = 0; g < c.n.size(); ++g) groups.push_back({c.b + c.disp[g], c.n[g]});
+    const uint64_t nunits = (G + UNIT - 1) / UNIT;
+    std::vector<std::vector<uint64_t>> units(ndev); // first group of every unit of a device, ascending
+    for (uint64_t u = 0; u < nunits; ++u) {
+        const uint64_t t = u / ndev, j = u % ndev, d = (t & 1) ? ndev - 1 - j : j;
+        units[d].push_back(G > (u + 1) * UNIT ? G - (u + 1) * UNIT : 0);
+    }
+    std::vector<std::vector<Piece>> per_dev(ndev);
+    for (unsigned d = 0; d < ndev; ++d) {
+        std::reverse(units[d].begin(), units[d].end());
+        auto unit_end = [&](uint64_t g0) { return std::min<uint64_t>(G, g0 == 0 && G % UNIT ? G % UNIT : g0 + UNIT); };
+        std::vector<uint64_t> gl;        // the device's groups, ascending
+        std::vector<uint8_t> unit_start; // ... and which of them open a unit (chunks are cut there when they can be)
+        uint64_t total = 0;
+        for (uint64_t g0 : units[d])
+            for (uint64_t g = g0; g < unit_end(g0); ++g) { gl.push_back(g); unit_start.push_back(g == g0); total += (uint64_t)groups[g].n * W; }
+        const uint64_t parts = std::max<uint64_t>(1, (total + max_chunk_size - 1) / max_chunk_size), target = (total + parts - 1) / parts;
+        size_t k = 0;
+        while (k < gl.size()) {
+            Piece p;
+            uint64_t bytes = 0;
+            const size_t k0 = k;
+            while (k < gl.size()) {
+                const uint64_t gb = (uint64_t)groups[gl[k]].n * W;
+                if (gb > max_chunk_size) throw std::runtime_error("OSWALD: max_chunk_size is smaller than one group of sequences.");
+                if (k > k0 && (bytes + gb > max_chunk_size || (bytes >= target && unit_start[k]))) break;
+                bytes += gb;
+                ++k;
+            }
+            p.owned_b.resize(bytes);
+            for (size_t i = k0; i < k; ++i) {
+                const uint64_t g = gl[i];
+                p.owned_n.push_back(groups[g].n);
+                for (uint64_t l = 0; l < W; ++l) if (g * W + l < N) p.index_map.push_back((uint32_t)(g * W + l));
+            }
+            p.owned_disp.resize(p.owned_n.size());
+            uint64_t off = 0;
+            for (size_t g = 0; g < p.owned_n.size(); ++g) { p.owned_disp[g] = (uint32_t)off; off += (uint64_t)p.owned_n[g] * W; }
+            p.ngroups = (uint32_t)p.owned_n.size();
+            p.nvalid = (uint32_t)p.index_map.size();
+            p.bytes = bytes;
+            // copy the groups together (the units are contiguous runs of the mapped cache)
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+            for (long g = 0; g < (long)p.ngroups; ++g) memcpy(p.owned_b.data() + p.owned_disp[g], groups[gl[k0 + g]].b, (size_t)p.owned_n[g] * W);
+            per_dev[d].push_back(std::move(p));
+        }
+    }
+    for (auto &v : per_dev) for (Piece &p : v) { p.b = p.owned_b.data(); p.n = p.owned_n.data(); p.disp = p.owned_disp.data(); }
+    return per_dev;
+}
+
 int do_search(Options &o)
 {
     if (o.execution_mode == 2) return do_search_host_only(o);
@@ -432,76 +528,95 @@ int do_search(Options &o)
     auto lap = [&](const char *what) { if (phases) { const double t = dwalltime(); fprintf(stderr, "[oswald] %-34s %8.3f ms\n", what, (t - tp) * 1e3); tp = t; } };
     oswald::Queries q = oswald::load_query_sequences(o.queries);
     lap("load queries");
-    oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, o.num_devices);
-    lap("load database + assemble chunks");
     const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength;
 
-    print_header(o, db);
+    // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80) -- and,
+    // like there, it adapts the maximum chunk size to the device's memory before the database is cut (utils.c:162-168)
+    oswald_hip_ctx *ctx = nullptr;
+    check(bring_up(o, &ctx), "device bring-up");
+    for (unsigned d = 0; d < o.num_devices; ++d) {
+        uint64_t fits = 0;
+        check(oswald_hip_max_chunk_size(ctx, (int)d, (uint32_t)nq, oswald::kMaxSequenceLength, &fits), "chunk size limit");
+        if (fits < o.max_chunk_size) o.max_chunk_size = fits;
+    }
+    lap("device bring-up");
 
-    if (db.sequences_count < o.top) o.top = db.sequences_count;
     // The report needs the top-r scores per query only.  For r <= 1024 they are selected on the devices, chunk by
-    // chunk, and merged by the library with the reference's tie rule (oswald_hip_topr; utils.c:3-86: equal scores ->
-    // later database index first); the full score table (the reference downloads and sorts it, FPGAsearch.c:232,
-    // :312-321) is only brought to the host for larger r.
+    // chunk, gathered over RCCL and folded on GPU 0 with the reference's tie rule (oswald_hip_topr; utils.c:3-86: equal
+    // scores -> later database index first); the full score table (the reference downloads and sorts it,
+    // FPGAsearch.c:232, :312-321) is only brought to the host for larger r, by the reference's chunk rule.
     const bool device_top = o.top <= 1024;
+    oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, device_top ? 1 : o.num_devices);
+    lap("load database + assemble chunks");
+    print_header(o, db);
+    if (db.sequences_count < o.top) o.top = db.sequences_count;
+    std::vector<std::vector<Piece>> pieces;
+    if (device_top) {
+        pieces = o.num_devices > 1 ? dealt_pieces(db, o.num_devices, o.max_chunk_size, std::max(o.cpu_threads, 1)) : contiguous_pieces(db);
+        lap("deal blocks to the devices");
+    }
     std::vector<int32_t> scores;
     if (!device_top) scores.assign(nq * db.vect_sequences_count * W, 0);
     std::vector<std::vector<int32_t>> tmp(o.num_devices);
-
-    // device bring-up is outside the timed region, like init() in the reference (main.c:46 vs FPGAsearch.c:80)
-    oswald_hip_ctx *ctx = nullptr;
-    check(bring_up(o, &ctx), "device bring-up");
     check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space"); // buffers sized before the clock starts, FPGAsearch.c:85-96
-    lap("device bring-up");
+    lap("device work space");
+
     const double tick = dwalltime();
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
-    if (device_top) check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");
-    // chunk c of a round goes to device c mod ndev (reference FPGAsearch.c:132-138)
-    std::vector<int> handle(o.num_devices, -1);
-    for (size_t k = 0; k < db.chunks.size(); k += o.num_devices) {
-        const size_t active = std::min<size_t>(o.num_devices, db.chunks.size() - k);
-        // uploads of the round's chunks are queued on all devices first (they overlap), then every device is
-        // given its search; the chunk's top list is selected on the device behind the search
-        if (device_top)
-            for (size_t d = 0; d < active; ++d) {
-                const oswald::Chunk &c = db.chunks[k + d];
-                check(oswald_hip_chunk_upload_async(ctx, (int)d, c.b, c.b_size, c.n.data(), c.disp.data(), (uint32_t)c.n.size(), (uint32_t)W,
-                                                    &handle[d]), "chunk upload");
-                const uint64_t first = c.accum * W, last = std::min<uint64_t>(db.sequences_count, (c.accum + c.n.size()) * W);
-                check(oswald_hip_chunk_set_index(ctx, (int)d, handle[d], (uint32_t)first, (uint32_t)(last - first), nullptr), "chunk index");
-            }
-        for (size_t d = 0; d < active; ++d) {
-            const oswald::Chunk &c = db.chunks[k + d];
-            if (device_top) {
-                check(oswald_hip_chunk_search(ctx, (int)d, handle[d], nullptr), "chunk search");
-            } else {
-                tmp[d].resize(nq * c.n.size() * W);
-                check(oswald_hip_search_chunk_async(ctx, (int)d, c.b, c.b_size, c.n.data(), c.disp.data(), (uint32_t)c.n.size(),
-                                                    (uint32_t)W, tmp[d].data()), "chunk search");
-            }
-        }
-        if (!device_top) check(oswald_hip_wait(ctx, -1), "wait");
-        for (size_t d = 0; d < active; ++d) {
-            const oswald::Chunk &c = db.chunks[k + d];
-            if (device_top) {
-                check(oswald_hip_chunk_release(ctx, (int)d, handle[d]), "chunk release"); // waits for the device: the host buffers of the round are free again
-            } else {
-                const size_t row = c.n.size() * W;
-                for (uint64_t qi = 0; qi < nq; ++qi)
-                    memcpy(scores.data() + (qi * db.vect_sequences_count + c.accum) * W, tmp[d].data() + qi * row, row * sizeof(int32_t));
-            }
-        }
-    }
-    // top lists of all queries (inside the timed region: they stand for the download of the score table)
     std::vector<std::vector<int32_t>> top_s(nq);
     std::vector<std::vector<uint64_t>> top_i(nq);
     if (device_top) {
+        check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");
+        // Round k = piece k of every device.  The uploads of a round are queued on all devices (they overlap), every
+        // device is given its search -- the piece's top list is selected and folded on the device behind it --, and
+        // the uploads of round k+1 are queued at once: they come in over the devices' upload streams while round k is
+        // being searched (the reference uploads and searches in turn, FPGAsearch.c:180-223).
+        size_t rounds = 0;
+        for (const auto &v : pieces) rounds = std::max(rounds, v.size());
+        std::vector<int> cur(o.num_devices, -1), nxt(o.num_devices, -1);
+        auto upload = [&](size_t k, std::vector<int> &h) {
+            for (unsigned d = 0; d < pieces.size(); ++d) {
+                h[d] = -1;
+                if (k >= pieces[d].size()) continue;
+                const Piece &p = pieces[d][k];
+                check(oswald_hip_chunk_upload_async(ctx, (int)d, p.b, p.bytes, p.n, p.disp, p.ngroups, (uint32_t)W, &h[d]), "chunk upload");
+                check(oswald_hip_chunk_set_index(ctx, (int)d, h[d], p.first_index, p.nvalid, p.index_map.empty() ? nullptr : p.index_map.data()), "chunk index");
+            }
+        };
+        upload(0, cur);
+        for (size_t k = 0; k < rounds; ++k) {
+            for (unsigned d = 0; d < pieces.size(); ++d)
+                if (cur[d] >= 0) check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search");
+            if (k + 1 < rounds) upload(k + 1, nxt);
+            for (unsigned d = 0; d < pieces.size(); ++d)
+                if (cur[d] >= 0) check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release"); // (the upload has landed; the device re-uses the slot when it is through with it)
+            cur.swap(nxt);
+        }
+        // top lists of all queries (inside the timed region: they stand for the download of the score table)
         std::vector<int32_t> ms(nq * o.top);
         std::vector<uint32_t> mi(nq * o.top);
         check(oswald_hip_topr(ctx, (uint32_t)o.top, ms.data(), mi.data()), "top scores");
         for (uint64_t i = 0; i < nq; ++i)
             for (uint64_t j = 0; j < o.top && ms[i * o.top + j] >= 0; ++j) { top_s[i].push_back(ms[i * o.top + j]); top_i[i].push_back(mi[i * o.top + j]); }
+    } else {
+        // chunk c of a round goes to device c mod ndev (reference FPGAsearch.c:132-138)
+        for (size_t k = 0; k < db.chunks.size(); k += o.num_devices) {
+            const size_t active = std::min<size_t>(o.num_devices, db.chunks.size() - k);
+            for (size_t d = 0; d < active; ++d) {
+                const oswald::Chunk &c = db.chunks[k + d];
+                tmp[d].resize(nq * c.n.size() * W);
+                check(oswald_hip_search_chunk_async(ctx, (int)d, c.b, c.b_size, c.n.data(), c.disp.data(), (uint32_t)c.n.size(),
+                                                    (uint32_t)W, tmp[d].data()), "chunk search");
+            }
+            check(oswald_hip_wait(ctx, -1), "wait");
+            for (size_t d = 0; d < active; ++d) {
+                const oswald::Chunk &c = db.chunks[k + d];
+                const size_t row = c.n.size() * W;
+                for (uint64_t qi = 0; qi < nq; ++qi)
+                    memcpy(scores.data() + (qi * db.vect_sequences_count + c.accum) * W, tmp[d].data() + qi * row, row * sizeof(int32_t));
+            }
+        }
     }
     const double workTime = dwalltime() - tick;
     lap("search (timed region)");

@@ -23,9 +23,32 @@ ordering rule is the reference's (descending score, ties by descending index,
 host/src/utils.c:3-86)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import dblayout
+
+
+def init_collective(backend: str, device=None):
+    """torch.distributed bring-up of a rank (RANK / WORLD_SIZE / MASTER_* from the environment): "nccl" = RCCL, one
+    rank per GPU; "gloo" = the rehearsal mode the caller asked for by name (ranks sharing a GPU, or no GPU at all).
+    There is NO fallback from one to the other: a failed RCCL bring-up ends the rank with a non-zero exit code and the
+    reason (the launcher then takes the other ranks down), so a scaling line can never quietly stop being RCCL
+    evidence, and no rank can end up in a rendezvous the others are not in.  Returns torch.distributed."""
+    import torch.distributed as dist
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"unknown collective backend {backend!r} (nccl = RCCL, or gloo)")
+    try:
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
+    except Exception as e:  # noqa: BLE001 -- whatever the bring-up raised: say so and leave; never switch backends
+        raise SystemExit(f"collective bring-up failed on rank {os.environ.get('RANK', '?')} with backend {backend} "
+                         f"({type(e).__name__}: {str(e)[:300]}); no other backend is tried -- ask for one by name "
+                         "(OSWALD_BENCH_BACKEND=gloo) if a rehearsal without RCCL is what you want")
+    return dist
 
 
 def rank_chunks(n_groups_len, W: int, max_chunk_size: int, world: int, rank: int):

