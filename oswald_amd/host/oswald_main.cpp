@@ -534,12 +534,13 @@ int do_search(Options &o)
     // like there, it adapts the maximum chunk size to the device's memory before the database is cut (utils.c:162-168)
     oswald_hip_ctx *ctx = nullptr;
     check(bring_up(o, &ctx), "device bring-up");
+    lap("device bring-up");
     for (unsigned d = 0; d < o.num_devices; ++d) {
         uint64_t fits = 0;
         check(oswald_hip_max_chunk_size(ctx, (int)d, (uint32_t)nq, oswald::kMaxSequenceLength, &fits), "chunk size limit");
         if (fits < o.max_chunk_size) o.max_chunk_size = fits;
     }
-    lap("device bring-up");
+    lap("chunk size limit");
 
     // The report needs the top-r scores per query only.  For r <= 1024 they are selected on the devices, chunk by
     // chunk, gathered over RCCL and folded on GPU 0 with the reference's tie rule (oswald_hip_topr; utils.c:3-86: equal
