@@ -369,11 +369,14 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
                                          ctx->extend_gap, (uint2 *)d.prof_alt.p, d.stream));
     }
     // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
-    // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern).  Uploaded on the
+    // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern), then the 8-bit cell's page.  Uploaded on the
     // device's stream like everything else here (ordered behind a search still in flight).
     std::vector<uint32_t> &pages = d.top_pages_host; // a member: an early return must not free the source of a queued copy
-    pages.assign((128 + OSW_I16S_TABLE) * 2, 0u);
+    pages.assign((128 + OSW_I16S_TABLE + 64) * 2, 0u);
     for (size_t i = 64; i < 128; ++i) pages[2 * i] = pages[2 * i + 1] = 0x04000400u;
+    // ... and behind the table 64 entries of the 8-bit cell's "zero": its offset c in every byte (q8_cell.h)
+    if (first_pass_is_q8(ctx))
+        for (size_t i = 128 + OSW_I16S_TABLE; i < 128 + OSW_I16S_TABLE + 64; ++i) pages[2 * i] = pages[2 * i + 1] = (uint32_t)offset8_of(ctx) * 0x01010101u;
     for (size_t k = 0; k < OSW_I16S_TABLE; ++k) {
         const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
         pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);

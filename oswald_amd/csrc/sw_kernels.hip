@@ -580,6 +580,7 @@ struct CellI32 {
 };
 
 // The 8-bit cell of cell_bits = 8 (SWAR: four 7-bit cells per register, offset domain): q8_cell.h.
+#include <type_traits>
 #include "q8_cell.h"
 
 static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
@@ -744,6 +745,118 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", OSW_INFLIGHT);
 }
 
+// ---------------------------------------------------------------------------
+// The same round for the hand-scheduled 8-bit cell (CellQ8F, q8_cell.h): identical step structure -- 2 stores + 3
+// loads per step through fixed registers, hand-counted waits -- on the register set v72..v79 that six waves per SIMD
+// leave room for.  H and F travel between steps / lane groups / rounds as 7-bit offset values ("zero" = the offset c
+// in every byte); a first round reads its row above from the constant page of that value (top_pages, behind the
+// column-frame cell's floor table).
+// ---------------------------------------------------------------------------
+#define OSW8_STEP_BEGIN_ASM(LFP)                                                                             \
+    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\t"                                                         \
+                 "v_cndmask_b32 " OSW8_VF ", " OSW8_VF ", " LFP ", %[mg0]"                                   \
+                 :                                                                                           \
+                 : [mg0] "s"(m_g0)                                                                           \
+                 : "memory", OSW8_INFLIGHT)
+
+#define OSW8_STEP_END_ASM(CP, LHP, LFP)                                                                      \
+    asm volatile("v_cndmask_b32 %[tp], " OSW8_VH ", " LHP ", %[mg0]\n\t"                                      \
+                 "s_mov_b64 %[sv], exec\n\t"                                                                 \
+                 "s_mov_b64 exec, %[mst]\n\t"                                                                \
+                 "global_store_dword %[voff], %[ho], %[sptr]\n\t"                                            \
+                 "global_store_dword %[voff], " OSW8_VF ", %[sptr] offset:4\n\t"                             \
+                 "s_not_b64 exec, %[mg0]\n\t"                                                                \
+                 "s_cbranch_execz 1f\n\t"                                                                    \
+                 "s_mov_b64 exec, %[sv]\n\t"                                                                 \
+                 "ds_bpermute_b32 " OSW8_VH ", %[src], %[ho]\n\t"                                            \
+                 "ds_bpermute_b32 " OSW8_VF ", %[src], " OSW8_VF "\n"                                         \
+                 "1:\n\t"                                                                                    \
+                 "s_mov_b64 exec, %[mg0]\n\t"                                                                \
+                 "global_load_dword " LHP ", %[voffl], %[lptr]\n\t"                                          \
+                 "global_load_dword " LFP ", %[voffl], %[lptr] offset:4\n\t"                                 \
+                 "s_mov_b64 exec, %[sv]\n\t"                                                                 \
+                 "global_load_ushort " CP ", %[voffc], %[tptr]"                                              \
+                 : [tp] "=&v"(tp), [sv] "=&s"(sv)                                                            \
+                 : [src] "v"(src), [ho] "v"(ho), [voff] "v"(voff), [voffl] "v"(voffl), [voffc] "v"(voffc), [mst] "s"(m_st), \
+                   [mg0] "s"(m_g0), [sptr] "s"(sptr), [lptr] "s"(lptr), [tptr] "s"(tptr)                      \
+                 : "memory", "scc", OSW8_INFLIGHT)
+
+template <int R>
+static __device__ __forceinline__ void sw_round_q8f(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
+                                                    const uint2 *top_pages, bool first, bool last, uint32_t G, uint32_t gl, int lane,
+                                                    const CellQ8::GapT &gp, uint32_t &score)
+{
+    typedef CellQ8F C;
+    const uint64_t m_g0 = gl >= 64 ? ~0ull : (1ull << gl) - 1ull; // lanes of group 0
+    const uint64_t m_st = ~0ull << (64u - gl);                     // lanes of the last group
+    const uint32_t src = (uint32_t)((lane - (int)gl) & 63) << 2;   // ds_bpermute source: the lane one group below
+    const uint32_t g = (uint32_t)lane / gl;
+    const uint32_t zb = C::zero_bits(gp);
+    const uint32_t voff = u * 8u, voffc = u * 2u + (G - 1u - g) * 128u;
+    const uint64_t data = (uint64_t)(bnd + OSW_SCRATCH_DATA);
+    const uint32_t sstep = last ? 0u : gl * 8u;
+    const uint32_t lstep = first ? 0u : gl * 8u;
+    const uint32_t voffl = first ? 0u : voff;
+    uint64_t lptr = first ? (uint64_t)(top_pages + 128 + OSW_I16S_TABLE) : data;
+    uint64_t sptr = last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u;
+    uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * 128u;
+    uint64_t sv;
+    asm volatile("v_mov_b32 " OSW8_VH ", %[fl]\n\t"
+                 "v_mov_b32 " OSW8_VF ", %[fl]\n\t"
+                 "global_load_ushort " OSW8_VC0 ", %[voffc], %[tptr]\n\t"
+                 "global_load_ushort " OSW8_VC1 ", %[voffc], %[tptr] offset:128\n\t"
+                 "s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[mg0]\n\t"
+                 "global_load_dword " OSW8_VLH0 ", %[voffl], %[lptr]\n\t"
+                 "global_load_dword " OSW8_VLF0 ", %[voffl], %[lptr] offset:4\n\t"
+                 "global_load_dword " OSW8_VLH1 ", %[voffl], %[lptr2]\n\t"
+                 "global_load_dword " OSW8_VLF1 ", %[voffl], %[lptr2] offset:4\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : [sv] "=&s"(sv)
+                 : [voffl] "v"(voffl), [voffc] "v"(voffc), [mg0] "s"(m_g0), [lptr] "s"(lptr), [lptr2] "s"(lptr + lstep), [tptr] "s"(tptr),
+                   [fl] "v"(zb)
+                 : "memory", OSW8_INFLIGHT);
+    lptr += 2 * lstep;
+    tptr += 256;
+    const uint32_t nsteps = ncols + G - 1;
+    // the strip's state is set up HERE, from values that come out of an asm statement ordered behind the prologue's:
+    // set up earlier, its 2R registers would be live across the prologue and spilled around it
+    uint32_t cg = gp.cG, d0 = zb - gp.bias;
+    asm volatile("" : "+v"(cg), "+v"(d0) : : OSW8_INFLIGHT);
+    uint32_t D[R], E[R], top_prev = zb;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { D[r] = d0; E[r] = cg; }
+    uint32_t sc = (score & gp.L) | gp.G, fl = score; // running score with its guard; the sticky flags of earlier rounds ride in fl
+#pragma unroll 1
+    for (uint32_t t = 0; t < nsteps; t += 2) {
+        {
+            OSW8_STEP_BEGIN_ASM(OSW8_VLF0);
+            uint32_t hl, tp;
+            C::template column<R, 0>(base, D, E, top_prev, hl, gp, sc, fl);
+            const uint32_t ho = hl;
+            OSW8_STEP_END_ASM(OSW8_VC0, OSW8_VLH0, OSW8_VLF0);
+            top_prev = tp;
+            sptr += sstep;
+            lptr += lstep;
+            tptr += 128;
+        }
+        if (t + 1 < nsteps) {
+            OSW8_STEP_BEGIN_ASM(OSW8_VLF1);
+            uint32_t hl, tp;
+            C::template column<R, 1>(base, D, E, top_prev, hl, gp, sc, fl);
+            const uint32_t ho = hl;
+            OSW8_STEP_END_ASM(OSW8_VC1, OSW8_VLH1, OSW8_VLF1);
+            top_prev = tp;
+            sptr += sstep;
+            lptr += lstep;
+            tptr += 128;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", OSW8_INFLIGHT);
+    score = (sc & gp.L) | (fl & gp.G);
+}
+
 // Compiler-scheduled version of the same round (int32 cell).
 template <class C, int R>
 static __device__ __forceinline__ void sw_round_plain(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
@@ -789,7 +902,8 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
 {
 #define OSW_ROUND_CASE(RR)                                                                                                      \
     case RR:                                                                                                                    \
-        if constexpr (C::kFast) sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score); \
+        if constexpr (std::is_same<C, CellQ8F>::value) sw_round_q8f<RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, goe, score); \
+        else if constexpr (C::kFast) sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score); \
         else sw_round_plain<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);                  \
         break
     switch (R) {
@@ -887,12 +1001,13 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         uint2 *pad = bnd + OSW_SCRATCH_DATA + (size_t)ncols * gl;
         for (uint32_t k = lane; k < (G + 2u) * gl; k += 64) {
             uint32_t z = C::kFloorBits;
+            if constexpr (std::is_same<C, CellQ8F>::value) z = C::zero_bits(goe); // the 8-bit cell's "zero" is its offset c in every byte
             if constexpr (C::kShifted) z += (ncols + k / gl + G) * (uint32_t)ge; // zero in the frame of that column
             pad[k] = make_uint2(z, z);
         }
     }
     T score;
-    if constexpr (!C::kFast) score = C::score_init(goe);   // compiler-scheduled cells: "zero" may depend on the scoring system (8-bit cell)
+    if constexpr (!C::kFast || std::is_same<C, CellQ8F>::value) score = C::score_init(goe);   // "zero" may depend on the scoring system (8-bit cell)
     else if constexpr (C::kShifted) score = C::from_bits(0u); // the column-frame cell keeps a true (unbiased) running score
     else score = C::zero();
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
@@ -1151,7 +1266,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
 // for the int32 kernel.  The four lanes combine their flags (homologous sequences sit next to each other in a sorted
 // database and usually flag together) and the first one queues the entry once.
 // ---------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) void osw_sw_q8(OswSearchArgs p)
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) OSW8_COMPILER_VGPRS void osw_sw_q8(OswSearchArgs p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS8 * 8 + OSW_LDS_SKEW_Q8];
     const int lane = threadIdx.x & 63;
@@ -1170,7 +1285,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) void osw_sw_q8(OswSea
         const uint32_t pair = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
         const OswBlock blk = p.blocks[B];
         const uint32_t gl = 64u >> lg;
-        const uint32_t score = run_item<CellQ8>(p, p.prof, pair, B, blk, sigma, lg, lane, 0, false, lds_prof[wv], bnd_wave, gp, gp);
+        const uint32_t score = run_item<CellQ8F>(p, p.prof, pair, B, blk, sigma, lg, lane, 0, false, lds_prof[wv], bnd_wave, gp, gp);
         const bool mine = (uint32_t)lane < gl;            // the lanes of group 0 hold the sub-block's scores
         uint32_t flags = mine ? score & 0x80808080u : 0u; // which of the lane's four (query, sequence) left the range
         // a re-run entry covers an aligned quad of lanes (eight sequences): combine the quad's flags

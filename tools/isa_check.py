@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""tools/isa_check.py -- ISA check of the packed-int16 kernels and the stamp that ties the shipped library to it.
+"""tools/isa_check.py -- ISA check of the hand-scheduled DP kernels and the stamp that ties the shipped library to it.
 
-The column loop of osw_sw_pk16 / osw_sw_pk16q / osw_sw_s16 / osw_sw_s16q loads straight into fixed physical registers
-from inline asm, two columns ahead (sw_kernels.hip, "Input registers of a column step").  The compiler does not know
+The column loop of osw_sw_pk16 / osw_sw_pk16q / osw_sw_s16 / osw_sw_s16q and (round 4) of the 8-bit kernel osw_sw_q8
+loads straight into fixed physical registers from inline asm, two columns ahead (sw_kernels.hip, "Input registers of a
+column step"; q8_cell.h for the 8-bit kernel's set).  The compiler does not know
 about those loads, so the design rests on it never touching these registers itself, on there being no scratch spills
 and on no compiler-issued vector-memory operation inside the loops that contain the asm loads (their waits are counted
 by hand).  check() compiles the kernels to assembly with the hipcc at hand and verifies exactly that
@@ -26,8 +27,18 @@ CSRC = os.path.join(ROOT, "oswald_amd", "csrc")
 SRC = os.path.join(CSRC, "sw_kernels.hip")
 LIB = os.path.join(ROOT, "oswald_amd", "liboswald_hip.so")
 STAMP = os.path.join(ROOT, "oswald_amd", "liboswald_hip.isa.json")
-KERNELS = ("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q")
-VGPR_BUDGET = 168  # three waves per SIMD (launch bounds of the packed-int16 kernels; the compiler gets 160, the asm 8 more)
+# kernel groups: their fixed in-flight registers (the #define that lists them, and the file it is in), the register
+# budget of their launch bounds, and the scratch bytes per lane tolerated OUTSIDE the column loops (loop-invariant state
+# parked before a round; inside the loops check_vmem_windows allows none)
+GROUPS = (
+    dict(kernels=("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q"), define="OSW_INFLIGHT", file="sw_kernels.hip",
+         budget=168,   # three waves per SIMD; the compiler gets 160, the asm 8 more
+         scratch=32, min_asm_uses=1000),
+    dict(kernels=("osw_sw_q8",), define="OSW8_INFLIGHT", file="q8_cell.h",
+         budget=80,    # six waves per SIMD; the compiler gets 72, the asm 8 more
+         scratch=0, min_asm_uses=100),
+)
+KERNELS = tuple(k for g in GROUPS for k in g["kernels"])
 SOURCES = ("sw_kernels.hip", "sw_kernels.h", "q8_cell.h", "oswald_hip.cpp")
 
 
@@ -36,18 +47,19 @@ def hipcc_path():
     return p if os.path.exists(p) else None
 
 
-def reserved_registers():
-    m = re.search(r'#define OSW_INFLIGHT (.*)', open(SRC).read())
+def reserved_registers(group=GROUPS[0]):
+    m = re.search(r'#define %s (.*)' % group["define"], open(os.path.join(CSRC, group["file"])).read())
     regs = [int(x) for x in re.findall(r'"v(\d+)"', m.group(1))]
     assert len(regs) == 8
     return set(regs)
 
 
 def compile_to_asm():
+    """The kernels' assembly, compiled by the library's own Makefile (`make asm`: same compiler, same flags as the
+    shipped liboswald_hip.so, so that what is checked is what is shipped)."""
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "sw_kernels.s")
-        subprocess.check_call([hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-I" + os.path.join(ROOT, "include"),
-                               "-I" + CSRC, "-o", out, SRC], stderr=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-s", "-C", CSRC, "asm", "ASM_OUT=" + out, "HIPCC=" + hipcc_path()], stderr=subprocess.DEVNULL)
         return open(out).read().split("\n")
 
 
@@ -61,9 +73,10 @@ def _touches(code, reserved):
     return False
 
 
-def check_inflight_registers(isa):
+def check_inflight_registers(isa, group=GROUPS[0]):
     """-> (instructions of the asm blocks that use the fixed registers, [(line, code)] of compiler-scheduled ones that do)"""
-    reserved = reserved_registers()
+    reserved = reserved_registers(group)
+    KERNELS = group["kernels"]
     fn, inasm, bad, seen_asm_use = None, False, [], 0
     for i, line in enumerate(isa):
         m = re.match(r'^(osw_\w+):', line)
@@ -88,24 +101,26 @@ def check_inflight_registers(isa):
     return seen_asm_use, bad
 
 
-def check_register_budget(isa):
-    """The kernels' launch bounds ask for VGPR_BUDGET registers at most (waves per SIMD = 512 / budget); a spill of a
-    loop-invariant value outside the column loops is tolerated (a few bytes), spill traffic inside them is ruled out by
-    check_vmem_windows.  -> list of complaints"""
+def check_register_budget(isa, group=GROUPS[0]):
+    """The kernels' launch bounds ask for group["budget"] registers at most (waves per SIMD = 512 / budget); a spill of
+    loop-invariant values outside the column loops is tolerated (group["scratch"] bytes), spill traffic inside them is
+    ruled out by check_vmem_windows.  -> list of complaints"""
     text, bad = "\n".join(isa), []
-    for k in KERNELS:
+    VGPR_BUDGET = group["budget"]
+    for k in group["kernels"]:
         m = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)' % k, text)
         m2 = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)' % k, text)
         if not m or int(m.group(1)) > VGPR_BUDGET:
             bad.append("%s needs more than %d VGPRs" % (k, VGPR_BUDGET))
-        if not m2 or int(m2.group(1)) > 32:
+        if not m2 or int(m2.group(1)) > group["scratch"]:
             bad.append("%s spills %s bytes per lane" % (k, m2.group(1) if m2 else "?"))
     return bad
 
 
-def check_vmem_windows(isa):
+def check_vmem_windows(isa, group=GROUPS[0]):
     """Inside the column loops (between the prologue's asm loads and the final `s_waitcnt vmcnt(0)` of a round) every
     vector-memory instruction must come from the asm blocks: a compiler-issued one would shift the hand-counted waits."""
+    KERNELS = group["kernels"]
     fn, inasm, window, bad = None, False, False, []
     for i, line in enumerate(isa):
         m = re.match(r'^(osw_\w+):', line)
@@ -132,13 +147,14 @@ def check_vmem_windows(isa):
 def check(isa=None):
     """All three checks; raises AssertionError with the findings."""
     isa = isa or compile_to_asm()
-    seen, bad = check_inflight_registers(isa)
-    assert seen > 1000, "the asm blocks that use the fixed registers were not found"
-    assert not bad, "compiler-scheduled instructions touch in-flight registers: %r" % bad[:8]
-    budget = check_register_budget(isa)
-    assert not budget, "; ".join(budget)
-    vm = check_vmem_windows(isa)
-    assert not vm, "compiler-issued vector memory inside an asm load window: %r" % vm[:8]
+    for group in GROUPS:
+        seen, bad = check_inflight_registers(isa, group)
+        assert seen > group["min_asm_uses"], "%s: the asm blocks that use the fixed registers were not found" % (group["kernels"],)
+        assert not bad, "compiler-scheduled instructions touch in-flight registers: %r" % bad[:8]
+        budget = check_register_budget(isa, group)
+        assert not budget, "; ".join(budget)
+        vm = check_vmem_windows(isa, group)
+        assert not vm, "compiler-issued vector memory inside an asm load window: %r" % vm[:8]
     return isa
 
 
@@ -165,7 +181,9 @@ def stamp():
     subprocess.check_call(["make", "-s", "-C", CSRC])
     ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout.strip().split("\n")
     info = {"library_sha256": sha256_file(LIB), "source_digest": source_digest(), "hipcc": ver[0] if ver else "", "kernels": list(KERNELS),
-            "checks": ["in-flight registers untouched by compiler-scheduled code", "<= %d VGPRs, <= 32 B of scratch" % VGPR_BUDGET, "no compiler-issued vector memory inside the asm load windows"]}
+            "checks": ["in-flight registers untouched by compiler-scheduled code",
+                       "; ".join("%s: <= %d VGPRs, <= %d B of scratch outside the column loops" % ("/".join(g["kernels"]), g["budget"], g["scratch"]) for g in GROUPS),
+                       "no compiler-issued vector memory (spill traffic included) inside the asm load windows"]}
     with open(STAMP, "w") as f:
         json.dump(info, f, indent=1)
     return info

@@ -106,6 +106,38 @@ __global__ __launch_bounds__(256) void cell_probe(unsigned long long *out, uint3
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (acc == 0x12345678u);
 }
 
+// the hand-scheduled cell (CellQ8F::column<OSW_RMAX8, 0>) on the same made-up profile: residues and F in the fixed registers
+__global__ __launch_bounds__(256) OSW8_COMPILER_VGPRS void cell_probe_f(unsigned long long *out, uint32_t go, uint32_t ge, uint32_t bias, uint32_t codes0, int iters)
+{
+    extern __shared__ uint32_t lds[];
+    for (int i = threadIdx.x; i < 4 * 32 * 2 * 4; i += 256) lds[i] = 0x04030201u * ((i * 7) & 7) + 0x01010101u * bias;
+    __syncthreads();
+    const CellQ8::GapT g = CellQ8::make_gap(go, ge, bias, go + ge > bias ? go + ge : bias);
+    uint32_t D[OSW_RMAX8], E[OSW_RMAX8], top_prev, hl = 0;
+    CellQ8::init_state<OSW_RMAX8>(D, E, top_prev, g);
+    uint32_t sc = CellQ8::score_init(g) | g.G, fl = 0;
+    const uint32_t codes = (codes0 + threadIdx.x * 8) & 0xf8f8u, zb = CellQ8::zero_bits(g);
+    asm volatile("v_mov_b32 " OSW8_VC0 ", %0\n\tv_mov_b32 " OSW8_VF ", %1" : : "v"(codes), "v"(zb) : OSW8_INFLIGHT);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        CellQ8F::column<OSW_RMAX8, 0>(0u, D, E, top_prev, hl, g, sc, fl);
+        top_prev = hl;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t acc = sc ^ fl ^ hl;
+#pragma unroll
+    for (int i = 0; i < OSW_RMAX8; ++i) acc ^= D[i] ^ E[i];
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (acc == 0x12345678u);
+}
+
+// v_bitop3_b32 bitop3:0xe4 is the byte select of the hand-scheduled cell: (a & k) | (b & ~k)
+__global__ void bitop3_selfcheck(uint32_t *out, uint32_t a, uint32_t b, uint32_t k)
+{
+    uint32_t r;
+    asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(r) : "v"(a), "v"(b), "v"(k));
+    out[threadIdx.x] = r;
+}
+
 template <class L>
 static double slowest(L launch, int nb, unsigned long long *o)
 {
@@ -169,5 +201,16 @@ int main()
     printf("the 8-bit cell (q8_cell.h), cycles per query row of a 2 x 2 tile (= per 256 cells of a wave) per SIMD:\n");
     sweep("  CellQ8::column<OSW_RMAX8>, PAM250 14/2 (bias 8)", cell_probe, (double)OSW_RMAX8, iters / 8, cus, o, 14u, 2u, 8u, 0x1830u);
     sweep("  CellQ8::column<OSW_RMAX8>, BLOSUM62 10/2 (bias 4)", cell_probe, (double)OSW_RMAX8, iters / 8, cus, o, 10u, 2u, 4u, 0x1830u);
+    printf("the hand-scheduled cell (CellQ8F: 39 instructions + 1 v_perm_b32 per row, selects by v_bitop3_b32), same units:\n");
+    sweep("  CellQ8F::column<OSW_RMAX8>, PAM250 14/2 (bias 8)", cell_probe_f, (double)OSW_RMAX8, iters / 8, cus, o, 14u, 2u, 8u, 0x1830u);
+    sweep("  CellQ8F::column<OSW_RMAX8>, BLOSUM62 10/2 (bias 4)", cell_probe_f, (double)OSW_RMAX8, iters / 8, cus, o, 10u, 2u, 4u, 0x1830u);
+    {
+        uint32_t *chk, h[1];
+        (void)hipMalloc(&chk, 256);
+        hipLaunchKernelGGL(bitop3_selfcheck, dim3(1), dim3(1), 0, 0, chk, 0xA1B2C3D4u, 0x11223344u, 0x7f007f00u);
+        (void)hipMemcpy(h, chk, 4, hipMemcpyDeviceToHost);
+        const uint32_t want = (0xA1B2C3D4u & 0x7f007f00u) | (0x11223344u & ~0x7f007f00u);
+        printf("v_bitop3_b32 bitop3:0xe4 (a=0xA1B2C3D4, b=0x11223344, k=0x7f007f00) = 0x%08x, select wants 0x%08x: %s\n", h[0], want, h[0] == want ? "ok" : "MISMATCH");
+    }
     return 0;
 }
