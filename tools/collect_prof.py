@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""tools/collect_prof.py ROUND WORKLOAD NSEQ [LABEL] -- copy what tools/profile_gpu.sh left under gpurun_out/prof_<workload>/
-(scratch) into profiles/ (tracked): r<ROUND>_<label>_summary.json, ..._kernel_stats.csv, ..._domain_stats.csv and
-traffic_<workload>_<nseq>.json (the file bench.py reads for roofline.traffic)."""
+"""tools/collect_prof.py ROUND WORKLOAD NSEQ [LABEL [PROF_LABEL]] -- copy what tools/profile_gpu.sh left under
+gpurun_out/prof_<workload>_<nseq>[_<prof_label>]/ (scratch) into profiles/ (tracked): r<ROUND>_<label>_summary.json,
+..._kernel_stats.csv, ..._domain_stats.csv and traffic_<workload>_<nseq>.json (the file bench.py reads for
+roofline.traffic).  Refuses a summary whose kernel trace and bench line do not describe the same run (the trace's span of
+a chunk search must be within 3 % of the kernel time bench.py measured with HIP events in that run)."""
 import glob, json, os, shutil, sys
 
 rnd, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
 label = sys.argv[4] if len(sys.argv) > 4 else wl
+plabel = sys.argv[5] if len(sys.argv) > 5 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{wl}")
+src = os.path.join(root, "gpurun_out", f"prof_{wl}_{nseq}" + (f"_{plabel}" if plabel else ""))
 dst = os.path.join(root, "profiles")
 text = open(os.path.join(src, "summary.txt")).read()
 summary = json.loads(text[text.index("{"):])
+c = summary.get("consistency")
+if not c or not c.get("ok"):
+    sys.exit(f"collect_prof: {src}: kernel trace and bench line disagree or are missing ({c}); not collected")
 with open(os.path.join(dst, f"r{rnd}_{label}_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
@@ -20,6 +26,6 @@ if stats:
     if os.path.exists(dom):
         shutil.copy(dom, os.path.join(dst, f"r{rnd}_{label}_domain_stats.csv"))
 t = os.path.join(src, f"traffic_{wl}_{nseq}.json")
-if os.path.exists(t):
+if os.path.exists(t) and not plabel:   # (a labelled run -- other cells, other flags -- is not what bench.py's default line reports)
     shutil.copy(t, os.path.join(dst, f"traffic_{wl}_{nseq}.json"))
-print("collected", label, "->", dst)
+print("collected", label, "->", dst, "| trace vs bench kernel time: %+.2f %%" % (100 * c["relative_difference"]))

@@ -9,7 +9,10 @@ set -e -o pipefail
 WL=${1:-c2}
 NSEQ=${2:-100000}
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_${WL}
+# one directory per (workload, database size, extra label), emptied first: two runs can never share raw files
+# (round 3 keyed it by workload only; the C2 summaries at 100 000 and 1 000 000 sequences then mixed their traces)
+OUT=$REPO/gpurun_out/prof_${WL}_${NSEQ}${PROF_LABEL:+_$PROF_LABEL}
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --workload $WL --nseq $NSEQ --cpu-seconds 0 ${BENCH_EXTRA:-}"  # e.g. BENCH_EXTRA="--cell-bits 11"

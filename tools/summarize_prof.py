@@ -21,8 +21,21 @@ KERNELS = DP + ("osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw
 
 
 def find(sub, pattern):
-    r = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
-    return r[0] if r else None
+    r = sorted(glob.glob(os.path.join(out, sub, "**", pattern), recursive=True), key=os.path.getmtime)
+    if len(r) > 1:
+        print(f"summarize_prof: {len(r)} files match {sub}/{pattern}; taking the newest", file=sys.stderr)
+    return r[-1] if r else None
+
+
+def bench_line(sub):
+    """the JSON line bench.py printed in that pass (its stdout is in <sub>.log)"""
+    try:
+        for line in open(os.path.join(out, sub + ".log")):
+            if line.startswith("{") and '"metric"' in line:
+                return json.loads(line)
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 summary = {"workload": wl, "nseq": int(nseq)}
@@ -86,6 +99,16 @@ def calib(sub, counter, kernel):
     return tot or None
 
 
+# cross-check: the trace's span of one chunk search against the kernel time bench.py measured with
+# HIP events IN THE SAME RUN (the JSON line in stats.log); more than 3 % apart = the summary mixes runs, or a kernel is
+# missing from the DP list above
+b = bench_line("stats")
+if b and "dp_step_span" in summary:
+    kms = b["roofline"]["kernel_ms"]
+    rel = summary["dp_step_span"]["avg_ms"] / kms - 1.0 if kms else None
+    summary["consistency"] = {"bench_kernel_ms": kms, "bench_launches_per_step": b["roofline"].get("launches_per_step"), "bench_gcups": b["value"],
+                              "trace_step_span_ms": summary["dp_step_span"]["avg_ms"], "relative_difference": rel,
+                              "ok": rel is not None and abs(rel) <= 0.03}
 summary["pmc_fetch"] = pmc("fetch")
 summary["pmc_write"] = pmc("write")
 summary["pmc_sq"] = pmc("sq")
