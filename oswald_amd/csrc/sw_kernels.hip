@@ -1382,6 +1382,66 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__re
     }
 }
 
+// The same for the reference's own layout, W = 16 (round 4): vectorised, and with the live extents computed on the way
+// (below: osw_block_extent walks every lane back from the end of the block with dependent loads -- 0.86 ms for a
+// 100 000-sequence chunk, twice the time of the re-tile itself and half of a single-query search).  A thread takes
+// one COLUMN of one 16-sequence group: 16 residues = one 16-byte load, 8 lanes x {8 * code, 8 * code} = one 16-byte
+// store (the byte order of a group's column IS the lane order of the block's row); threads of a wave cover 32
+// consecutive columns of two neighbouring groups, so loads run over 512 contiguous bytes and stores fill whole
+// 32-byte sectors.  Every thread keeps, for the 8 lanes of its group, the last column with a real residue; the
+// workgroup combines them in LDS and writes sub_cols / blocks[B].ncols4 exactly as osw_block_extent does.
+extern "C" __global__ __launch_bounds__(256) void osw_retile16(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
+                                                                const uint32_t *__restrict__ disp, uint32_t ngroups,
+                                                                OswBlock *__restrict__ blocks, uint16_t *__restrict__ tiled, uint16_t *__restrict__ sub_cols)
+{
+    __shared__ uint32_t lane_n[64];
+    const uint32_t B = blockIdx.x, t = threadIdx.x;
+    const OswBlock blk = blocks[B];
+    if (t < 64) lane_n[t] = 0;
+    __syncthreads();
+    const uint32_t gi = t >> 5, jl = t & 31;      // group of the block (0..7), column inside a run of 32
+    const uint32_t g = B * 8 + gi;
+    const bool have = g < ngroups;
+    const uint32_t ng = have ? n[g] : 0;
+    const uint8_t *src = b + (have ? disp[g] : 0);
+    const uint32_t ncols = blk.ncols4_alloc * 4;
+    const bool aligned = (((uintptr_t)src) & 15u) == 0; // (the caller's buffer and displacements are multiples of 16 in the reference's layout; anything else takes byte loads)
+    uint4 *dst = (uint4 *)(tiled + (size_t)blk.col4_off * 4 * 64) + gi;    // + j * 8: row j is 128 B = 8 x 16 B
+    uint32_t last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t D4 = 0x17171717u;              // four dummy residues (code 23)
+    for (uint32_t j = jl; j < ncols; j += 32) {
+        uint4 v = make_uint4(D4, D4, D4, D4);
+        if (j < ng) {
+            if (aligned) v = *(const uint4 *)(src + (size_t)j * 16);
+            else {
+                const uint8_t *q = src + (size_t)j * 16;
+                uint32_t w[4];
+                for (int k = 0; k < 4; ++k) w[k] = (uint32_t)q[4 * k] | ((uint32_t)q[4 * k + 1] << 8) | ((uint32_t)q[4 * k + 2] << 16) | ((uint32_t)q[4 * k + 3] << 24);
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // word k = lanes 2k, 2k+1 of the group (two residues each)
+            if ((w[k] & 0xffffu) != 0x1717u) last[2 * k] = j + 1;
+            if ((w[k] >> 16) != 0x1717u) last[2 * k + 1] = j + 1;
+        }
+        // codes >= 32 cannot come from the reference's preprocessing (0..23); keep the offset inside the entry row
+        dst[(size_t)j * 8] = make_uint4((v.x & 0x1f1f1f1fu) << 3, (v.y & 0x1f1f1f1fu) << 3, (v.z & 0x1f1f1f1fu) << 3, (v.w & 0x1f1f1f1fu) << 3);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (last[k]) atomicMax(&lane_n[gi * 8 + k], last[k]);
+    __syncthreads();
+    if (t < 127) {
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(t + 1u), sigma = t + 1u - (1u << lg), gl = 64u >> lg;
+        uint32_t mx = 0;
+        for (uint32_t k = 0; k < gl; ++k) mx = lane_n[sigma * gl + k] > mx ? lane_n[sigma * gl + k] : mx;
+        sub_cols[(size_t)B * 128 + t] = (uint16_t)mx;
+        if (t == 0) blocks[B].ncols4 = (mx + 3) / 4;
+    }
+}
+
 // Live extents.  Columns past a sequence's end hold the dummy residue, which scores 0 against
 // everything (reference submat.c: column 23 is zero) and therefore cannot raise any maximum: an item
 // stops at the longest sequence of ITS sub-block (the sequences are sorted by length, so this trims
@@ -1653,6 +1713,11 @@ hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
+    if (W == 16) { // the reference's layout: one kernel re-tiles and finds the live extents
+        hipLaunchKernelGGL(osw_retile16, dim3(nblocks), dim3(256), 0, s, b, n, disp, ngroups, blocks, tiled, sub_cols);
+        OSW_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(osw_retile, dim3(nblocks), dim3(256), 0, s, b, n, disp, ngroups, W, (const OswBlock *)blocks, tiled);
     OSW_LAUNCH_CHECK();
     hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(128), 0, s, blocks, (const uint16_t *)tiled, sub_cols);

@@ -26,6 +26,9 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES
 echo "sq pass done"
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d "$OUT/sq2" -- $BENCH --steps 2 --warmup 0 > "$OUT/sq2.log" 2>&1 || echo "sq2 pass failed (counters not available?)"
 echo "sq2 pass done"
+# effective clock of the dispatches: GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time (MI355X_MICROARCH.md, DVFS give-back)
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/clk" -- $BENCH --steps 2 --warmup 0 > "$OUT/clk.log" 2>&1 || echo "clk pass failed"
+echo "clk pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -- $REPO/tools/ubench calib > "$OUT/calib_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -- $REPO/tools/ubench calib > "$OUT/calib_write.log" 2>&1
 echo "calibration passes done"
