@@ -79,7 +79,10 @@ def parse():
     ap.add_argument("--nseq", type=int, default=0, help="TOTAL database sequences (default: 1000000 = C4 for the default workload at every --gpus, 100000 for c3 / c5 / q1; 100000 = C2); per GPU with --weak")
     ap.add_argument("--shard-rule", default="deal", choices=["deal", "reference"], help="how the sorted database is divided among the ranks (see the module docstring)")
     ap.add_argument("--weak", action="store_true", help="round-1 mode: every rank searches its own independent --nseq database")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "q1", "hi", "hi8"],
+                    help="c2 / c3 / c5 / q1: BASELINE configs; hi: escalation-heavy (ten queries of 4400-6600 residues against a database in which 1 %% of the "
+                         "sequences are near-copies of them: scores beyond the int16 cells, re-run in int32); hi8: the C3 set on the 8-bit cells with 5 %% of the "
+                         "database planted homologs (pairs that leave the 7-bit range, re-run in int16)")
     ap.add_argument("--top", type=int, default=10)
     ap.add_argument("--max-chunk", type=int, default=134217728, help="chunk size limit in bytes (the reference's -k, default 128 MiB)")
     ap.add_argument("--cell-bits", type=int, default=0, choices=[0, 8, 16, 32],
@@ -101,6 +104,15 @@ def workload(name):
         return dict(qlens=None, matrix="blosum62", go=10, ge=2, label="20 queries len 100-1000 x {nseq}-seq synthetic DB, BLOSUM62 10/2")
     if name == "c3":
         return dict(qlens=None, matrix="pam250", go=14, ge=2, label="20 queries len 100-1000 x {nseq}-seq synthetic DB, PAM250 14/2")
+    if name == "hi":
+        # every query's self-score is beyond the column-frame cell's ceiling (22 256), the longer ones' beyond the plain int16
+        # cell's (30 576): ~5.3 per residue.  Copies at 1 .. 30 % substitutions: most of them above 22 256, the best above 30 576.
+        return dict(qlens=[4400 + 245 * k for k in range(10)], matrix="blosum62", go=10, ge=2, planted_share=0.01,
+                    rates=[0.01, 0.02, 0.03, 0.05, 0.07, 0.10, 0.14, 0.18, 0.24, 0.30],
+                    label="10 queries len 4400-6605 x {nseq}-seq synthetic DB of which 1 % are near-copies of the queries (1-30 % substitutions), BLOSUM62 10/2")
+    if name == "hi8":
+        return dict(qlens=None, matrix="pam250", go=14, ge=2, planted_share=0.05, rates=None,
+                    label="20 queries len 100-1000 x {nseq}-seq synthetic DB of which 5 % are planted homologs (5-60 % substitutions), PAM250 14/2")
     if name == "q1":
         return dict(qlens=[375], matrix="blosum62", go=10, ge=2, label="1 query len 375 (the C1 query) x {nseq}-seq synthetic DB, BLOSUM62 10/2")
     return dict(qlens=[5000], matrix="blosum62", go=10, ge=2, label="1 query len 5000 x {nseq}-seq synthetic DB, BLOSUM62 10/2")
@@ -168,11 +180,12 @@ def main():
     t0 = time.time()
     strong = not args.weak
     nseq_total = args.nseq or (1000000 if args.workload == "c2" and not args.weak else 100000)
+    per_query = max(1, int(round(wl["planted_share"] * nseq_total / nq))) if wl.get("planted_share") else 12   # planted copies per query
     if strong:
-        plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB, 12)
+        plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB, per_query, wl.get("rates"))
         shard_world, shard_rank = world, rank
     else:
-        plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB + 1000003 * rank, 12)
+        plan = synth.DatabasePlan(nseq_total, queries, synth.SEED_DB + 1000003 * rank, per_query, wl.get("rates"))
         shard_world, shard_rank = 1, 0
     shard = multigpu.ShardedDatabase(plan, 16, args.max_chunk, shard_world, shard_rank, args.shard_rule)
     index_base = 0 if strong else rank * nseq_total      # weak mode: global index = shard base + sorted position
@@ -184,7 +197,7 @@ def main():
         if dist is not None:
             dist.broadcast_object_list(ident, src=0, device=coll_dev)
         ctx.comm_init_rank(ident[0], world, rank)
-    cell_bits = args.cell_bits or (8 if args.workload == "c3" else 16)
+    cell_bits = args.cell_bits or (8 if args.workload in ("c3", "hi8") else 16)
     ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
     ctx.set_queries(a, m, a_disp)
     chunks = []          # resident chunks of this rank (+ their host arrays for the PCIe-inclusive leg)
@@ -244,6 +257,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_launches, rerun = ctx.kernel_stats()
+    rerun16_ms, rerun32_ms = ctx.rerun_stats()
     ctx.set_profiling(False)
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
@@ -270,7 +284,8 @@ def main():
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / row_cycles) * 128.0 / 1e9
         kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
         traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None)
-        cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1"}[args.workload]
+        cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1",
+                    "hi": "escalation-heavy (int16 -> int32)", "hi8": "escalation-heavy (int8 -> int16)"}[args.workload]
         if cfg_name == "C4" and world == 1:
             cfg_name = "C4 database on one GPU"
         rule_note = "128-sequence wave blocks dealt to the GPUs in alternating order" if args.shard_rule == "deal" else f"the reference's chunk rule (chunk c -> GPU c mod {world})"
@@ -299,7 +314,11 @@ def main():
             # the north star's ">= 0.5 x HBM roofline" is only well posed under the reference's own traffic
             # model, 1 B of substitution score per cell streamed from device DRAM (sw.cl:57): 8 TB/s = 8000 GCUPS
             "reference_traffic_model": {"bytes_per_cell": 1.0, "roofline_gcups": HBM_PEAK_GBS, "frac": round(gcups / world / HBM_PEAK_GBS, 4)},
-            "rerun_items_int32": int(rerun), "rerun_items_int16": int(ctx.rerun_counts()[0]), "work_items": int(sum(ctx.chunk_geometry(c["h"])["work_items"] for c in chunks)),
+            "rerun_items_int32": int(rerun), "rerun_items_int16": int(ctx.rerun_counts()[0]),
+            # device time of the escalation tiers per step on rank 0 (HIP events around their launches; part of kernel_ms): the int16
+            # re-run of what left the 8-bit cells, the exact int32 re-run of what reached the int16 cells' ceiling
+            "rerun_ms_per_step": {"int16": round(rerun16_ms / args.steps, 3), "int32": round(rerun32_ms / args.steps, 3),
+                                  "share_of_kernel_time": round((rerun16_ms + rerun32_ms) / kern_ms, 4) if kern_ms > 0 else None}, "work_items": int(sum(ctx.chunk_geometry(c["h"])["work_items"] for c in chunks)),
             "max_log2_geometry": int(max([ctx.chunk_geometry(c["h"])["max_log2_geometry"] for c in chunks] or [0])),
             "planned_spill_bytes_per_step": int(sum(ctx.chunk_geometry(c["h"])["planned_spill_bytes"] for c in chunks)),
             "top1_scores": [int(x) for x in top[0][:, 0]] if top is not None else None,
@@ -326,26 +345,16 @@ def main():
             raise SystemExit("bench.py: the merged top list differs from the single-GPU golden result (tests/golden/bench_top_*.json)")
 
 
-def pinned_like(x):
-    """A copy of the numpy array in page-locked host memory (torch's allocator = hipHostMalloc)."""
-    import torch
-    t = torch.empty(x.shape, dtype=torch.from_numpy(x[:0]).dtype).pin_memory()
-    v = t.numpy()
-    v[...] = x
-    return t, v
-
-
 def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned):
     """SURVEY 8(d)'s timed region on rank 0's chunks: H2D of the interleaved chunk + re-tile + search + D2H of the
     whole int32 score table, chunk k+1 uploading while chunk k is searched."""
-    import torch
+    from oswald_amd import capi
     keep, bufs, outs = [], [], []
     for c in chunks:
-        if pinned:
-            tb, b = pinned_like(c["b"]); tn, n = pinned_like(c["n"]); td, d = pinned_like(c["disp"])
-            to = torch.empty((nq, len(c["n"]) * 16), dtype=torch.int32).pin_memory()
-            keep += [tb, tn, td, to]
-            bufs.append((b, n, d)); outs.append(to.numpy())
+        if pinned:   # page-locked buffers from the library (oswald_hip_host_alloc), filled before the clock starts
+            hb = [capi.pinned_copy(c[k]) for k in ("b", "n", "disp")] + [capi.HostBuffer((nq, len(c["n"]) * 16), np.int32)]
+            keep += hb
+            bufs.append((hb[0].a, hb[1].a, hb[2].a)); outs.append(hb[3].a)
         else:
             bufs.append((c["b"], c["n"], c["disp"])); outs.append(np.zeros((nq, len(c["n"]) * 16), np.int32))
     ctx.wait()
@@ -358,10 +367,12 @@ def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned):
         h = nxt
     ctx.wait()
     t = time.perf_counter() - t0
-    pcie_inclusive.last_scores = outs
+    pcie_inclusive.last_scores = [np.array(o) for o in outs] if pinned else outs   # (the pinned buffers go back to the library)
+    for hb in keep:
+        hb.close()
     return {"gcups": round(sum_m * d_local / t / 1e9, 1), "ms": round(t * 1e3, 2),
             "what": "SURVEY 8(d)'s timed region on rank 0's chunks (reference FPGAsearch.c:80-276): H2D of the interleaved chunk + re-tile + search + D2H of "
-                    "all int32 scores; upload of chunk k+1 overlapped with the search of chunk k; " + ("pinned host buffers" if pinned else "pageable host memory")}
+                    "all int32 scores; upload of chunk k+1 overlapped with the search of chunk k; " + ("page-locked host buffers (oswald_hip_host_alloc)" if pinned else "pageable host memory")}
 
 
 def golden_path(args, nseq_total):

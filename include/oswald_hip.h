@@ -58,6 +58,13 @@ const char *oswald_hip_last_error(void);
 /* Number of visible GPUs.  Replaces getDevices() in utils.c:115-118. */
 int oswald_hip_device_count(int *count);
 
+/* Page-locked host memory for the buffers the caller hands to oswald_hip_chunk_upload* and the score tables it has
+ * filled: the DMA engines read / write it directly and asynchronously (pageable memory works too; the runtime then
+ * stages it).  Stands where the reference allocates its host buffers 64-byte aligned "for DMA":
+ * posix_memalign(AOCL_ALIGNMENT, ...), host/src/sequences.h:15, host/src/FPGAsearch.c:69-74.  Needs a GPU. */
+int oswald_hip_host_alloc(size_t bytes, void **ptr);
+int oswald_hip_host_free(void *ptr);
+
 /* Bring-up: one stream and one buffer set per device; device_ids == NULL means
  * devices 0..ndev-1.  Replaces init(), utils.c:99-173 (platform, context,
  * queues, program, kernels).  Nothing is retained after oswald_hip_finalize(). */
@@ -206,6 +213,12 @@ int oswald_hip_comm_info(oswald_hip_ctx *ctx, int *out4);
 int oswald_hip_set_profiling(oswald_hip_ctx *ctx, int enable);
 int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, uint64_t *dp_launches,
                             uint64_t *rerun_items, int reset);
+
+/* Device time of the escalation tiers since the last reset of oswald_hip_kernel_stats (profiling enabled): out[0] = the
+ * int16 re-run launches behind the 8-bit pass, out[1] = the int32 re-run launches (both are part of dp_kernel_ms).
+ * What the reference spends in its two overflow branches, HybridSearch.c:1683-1771, :1787-1874 / sw_host
+ * FPGAsearch.c:377-507. */
+int oswald_hip_rerun_stats(oswald_hip_ctx *ctx, int dev, double *ms2);
 
 /* Escalations of the most recent search on `dev`: out[0] = work items the 8-bit
  * pass queued for the int16 re-run, out[1] = sequences the int16 cells queued

@@ -27,6 +27,7 @@ SYMBOLS = (
     "oswald_hip_set_profiling", "oswald_hip_kernel_stats", "oswald_hip_chunk_geometry", "oswald_hip_chunk_upload_async", "oswald_hip_reserve", "oswald_hip_rerun_counts",
     "oswald_hip_topr_begin", "oswald_hip_chunk_set_index", "oswald_hip_topr", "oswald_hip_merge_candidates",
     "oswald_hip_comm_unique_id", "oswald_hip_comm_init_rank", "oswald_hip_comm_info", "oswald_hip_max_chunk_size",
+    "oswald_hip_host_alloc", "oswald_hip_host_free", "oswald_hip_rerun_stats",
 )
 COMM_ID_BYTES = 128   # OSWALD_HIP_COMM_ID_BYTES
 
@@ -69,6 +70,9 @@ def load():
     lib.oswald_hip_chunk_set_index.argtypes = [vp, i32, i32, u32, u32, vp]
     lib.oswald_hip_topr.argtypes = [vp, u32, vp, vp]
     lib.oswald_hip_merge_candidates.argtypes = [u32, u64, vp, vp, u32, vp, vp]
+    lib.oswald_hip_rerun_stats.argtypes = [vp, i32, C.POINTER(C.c_double)]
+    lib.oswald_hip_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    lib.oswald_hip_host_free.argtypes = [vp]
     lib.oswald_hip_max_chunk_size.argtypes = [vp, i32, u32, u32, C.POINTER(u64)]
     lib.oswald_hip_comm_unique_id.argtypes = [vp, sz]
     lib.oswald_hip_comm_init_rank.argtypes = [vp, vp, sz, i32, i32]
@@ -103,6 +107,35 @@ def merge_candidates(cand_scores: np.ndarray, cand_index: np.ndarray, r: int):
     out_i = np.empty((cs.shape[0], r), np.uint32)
     _chk(load().oswald_hip_merge_candidates(cs.shape[0], cs.shape[1], _ptr(cs), _ptr(ci), r, _ptr(out_s), _ptr(out_i)))
     return out_s, out_i
+
+
+class HostBuffer:
+    """Page-locked host memory from oswald_hip_host_alloc as a numpy array (`.a`); freed by close() / garbage collection."""
+
+    def __init__(self, shape, dtype):
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        self.p = C.c_void_p()
+        _chk(load().oswald_hip_host_alloc(max(nbytes, 1), C.byref(self.p)))
+        self.a = np.frombuffer((C.c_char * max(nbytes, 1)).from_address(self.p.value), dtype=dtype, count=nbytes // np.dtype(dtype).itemsize).reshape(shape)
+
+    def close(self):
+        if self.p:
+            self.a = None
+            load().oswald_hip_host_free(self.p)
+            self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def pinned_copy(x: np.ndarray) -> HostBuffer:
+    hb = HostBuffer(x.shape, x.dtype)
+    hb.a[...] = x
+    return hb
 
 
 def comm_unique_id() -> bytes:
@@ -243,6 +276,12 @@ class Context:
         ms, n, re = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         _chk(self.lib.oswald_hip_kernel_stats(self.h, dev, C.byref(ms), C.byref(n), C.byref(re), 1 if reset else 0))
         return ms.value, n.value, re.value
+
+    def rerun_stats(self, dev: int = 0):
+        """(ms in the int16 re-run launches of the 8-bit pass, ms in the int32 re-run launches) since the last stats reset."""
+        out = (C.c_double * 2)()
+        _chk(self.lib.oswald_hip_rerun_stats(self.h, dev, out))
+        return float(out[0]), float(out[1])
 
     def rerun_counts(self, dev: int = 0):
         """(items the 8-bit pass sent to the int16 re-run, sequences the int16 cells sent to the int32 re-run)."""

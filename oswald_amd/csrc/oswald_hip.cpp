@@ -177,7 +177,7 @@ struct Chunk {
     DevBuf index_map_dev;
 };
 
-struct EventPair { hipEvent_t a, b; };
+struct EventPair { hipEvent_t a, b, c, d; bool c_used; }; // a..b: all DP launches of a chunk search; c..d: the int16 re-run of the 8-bit pass (c_used); d..b: the int32 re-run
 
 struct Device {
     int id = -1;
@@ -211,7 +211,7 @@ struct Device {
     int leader = -1;                 // index of the first context device on this GPU
     int comm_rank = -1;              // leader: rank in the context's communicator (order of first appearance)
     ncclComm_t comm = nullptr;       // leader, when the context spans more than one GPU
-    double dp_ms = 0;
+    double dp_ms = 0, rerun16_ms = 0, rerun32_ms = 0;
     uint64_t dp_launches = 0, rerun_items = 0;
 };
 
@@ -711,6 +711,8 @@ void drain_events(Device &d)
     for (auto &e : d.ev_used) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { d.dp_ms += ms; d.dp_launches++; }
+        if (e.c_used && hipEventElapsedTime(&ms, e.c, e.d) == hipSuccess) d.rerun16_ms += ms;
+        if (hipEventElapsedTime(&ms, e.d, e.b) == hipSuccess) d.rerun32_ms += ms;
         d.ev_pool.push_back(e);
     }
     d.ev_used.clear();
@@ -773,6 +775,22 @@ extern "C" {
 int oswald_hip_abi_version(void) { return OSWALD_HIP_ABI_VERSION; }
 
 const char *oswald_hip_last_error(void) { return g_err.c_str(); }
+
+// Page-locked host memory for the caller's chunk buffers and score tables.
+int oswald_hip_host_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr) return fail(OSWALD_HIP_EINVAL, "null out-pointer");
+    *ptr = nullptr;
+    if (bytes == 0) return 0;
+    HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+int oswald_hip_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return 0;
+}
 
 int oswald_hip_device_count(int *count)
 {
@@ -885,7 +903,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
             b->release();
         if (d.ev_top) (void)hipEventDestroy(d.ev_top);
         drain_events(d);
-        for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); }
         if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
         if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
         if (d.ev_join) (void)hipEventDestroy(d.ev_join);
@@ -1171,7 +1189,10 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         if (d.ev_pool.empty()) {
             HIP_TRY(hipEventCreate(&ev.a));
             HIP_TRY(hipEventCreate(&ev.b));
+            HIP_TRY(hipEventCreate(&ev.c));
+            HIP_TRY(hipEventCreate(&ev.d));
         } else { ev = d.ev_pool.back(); d.ev_pool.pop_back(); }
+        ev.c_used = false;
     }
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, (OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream));
     const uint32_t grid_cap = ctx->tun.grid_per_cu ? std::min<uint32_t>(d.grid, (uint32_t)d.prop.multiProcessorCount * ctx->tun.grid_per_cu) : d.grid; // (-DOSW_DIAG sweep)
@@ -1211,6 +1232,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             ar.nitems_wg = 0;
             ar.nitems_dev = a.counters_ovf + 1; // workgroup entries (four waves on the four lanes of a flagged quad, geometry 64)
             ar.counters = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
+            if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.c, d.stream)); ev.c_used = true; }
             HIP_TRY(osw_launch_pk16(ar, std::min<uint32_t>(d.grid, 512u), d.stream));
         }
     } else if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
@@ -1244,6 +1266,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     } else if (ctx->cell_bits != 32 && c.nitems + c.nitems_wg > 0) {
         HIP_TRY(launch_single(as, grid, d.stream));
     }
+    if (ctx->profiling) HIP_TRY(hipEventRecord(ev.d, d.stream));
     HIP_TRY(osw_launch_i32(a, std::min<uint32_t>(d.grid, 1024u), d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
@@ -1322,7 +1345,10 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         // pin the caller's table for the copy: the DMA engine then writes it directly (a copy into a pageable
         // buffer it has not seen before runs at ~1 GB/s here, 8.9 ms for the 8 MB of C2; this way 0.5 ms)
         const size_t bytes = (size_t)ctx->nq * row * sizeof(int32_t);
-        if (bytes >= (1u << 20) && !ctx->tun.no_pin) {
+        hipPointerAttribute_t attr;
+        const bool pinned_already = hipPointerGetAttributes(&attr, scores_out) == hipSuccess && attr.type == hipMemoryTypeHost; // e.g. from oswald_hip_host_alloc
+        (void)hipGetLastError(); // (an unknown -- pageable -- pointer is reported as an error by some runtimes)
+        if (bytes >= (1u << 20) && !ctx->tun.no_pin && !pinned_already) {
             const auto t0 = std::chrono::steady_clock::now();
             if (hipHostRegister(scores_out, bytes, hipHostRegisterDefault) == hipSuccess) d.registered.push_back(scores_out);
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1608,7 +1634,20 @@ int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, 
     if (dp_kernel_ms) *dp_kernel_ms = d.dp_ms;
     if (dp_launches) *dp_launches = d.dp_launches;
     if (rerun_items) *rerun_items = ctr[0]; // of the most recent search
-    if (reset) { d.dp_ms = 0; d.dp_launches = 0; }
+    if (reset) { d.dp_ms = 0; d.dp_launches = 0; d.rerun16_ms = 0; d.rerun32_ms = 0; }
+    return 0;
+}
+
+int oswald_hip_rerun_stats(oswald_hip_ctx *ctx, int dev, double *ms2)
+{
+    if (int r = check_dev(ctx, dev)) return r;
+    if (!ms2) return fail(OSWALD_HIP_EINVAL, "null output");
+    Device &d = ctx->dev[dev];
+    HIP_TRY(hipSetDevice(d.id));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    drain_events(d);
+    ms2[0] = d.rerun16_ms;
+    ms2[1] = d.rerun32_ms;
     return 0;
 }
 

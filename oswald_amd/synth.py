@@ -158,7 +158,8 @@ class DatabasePlan:
     stream and the planted homologs.  Cheap (no per-residue work), so every rank of a sharded search
     can hold the plan of the whole database and materialise only the sequences of its own shard."""
 
-    def __init__(self, nseq, queries, seed, homologs_per_query):
+    def __init__(self, nseq, queries, seed, homologs_per_query, rates=None):
+        """rates: substitution rates of a query's planted copies, cycled through (default 5 %, 10 %, ... by copy number)"""
         self.nseq, self.seed = nseq, seed
         lengths = random_lengths(seed, nseq).astype(np.int64)
         self.planted = {}
@@ -170,7 +171,8 @@ class DatabasePlan:
                     idx = int(ranks[k] % np.uint64(nseq))
                     while idx in self.planted:
                         idx = (idx + 1) % nseq
-                    mut = mutate(np.asarray(q, dtype=np.uint8), 0.05 * (h + 1), seed + 7919 * (qi * homologs_per_query + h + 1))
+                    rate = 0.05 * (h + 1) if rates is None else rates[h % len(rates)]
+                    mut = mutate(np.asarray(q, dtype=np.uint8), rate, seed + 7919 * (qi * homologs_per_query + h + 1))
                     if len(mut) > 65520:
                         mut = mut[:65520]
                     self.planted[idx] = mut
