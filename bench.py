@@ -359,12 +359,14 @@ def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned):
             bufs.append((c["b"], c["n"], c["disp"])); outs.append(np.zeros((nq, len(c["n"]) * 16), np.int32))
     ctx.wait()
     t0 = time.perf_counter()  # (rank 0's chunks; the other ranks idle at the final barrier meanwhile)
-    h = ctx.chunk_upload(*bufs[0], 16, wait=False) if bufs else None
+    # two chunks ahead: the copies of chunk k+2 run beside the search of chunk k, its re-tile when that search drains, and
+    # the host plans and queues the search of chunk k+1 meanwhile
+    hs = [ctx.chunk_upload(*bufs[k], 16, wait=False) for k in range(min(2, len(bufs)))]
     for k in range(len(bufs)):
-        ctx.chunk_search(h, outs[k])                 # waits for ITS upload only; queued behind the search before it
-        nxt = ctx.chunk_upload(*bufs[k + 1], 16, wait=False) if k + 1 < len(bufs) else None
-        ctx.chunk_release(h)                         # the slot is re-used once the device is through with it
-        h = nxt
+        ctx.chunk_search(hs[k], outs[k])             # waits for ITS upload only; queued behind the search before it
+        ctx.chunk_release(hs[k])                     # the slot is re-used once the device is through with it
+        if k + 2 < len(bufs):
+            hs.append(ctx.chunk_upload(*bufs[k + 2], 16, wait=False))
     ctx.wait()
     t = time.perf_counter() - t0
     pcie_inclusive.last_scores = [np.array(o) for o in outs] if pinned else outs   # (the pinned buffers go back to the library)
@@ -372,7 +374,7 @@ def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned):
         hb.close()
     return {"gcups": round(sum_m * d_local / t / 1e9, 1), "ms": round(t * 1e3, 2),
             "what": "SURVEY 8(d)'s timed region on rank 0's chunks (reference FPGAsearch.c:80-276): H2D of the interleaved chunk + re-tile + search + D2H of "
-                    "all int32 scores; upload of chunk k+1 overlapped with the search of chunk k; " + ("page-locked host buffers (oswald_hip_host_alloc)" if pinned else "pageable host memory")}
+                    "all int32 scores; uploads two chunks ahead of the search; " + ("page-locked host buffers (oswald_hip_host_alloc)" if pinned else "pageable host memory")}
 
 
 def golden_path(args, nseq_total):

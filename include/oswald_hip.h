@@ -127,8 +127,8 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
 
 /* The largest chunk -- in bytes of b, i.e. padded residues, the unit of the command line's -k -- device dev can hold for
  * a set of nq queries and sequences of up to max_sequence_length residues: 0.8 of its free memory (less the work
- * space still to be allocated) over what a byte of chunk costs at worst (staging copy, two resident chunks per device
- * -- one searched while the next comes in --, re-tiled residues, scores and re-run queues).  Replaces the clamp of
+ * space still to be allocated) over what a byte of chunk costs at worst (three resident chunks per device -- one
+ * searched while the next two come in --, each with its staging copy, re-tiled residues, scores and re-run queues).  Replaces the clamp of
  * max_chunk_size to the device's global memory in init(), utils.c:162-168 (0.8 x memory / 23 score-profile rows). */
 int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_t max_sequence_length, uint64_t *bytes);
 

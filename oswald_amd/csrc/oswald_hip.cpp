@@ -155,8 +155,18 @@ struct Chunk {
     DevBuf tiled, blocks, sub_cols_buf, items, items_q, scores, ovf, ovf8;
     const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
-    std::vector<uint16_t> sub_cols;     // host copy of the live extents (see osw_block_extent), for the planner
-    std::vector<OswBlock> blocks_host;  // source of the asynchronous upload of the block table: must outlive it
+    // host copy of the live extents (see osw_retile16 / osw_block_extent), for the planner: PAGE-LOCKED, so that the copy
+    // queued behind the re-tile is asynchronous -- into pageable memory hipMemcpyAsync blocks the caller until the copy has
+    // run, i.e. until the re-tile kernel found room on the GPU: an "asynchronous" upload queued beside a running search (the
+    // persistent search grid leaves no wave slot free) returned when that search was over, 114 ms later
+    uint16_t *sub_cols = nullptr;
+    size_t sub_cols_cap = 0;            // entries
+    std::vector<OswBlock> blocks_host;  // the block table as planned on the host ...
+    OswBlock *blocks_pin = nullptr;     // ... and its page-locked copy, the source of the asynchronous upload
+    size_t blocks_pin_cap = 0;
+    DevBuf st_b, st_n, st_disp;         // the caller's arrays as they arrive on the device (the re-tile kernel's input): per slot,
+                                        // so that the copies of the next upload never wait for a re-tile that has not found room yet
+    hipEvent_t ev_copy = nullptr;       // recorded on the copy stream behind them
     uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
     uint32_t nitems_q = 0, nitems_q_wg = 0; // the same for the query-pair kernel's queue
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
@@ -183,13 +193,14 @@ struct Device {
     int id = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second queue: the single-query launch runs beside the query-pair launch
-    hipStream_t stream_up = nullptr; // uploads (H2D + re-tile): the next chunk comes in while the current one is searched
+    hipStream_t stream_up = nullptr; // uploads (re-tile): the next chunk comes in while the current one is searched
+    hipStream_t stream_copy = nullptr; // ... and the copies of the caller's arrays: DMA only, never queued behind a kernel
     uint64_t up_seq = 0;             // uploads queued so far
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     uint32_t grid_q8 = 0;            // ... of the 8-bit kernel (more workgroups per CU; at most 2 x grid: it runs alone and may use both halves of the spill scratch)
-    DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters, staging_b, staging_n, staging_disp;
+    DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters;
     DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
     std::vector<uint32_t> top_pages_host; // source of the asynchronous upload of top_pages
     std::vector<std::shared_ptr<const std::vector<uint32_t>>> retired_maps; // index maps of re-used slots whose upload may still be queued
@@ -566,7 +577,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
             const uint32_t G = 1u << lg;
             c.max_lg = std::max(c.max_lg, lg);
             // an item runs to the last real residue of its own sub-block (workgroup item: of its four sub-blocks)
-            const uint16_t *sc = c.sub_cols.data() + (size_t)b * 128 + (G - 1);
+            const uint16_t *sc = c.sub_cols + (size_t)b * 128 + (G - 1);
             if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg[e.kind].push_back({item_cost(e, lg, std::max(std::max(sc[s], sc[s + 1]), std::max(sc[s + 2], sc[s + 3])), wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
             else for (uint32_t s = 0; s < G; ++s) its[e.kind].push_back({item_cost(e, lg, sc[s], wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
             for (uint32_t s = 0; s < G; ++s) c.planned_spill_bytes += (uint64_t)spill_bytes(e, lg, sc[s], wg);
@@ -824,6 +835,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_up, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_copy, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_top, hipEventDisableTiming);
@@ -892,13 +904,26 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         release_registered(d);
         if (d.stream2) (void)hipStreamSynchronize(d.stream2);
+        if (d.stream_copy) { (void)hipStreamSynchronize(d.stream_copy); (void)hipStreamDestroy(d.stream_copy); d.stream_copy = nullptr; }
         if (d.stream_up) { (void)hipStreamSynchronize(d.stream_up); (void)hipStreamDestroy(d.stream_up); d.stream_up = nullptr; }
-        for (Chunk &c : d.chunks) { if (c.ev_up) (void)hipEventDestroy(c.ev_up); if (c.ev_use) (void)hipEventDestroy(c.ev_use); c.ev_up = c.ev_use = nullptr; }
+        for (Chunk &c : d.chunks) {
+            if (c.ev_up) (void)hipEventDestroy(c.ev_up);
+            if (c.ev_use) (void)hipEventDestroy(c.ev_use);
+            if (c.ev_copy) (void)hipEventDestroy(c.ev_copy);
+            if (c.sub_cols) (void)hipHostFree(c.sub_cols);
+            if (c.blocks_pin) (void)hipHostFree(c.blocks_pin);
+            c.ev_up = c.ev_use = c.ev_copy = nullptr;
+            c.sub_cols = nullptr;
+            c.sub_cols_cap = 0;
+            c.blocks_pin = nullptr;
+            c.blocks_pin_cap = 0;
+            c.st_b.release(); c.st_n.release(); c.st_disp.release();
+        }
         if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev.release(); }
-        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters, &d.staging_b,
-                          &d.staging_n, &d.staging_disp, &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
+        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
+                          &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
             b->release();
         if (d.ev_top) (void)hipEventDestroy(d.ev_top);
@@ -1029,30 +1054,52 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     HIP_TRY(c.tiled.reserve((off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2)));
     HIP_TRY(c.blocks.reserve(c.nblocks * sizeof(OswBlock) + 16));
     HIP_TRY(c.sub_cols_buf.reserve((size_t)c.nblocks * 128 * sizeof(uint16_t) + 16));
-    HIP_TRY(d.staging_b.reserve(vD + 64));
-    HIP_TRY(d.staging_n.reserve(ngroups * sizeof(uint16_t) + 16));
-    HIP_TRY(d.staging_disp.reserve(ngroups * sizeof(uint32_t) + 16));
+    if ((size_t)c.nblocks * 128 > c.sub_cols_cap) {
+        if (c.sub_cols) HIP_TRY(hipHostFree(c.sub_cols));
+        c.sub_cols = nullptr;
+        c.sub_cols_cap = 0;
+        const size_t want = (size_t)c.nblocks * 128 + (size_t)c.nblocks * 16 + 128;
+        HIP_TRY(hipHostMalloc((void **)&c.sub_cols, want * sizeof(uint16_t), hipHostMallocDefault));
+        c.sub_cols_cap = want;
+    }
+    HIP_TRY(c.st_b.reserve(vD + 64));
+    HIP_TRY(c.st_n.reserve(ngroups * sizeof(uint16_t) + 16));
+    HIP_TRY(c.st_disp.reserve(ngroups * sizeof(uint32_t) + 16));
+    if (c.nblocks > c.blocks_pin_cap) {
+        if (c.blocks_pin) HIP_TRY(hipHostFree(c.blocks_pin));
+        c.blocks_pin = nullptr;
+        c.blocks_pin_cap = 0;
+        const size_t want = (size_t)c.nblocks + c.nblocks / 8 + 16;
+        HIP_TRY(hipHostMalloc((void **)&c.blocks_pin, want * sizeof(OswBlock), hipHostMallocDefault));
+        c.blocks_pin_cap = want;
+    }
+    if (c.nblocks) memcpy(c.blocks_pin, blocks.data(), c.nblocks * sizeof(OswBlock));
     if (!c.ev_up) HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
     if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
+    if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
     pt.lap("upload: plan + allocations");
-    // Uploads have a stream of their own: chunk k+1 comes in (DMA + re-tile) while chunk k is searched.  The slot may
-    // still be in use by the search of the chunk it held before (oswald_hip_search_chunk_async, or a release right
-    // behind a search): the upload stream waits for that search.  The staging buffers are shared by the uploads of a
-    // device, which that one stream keeps in order.
+    // Uploads have streams of their own: chunk k+1 comes in while chunk k is searched.  The copies of the caller's arrays
+    // go into the slot's own staging buffers on a stream that carries nothing but DMA -- they start at once, whatever the
+    // GPU is computing.  The re-tile (a kernel) goes on the upload stream behind them; the persistent grid of a running
+    // search leaves it no wave slot, so it runs when that search drains -- by then the host has long returned (every
+    // host-side source / destination of this stream is page-locked: an asynchronous copy from or into pageable memory
+    // would hold the caller until it has run).  The slot may still be in use by the search of the chunk it held before
+    // (oswald_hip_search_chunk_async, or a release right behind a search): the upload stream waits for that search.
     hipStream_t up = d.stream_up;
     if (c.use_pending) { HIP_TRY(hipStreamWaitEvent(up, c.ev_use, 0)); c.use_pending = false; }
     if (ngroups > 0) {
-        HIP_TRY(hipMemcpyAsync(d.staging_b.p, b, vD, hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemcpyAsync(d.staging_n.p, n, ngroups * sizeof(uint16_t), hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemcpyAsync(d.staging_disp.p, disp, ngroups * sizeof(uint32_t), hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemcpyAsync(c.blocks.p, blocks.data(), c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(c.st_b.p, b, vD, hipMemcpyHostToDevice, d.stream_copy));
+        HIP_TRY(hipMemcpyAsync(c.st_n.p, n, ngroups * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream_copy));
+        HIP_TRY(hipMemcpyAsync(c.st_disp.p, disp, ngroups * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream_copy));
+        HIP_TRY(hipEventRecord(c.ev_copy, d.stream_copy));
+        HIP_TRY(hipStreamWaitEvent(up, c.ev_copy, 0));
+        HIP_TRY(hipMemcpyAsync(c.blocks.p, c.blocks_pin, c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, up));
         HIP_TRY(hipMemsetAsync(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), up)); // pads = dummy residue
-        HIP_TRY(osw_launch_retile((const uint8_t *)d.staging_b.p, (const uint16_t *)d.staging_n.p, (const uint32_t *)d.staging_disp.p,
+        HIP_TRY(osw_launch_retile((const uint8_t *)c.st_b.p, (const uint16_t *)c.st_n.p, (const uint32_t *)c.st_disp.p,
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, (uint16_t *)c.sub_cols_buf.p, up));
     }
     if (pt.on) { HIP_TRY(hipStreamSynchronize(up)); pt.lap("upload: H2D + re-tile"); }
-    c.sub_cols.assign((size_t)c.nblocks * 128, 0);
-    if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols.data(), c.sub_cols_dev(), c.sub_cols.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, up));
+    if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols, c.sub_cols_dev(), (size_t)c.nblocks * 128 * sizeof(uint16_t), hipMemcpyDeviceToHost, up));
     HIP_TRY(hipEventRecord(c.ev_up, up));
     c.up_seq = ++d.up_seq;
     c.items_version = ~0ull;
@@ -1096,8 +1143,8 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
     return 0;
 }
 
-// Device memory one byte of chunk (one padded residue of the interleaved groups) takes, worst case: the staging copy
-// of the upload (1), and for each of the two chunks a device holds while one is searched and the next comes in: the
+// Device memory one byte of chunk (one padded residue of the interleaved groups) takes, worst case, for each of the
+// three chunks a device holds while one is searched and the next two come in: the staging copy of the upload (1), the
 // re-tiled residues (a 128-sequence block is padded to its longest group: <= 1.25), the all-dummy columns behind every
 // block (18 x 512 B per block of >= 128 x 28 B: 2.6), and per sequence -- at most one per 28 bytes, the shortest
 // padded group length -- 4 B of score, 8 B of int32 re-run queue and 8 B of int16 re-run queue per query.
@@ -1116,7 +1163,7 @@ int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_
     const uint64_t scratch = 2ull * d.grid * (OSW_WG_THREADS / 64) * (stride + OSW_SCRATCH_DATA) * sizeof(uint2);
     uint64_t usable = (uint64_t)(0.8 * (double)free_b);
     if (stride > d.bnd_stride || !d.bnd.p) usable = usable > scratch ? usable - scratch : 0;
-    const double per_byte = 1.0 + 2.0 * (1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
+    const double per_byte = 3.0 * (1.0 + 1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
     const uint64_t fit = (uint64_t)((double)usable / per_byte);
     *bytes = std::min<uint64_t>(fit, 0xfff00000ull); // (column offsets inside a chunk are 32-bit)
     return 0;
@@ -1393,6 +1440,7 @@ int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
     for (int i = 0; i < (int)ctx->dev.size(); ++i) {
         if (dev >= 0 && i != dev) continue;
         HIP_TRY(hipSetDevice(ctx->dev[i].id));
+        HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_copy));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_up));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream));
         for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; }

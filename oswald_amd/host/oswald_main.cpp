@@ -571,28 +571,33 @@ int do_search(Options &o)
         check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");
         // Round k = piece k of every device.  The uploads of a round are queued on all devices (they overlap), every
         // device is given its search -- the piece's top list is selected and folded on the device behind it --, and
-        // the uploads of round k+1 are queued at once: they come in over the devices' upload streams while round k is
-        // being searched (the reference uploads and searches in turn, FPGAsearch.c:180-223).
+        // the uploads of the rounds to come are queued ahead: they come in over the devices' upload streams while round k
+        // is being searched (the reference uploads and searches in turn, FPGAsearch.c:180-223).
         size_t rounds = 0;
         for (const auto &v : pieces) rounds = std::max(rounds, v.size());
-        std::vector<int> cur(o.num_devices, -1), nxt(o.num_devices, -1);
-        auto upload = [&](size_t k, std::vector<int> &h) {
+        // (two rounds ahead: the copies of round k+2 run beside the search of round k, its re-tile -- a kernel, for which the
+        // persistent search grid leaves no room -- when that search drains; the host meanwhile plans and queues round k+1,
+        // so the device goes from one search into the next without waiting for the host)
+        std::vector<std::vector<int>> h(3, std::vector<int>(o.num_devices, -1));
+        auto upload = [&](size_t k) {
+            std::vector<int> &hk = h[k % 3];
             for (unsigned d = 0; d < pieces.size(); ++d) {
-                h[d] = -1;
+                hk[d] = -1;
                 if (k >= pieces[d].size()) continue;
                 const Piece &p = pieces[d][k];
-                check(oswald_hip_chunk_upload_async(ctx, (int)d, p.b, p.bytes, p.n, p.disp, p.ngroups, (uint32_t)W, &h[d]), "chunk upload");
-                check(oswald_hip_chunk_set_index(ctx, (int)d, h[d], p.first_index, p.nvalid, p.index_map.empty() ? nullptr : p.index_map.data()), "chunk index");
+                check(oswald_hip_chunk_upload_async(ctx, (int)d, p.b, p.bytes, p.n, p.disp, p.ngroups, (uint32_t)W, &hk[d]), "chunk upload");
+                check(oswald_hip_chunk_set_index(ctx, (int)d, hk[d], p.first_index, p.nvalid, p.index_map.empty() ? nullptr : p.index_map.data()), "chunk index");
             }
         };
-        upload(0, cur);
+        upload(0);
+        if (rounds > 1) upload(1);
         for (size_t k = 0; k < rounds; ++k) {
+            std::vector<int> &cur = h[k % 3];
             for (unsigned d = 0; d < pieces.size(); ++d)
                 if (cur[d] >= 0) check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search");
-            if (k + 1 < rounds) upload(k + 1, nxt);
             for (unsigned d = 0; d < pieces.size(); ++d)
                 if (cur[d] >= 0) check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release"); // (the upload has landed; the device re-uses the slot when it is through with it)
-            cur.swap(nxt);
+            if (k + 2 < rounds) upload(k + 2);
         }
         // top lists of all queries (inside the timed region: they stand for the download of the score table)
         std::vector<int32_t> ms(nq * o.top);
