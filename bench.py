@@ -361,12 +361,13 @@ def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned):
     t0 = time.perf_counter()  # (rank 0's chunks; the other ranks idle at the final barrier meanwhile)
     # two chunks ahead: the copies of chunk k+2 run beside the search of chunk k, its re-tile when that search drains, and
     # the host plans and queues the search of chunk k+1 meanwhile
-    hs = [ctx.chunk_upload(*bufs[k], 16, wait=False) for k in range(min(2, len(bufs)))]
+    hs = [ctx.chunk_upload(*bufs[0], 16, wait=False)] if bufs else []
     for k in range(len(bufs)):
         ctx.chunk_search(hs[k], outs[k])             # waits for ITS upload only; queued behind the search before it
         ctx.chunk_release(hs[k])                     # the slot is re-used once the device is through with it
-        if k + 2 < len(bufs):
-            hs.append(ctx.chunk_upload(*bufs[k + 2], 16, wait=False))
+        for j in ((1, 2) if k == 0 else (k + 2,)):   # (the first search starts as soon as its own upload is in)
+            if j < len(bufs):
+                hs.append(ctx.chunk_upload(*bufs[j], 16, wait=False))
     ctx.wait()
     t = time.perf_counter() - t0
     pcie_inclusive.last_scores = [np.array(o) for o in outs] if pinned else outs   # (the pinned buffers go back to the library)

@@ -167,6 +167,8 @@ struct Chunk {
     DevBuf st_b, st_n, st_disp;         // the caller's arrays as they arrive on the device (the re-tile kernel's input): per slot,
                                         // so that the copies of the next upload never wait for a re-tile that has not found room yet
     hipEvent_t ev_copy = nullptr;       // recorded on the copy stream behind them
+    hipEvent_t ev_down = nullptr;       // recorded on the download stream behind the copy of the chunk's score table to the caller ...
+    bool down_pending = false;          // ... which the next search that writes the slot's table must wait for
     uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
     uint32_t nitems_q = 0, nitems_q_wg = 0; // the same for the query-pair kernel's queue
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
@@ -195,6 +197,7 @@ struct Device {
     hipStream_t stream2 = nullptr;   // second queue: the single-query launch runs beside the query-pair launch
     hipStream_t stream_up = nullptr; // uploads (re-tile): the next chunk comes in while the current one is searched
     hipStream_t stream_copy = nullptr; // ... and the copies of the caller's arrays: DMA only, never queued behind a kernel
+    hipStream_t stream_down = nullptr; // score tables on their way to the caller, beside the next chunk's search
     uint64_t up_seq = 0;             // uploads queued so far
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
@@ -836,6 +839,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_up, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_copy, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_down, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_top, hipEventDisableTiming);
@@ -901,15 +905,18 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
     if (!ctx) return 0;
     for (Device &d : ctx->dev) {
         (void)hipSetDevice(d.id);
-        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        for (hipStream_t st : {d.stream, d.stream2, d.stream_copy, d.stream_up, d.stream_down}) if (st) (void)hipStreamSynchronize(st);
         release_registered(d);
         if (d.stream2) (void)hipStreamSynchronize(d.stream2);
         if (d.stream_copy) { (void)hipStreamSynchronize(d.stream_copy); (void)hipStreamDestroy(d.stream_copy); d.stream_copy = nullptr; }
+        if (d.stream_down) { (void)hipStreamSynchronize(d.stream_down); (void)hipStreamDestroy(d.stream_down); d.stream_down = nullptr; }
         if (d.stream_up) { (void)hipStreamSynchronize(d.stream_up); (void)hipStreamDestroy(d.stream_up); d.stream_up = nullptr; }
         for (Chunk &c : d.chunks) {
             if (c.ev_up) (void)hipEventDestroy(c.ev_up);
             if (c.ev_use) (void)hipEventDestroy(c.ev_use);
             if (c.ev_copy) (void)hipEventDestroy(c.ev_copy);
+            if (c.ev_down) (void)hipEventDestroy(c.ev_down);
+            c.ev_down = nullptr;
             if (c.sub_cols) (void)hipHostFree(c.sub_cols);
             if (c.blocks_pin) (void)hipHostFree(c.blocks_pin);
             c.ev_up = c.ev_use = c.ev_copy = nullptr;
@@ -1077,6 +1084,7 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     if (!c.ev_up) HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
     if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
     if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
+    if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
     pt.lap("upload: plan + allocations");
     // Uploads have streams of their own: chunk k+1 comes in while chunk k is searched.  The copies of the caller's arrays
     // go into the slot's own staging buffers on a stream that carries nothing but DMA -- they start at once, whatever the
@@ -1186,6 +1194,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     pt.lap("search: work-queue plan");
     if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return topr_after_search(ctx, d, c); }
     if (!d.bnd.p || d.bnd_stride == 0) return fail(OSWALD_HIP_ESTATE, "device %d has no spill scratch (an earlier allocation failed)", dev);
+    if (c.down_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_down, 0)); c.down_pending = false; } // the table of the slot's last search is still on its way out
 
     OswSearchArgs a;
     memset(&a, 0, sizeof a);
@@ -1378,22 +1387,17 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     }
     if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: kernels"); }
     if (scores_out) {
-        // the caller's table is [nq][ngroups*W]; ours is pitched to whole wave blocks: pack on the device (a pitched
-        // copy into pageable memory runs at a fraction of a GB/s), then one linear copy
+        // The caller's table is [nq][ngroups*W]; ours is pitched to whole wave blocks.  It leaves on the download stream,
+        // behind the search (ev_use) and beside whatever the search stream runs next: row by row when the rows are few (plain
+        // DMA, nothing that needs a wave slot), packed on the device first when they are many (a pitched copy into
+        // pageable memory runs at a fraction of a GB/s).
         const uint32_t row = c.ngroups * c.W;
-        const void *src = c.scores.p;
-        if (row != c.score_stride && ctx->nq > 1) {
-            HIP_TRY(d.scores_packed.reserve((size_t)ctx->nq * row * sizeof(int32_t)));
-            HIP_TRY(hipMemcpy2DAsync(d.scores_packed.p, (size_t)row * sizeof(int32_t), c.scores.p, (size_t)c.score_stride * sizeof(int32_t),
-                                     (size_t)row * sizeof(int32_t), ctx->nq, hipMemcpyDeviceToDevice, d.stream));
-            src = d.scores_packed.p;
-            if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: pack score table"); }
-        }
-        // pin the caller's table for the copy: the DMA engine then writes it directly (a copy into a pageable
-        // buffer it has not seen before runs at ~1 GB/s here, 8.9 ms for the 8 MB of C2; this way 0.5 ms)
         const size_t bytes = (size_t)ctx->nq * row * sizeof(int32_t);
+        // pin the caller's table for the copy unless it is page-locked already (oswald_hip_host_alloc): the DMA engine then
+        // writes it directly (a copy into a pageable buffer it has not seen before runs at ~1 GB/s: 8.9 ms for the 8 MB of
+        // C2; this way 0.5 ms)
         hipPointerAttribute_t attr;
-        const bool pinned_already = hipPointerGetAttributes(&attr, scores_out) == hipSuccess && attr.type == hipMemoryTypeHost; // e.g. from oswald_hip_host_alloc
+        const bool pinned_already = hipPointerGetAttributes(&attr, scores_out) == hipSuccess && attr.type == hipMemoryTypeHost;
         (void)hipGetLastError(); // (an unknown -- pageable -- pointer is reported as an error by some runtimes)
         if (bytes >= (1u << 20) && !ctx->tun.no_pin && !pinned_already) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -1403,8 +1407,22 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             else (void)hipGetLastError(); // e.g. already pinned by the caller: the plain copy below is still correct
             pt.lap("search: pin caller's table");
         }
-        HIP_TRY(hipMemcpyAsync(scores_out, src, bytes, hipMemcpyDeviceToHost, d.stream));
-        if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: D2H of the score table"); }
+        HIP_TRY(hipStreamWaitEvent(d.stream_down, c.ev_use, 0));
+        if (row == c.score_stride || ctx->nq == 1) {
+            HIP_TRY(hipMemcpyAsync(scores_out, c.scores.p, bytes, hipMemcpyDeviceToHost, d.stream_down));
+        } else if (ctx->nq <= 64) {
+            for (uint32_t q = 0; q < ctx->nq; ++q)
+                HIP_TRY(hipMemcpyAsync(scores_out + (size_t)q * row, (const int32_t *)c.scores.p + (size_t)q * c.score_stride, (size_t)row * sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, d.stream_down));
+        } else {
+            HIP_TRY(d.scores_packed.reserve(bytes));
+            HIP_TRY(hipMemcpy2DAsync(d.scores_packed.p, (size_t)row * sizeof(int32_t), c.scores.p, (size_t)c.score_stride * sizeof(int32_t),
+                                     (size_t)row * sizeof(int32_t), ctx->nq, hipMemcpyDeviceToDevice, d.stream_down));
+            HIP_TRY(hipMemcpyAsync(scores_out, d.scores_packed.p, bytes, hipMemcpyDeviceToHost, d.stream_down));
+        }
+        HIP_TRY(hipEventRecord(c.ev_down, d.stream_down));
+        c.down_pending = true;
+        if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream_down)); pt.lap("search: D2H of the score table"); }
     }
     return 0;
 }
@@ -1443,7 +1461,8 @@ int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_copy));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_up));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream));
-        for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; }
+        HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_down));
+        for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; c.down_pending = false; }
         release_registered(ctx->dev[i]);
     }
     return 0;
@@ -1592,6 +1611,8 @@ int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *
     for (Device &d : ctx->dev) { // everything queued is done: the lists have been folded, downloads of score tables have landed
         HIP_TRY(hipSetDevice(d.id));
         HIP_TRY(hipStreamSynchronize(d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream_down));
+        for (Chunk &c : d.chunks) c.down_pending = false;
         release_registered(d);
     }
     memcpy(scores, ctx->top_host, out_cnt * sizeof(int32_t));

@@ -149,10 +149,12 @@ struct MappedFile {
         if (fd < 0) return nullptr;
         struct stat st;
         if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return nullptr; }
-        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        // MAP_POPULATE: the pages are read in and mapped HERE, while the database is being loaded -- the reference reads its
+        // database from disk before its clock starts (sequences.c:407-439).  Mapped lazily, the first upload of every
+        // chunk would take the page faults inside the timed region (12 ms instead of 2.6 ms for a 128 MiB chunk).
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
         ::close(fd);
         if (m == MAP_FAILED) return nullptr;
-        (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
         auto r = std::make_shared<MappedFile>();
         r->p = (const uint8_t *)m;
         r->bytes = (size_t)st.st_size;

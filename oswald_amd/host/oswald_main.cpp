@@ -565,6 +565,7 @@ int do_search(Options &o)
     const double tick = dwalltime();
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
+    lap("  scoring + queries");
     std::vector<std::vector<int32_t>> top_s(nq);
     std::vector<std::vector<uint64_t>> top_i(nq);
     if (device_top) {
@@ -588,21 +589,25 @@ int do_search(Options &o)
                 check(oswald_hip_chunk_upload_async(ctx, (int)d, p.b, p.bytes, p.n, p.disp, p.ngroups, (uint32_t)W, &hk[d]), "chunk upload");
                 check(oswald_hip_chunk_set_index(ctx, (int)d, hk[d], p.first_index, p.nvalid, p.index_map.empty() ? nullptr : p.index_map.data()), "chunk index");
             }
+            lap("  queue uploads of a round");
         };
+        // the first search starts as soon as its own upload is in; the uploads of the next two rounds follow while it runs
         upload(0);
-        if (rounds > 1) upload(1);
         for (size_t k = 0; k < rounds; ++k) {
             std::vector<int> &cur = h[k % 3];
             for (unsigned d = 0; d < pieces.size(); ++d)
                 if (cur[d] >= 0) check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search");
+            lap("  queue searches of a round");
             for (unsigned d = 0; d < pieces.size(); ++d)
                 if (cur[d] >= 0) check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release"); // (the upload has landed; the device re-uses the slot when it is through with it)
+            if (k == 0 && rounds > 1) upload(1);
             if (k + 2 < rounds) upload(k + 2);
         }
         // top lists of all queries (inside the timed region: they stand for the download of the score table)
         std::vector<int32_t> ms(nq * o.top);
         std::vector<uint32_t> mi(nq * o.top);
         check(oswald_hip_topr(ctx, (uint32_t)o.top, ms.data(), mi.data()), "top scores");
+        lap("  gather the top lists (waits for the devices)");
         for (uint64_t i = 0; i < nq; ++i)
             for (uint64_t j = 0; j < o.top && ms[i * o.top + j] >= 0; ++j) { top_s[i].push_back(ms[i * o.top + j]); top_i[i].push_back(mi[i * o.top + j]); }
     } else {
