@@ -862,6 +862,11 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             r = scratch.reserve(tmp.size());
             if (r == hipSuccess) r = hipMemcpyAsync(scratch.p, tmp.data(), tmp.size(), hipMemcpyHostToDevice, d.stream);
             if (r == hipSuccess) r = hipMemcpyAsync(tmp.data(), scratch.p, tmp.size(), hipMemcpyDeviceToHost, d.stream);
+            // (the chunks arrive on the copy stream, score tables leave on the download stream: their first copies too)
+            for (int rep = 0; rep < 4 && r == hipSuccess; ++rep) r = hipMemcpyAsync(scratch.p, tmp.data(), tmp.size(), hipMemcpyHostToDevice, d.stream_copy);
+            if (r == hipSuccess) r = hipStreamSynchronize(d.stream_copy);
+            if (r == hipSuccess) r = hipMemcpyAsync(tmp.data(), scratch.p, tmp.size(), hipMemcpyDeviceToHost, d.stream_down);
+            if (r == hipSuccess) r = hipStreamSynchronize(d.stream_down);
             if (r == hipSuccess) r = hipMemsetAsync(d.counters.p, 0, (OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t), d.stream);
             OswSearchArgs a;
             memset(&a, 0, sizeof a); // empty queues: every wave leaves at once

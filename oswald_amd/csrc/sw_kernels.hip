@@ -1224,6 +1224,121 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
 
 // ---------------------------------------------------------------------------
+// The int32 re-run of ONE (query, sequence) on the FOUR waves of a workgroup (round 4).  A sequence that reaches the
+// int16 cells' ceiling is a near-copy of a long query: thousands of rows against thousands of columns, 20+ rounds of 256
+// rows at geometry 64, which one wave ran one after the other -- 30-60 ms per item, with a hundred such items on a
+// device of 4096 wave slots the re-run took a quarter of the whole search although it is 0.2 % of its cells
+// (bench.py --workload hi).  Here wave w of the workgroup runs rounds w, w+4, w+8, ... of the item, each behind the
+// round before it by a few dozen columns: the boundary row {H, F} of round rho goes through the spill scratch of the
+// wave that ran it (a region per wave, as always) to the wave that runs round rho+1, column by column.  The producer
+// publishes, in LDS, how many columns of its round are stored (a workgroup-scope release fence in front: the stores
+// have been performed; the waves of a workgroup share the CU's L1); the consumer waits for the columns of its next
+// batch of 32 steps (acquire fence behind the wait).  No wave ever waits for a later round, the first round waits for
+// nothing, and the four waves of a workgroup are resident together: the waits cannot deadlock.  A region is overwritten
+// by its owner's NEXT round (rho+4), which depends -- through rounds rho+3, rho+2, rho+1 -- on the reader of this
+// round's row having been there already.
+// ---------------------------------------------------------------------------
+#define OSW_PIPE_BATCH 32u
+template <int R>
+static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, const uint2 *src_region,
+                                                         uint2 *dst_region, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half, int goe,
+                                                         int ge, int &score, volatile uint32_t *prog_src, volatile uint32_t *prog_mine, uint32_t rho)
+{
+    typedef CellI32 C;
+    int D[R], E[R], top_prev;
+    C::template init_state<R>(D, E, top_prev, goe);
+    const bool g0 = (uint32_t)lane < gl;
+    const bool glast = (uint32_t)lane >= 64u - gl;
+    const int src = ((lane - (int)gl) & 63) << 2;
+    const uint16_t *tb = tcol + u;
+    const uint2 *colr = src_region + OSW_SCRATCH_DATA + u;
+    uint2 *colw = dst_region + OSW_SCRATCH_DATA + u;
+    const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
+    uint32_t hand_h = 0, hand_f = 0, hand_c = dummy;
+    const uint32_t nsteps = ncols + G - 1;
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < nsteps; t0 += OSW_PIPE_BATCH) {
+        const uint32_t t1 = t0 + OSW_PIPE_BATCH < nsteps ? t0 + OSW_PIPE_BATCH : nsteps;
+        if (!first) {
+            // the batch reads the boundary columns t0 .. min(t1, ncols) - 1 of round rho - 1 (published under the tag rho)
+            const uint32_t need = (rho << 20) | (t1 < ncols ? t1 : ncols);
+            while (*prog_src < need) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+#pragma unroll 1
+        for (uint32_t t = t0; t < t1; ++t) {
+            uint32_t codes = dummy, topb = 0, fb = 0;
+            if (t < ncols) {
+                codes = tb[(size_t)t * 64];
+                if (!first) { const uint2 b = colr[(size_t)t * gl]; topb = b.x; fb = b.y; }
+            }
+            if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
+            int f = (int)fb, hl;
+            C::template column<R>(base, codes, half, D, E, top_prev, f, hl, goe, ge, score);
+            top_prev = (int)topb;
+            if (!last && t + 1 >= G && glast) colw[(size_t)(t + 1 - G) * gl] = make_uint2((uint32_t)hl, (uint32_t)f);
+            if (G > 1) {
+                hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, hl);
+                hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, f);
+                hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
+            }
+        }
+        if (!last) {
+            // columns 0 .. t1 - G of this round are stored; make them visible, then say so
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 63) *prog_mine = ((rho + 1u) << 20) | (t1 >= G ? t1 + 1u - G : 0u);
+        }
+    }
+}
+
+// one (query, sequence half) on the workgroup: -> the score, valid in the lanes of group 0 of EVERY wave
+static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma, uint32_t lg,
+                                                        int lane, int wv, int half, uint2 *lds_wave, uint2 *bnd_wg, volatile uint32_t *prog, int *red)
+{
+    typedef CellI32 C;
+    const uint32_t G = 1u << lg, gl = 64u >> lg;
+    const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
+    const uint32_t ncols = __builtin_amdgcn_readfirstlane((uint32_t)p.sub_cols[(size_t)B * 128 + (G - 1u) + sigma]);
+    const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
+    const OswPlan plan = osw_plan(p.qlen[q], G, C::kLdsRows, C::kRows);
+    const uint2 *prof_q = p.prof + (size_t)p.prof_off[q] * 32u;
+    uint2 *mine = (uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)wv * p.bnd_stride));
+    const uint2 *prev = (const uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)((wv + 3) & 3) * p.bnd_stride));
+    if (lane == 0) prog[wv] = 0;
+    __syncthreads();
+    int score = 0;
+    for (uint32_t rho = (uint32_t)wv; rho < plan.rounds; rho += OSW_WG_THREADS / 64) {
+        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
+        __builtin_amdgcn_wave_barrier();
+        fill_profile_slice<uint2>(prof_q, rb0, R / 4, G, rb_end, lds_wave, (uint32_t)lane, 64u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_wave + g * (R * C::kRowBytes + (uint32_t)sizeof(uint2)));
+        const bool first = rho == 0, last = rho + 1 == plan.rounds;
+        volatile uint32_t *ps = prog + ((wv + 3) & 3), *pm = prog + wv;
+        switch (R) {
+        case 4: sw_round_pipe_i32<4>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
+        case 8: sw_round_pipe_i32<8>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
+        case 12: sw_round_pipe_i32<12>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
+        default: sw_round_pipe_i32<16>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
+        }
+    }
+    // best over the strips = best over the lane groups, then over the waves
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    for (uint32_t off = gl; off < 64; off <<= 1) {
+        const int o = __builtin_amdgcn_ds_bpermute((ln ^ (int)off) << 2, score);
+        score = o > score ? o : score;
+    }
+    red[wv * 64 + lane] = score;
+    __syncthreads();
+    int best = red[lane];
+    for (int w = 1; w < OSW_WG_THREADS / 64; ++w) best = red[w * 64 + lane] > best ? red[w * 64 + lane] : best;
+    __syncthreads(); // (red and prog are free for the next item)
+    return best;
+}
+
+// ---------------------------------------------------------------------------
 // Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at
 // geometry 64 (each lane one strip of the same sequence: the whole wave works
 // on one sequence at a time).  force_all: run `items` (cell_bits = 32 mode).
@@ -1240,6 +1355,32 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
     const uint32_t nitems = p.force_all ? p.nitems : p.counters_ovf[0];
     const uint2 *items = p.force_all ? p.items + (size_t)p.nitems_wg * 4 : p.ovf_items;
 
+    if (!p.force_all) {
+        // the re-run queue: few, long items -- a workgroup per item, its four waves a pipeline over the item's rounds
+        __shared__ uint32_t prog[OSW_WG_THREADS / 64];
+        __shared__ uint32_t wg_it;
+        __shared__ int red[OSW_WG_THREADS];
+        uint2 *bnd_wg = p.bnd + (size_t)blockIdx.x * (OSW_WG_THREADS / 64) * p.bnd_stride;
+        for (;;) {
+            if (threadIdx.x == 0) wg_it = atomicAdd(&p.counters[OSW_CTR_WORK32], 1u);
+            __syncthreads();
+            const uint32_t it = wg_it;
+            __syncthreads();
+            if (it >= nitems) break;
+            const uint2 item = items[it];
+            const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
+            const uint32_t hm = OSW_ITEM_HALVES(item.x);
+            const OswBlock blk = p.blocks[B];
+            const uint32_t gl = 64u >> lg;
+            for (int half = 0; half < 2; ++half) {
+                if (!((hm >> half) & 1u)) continue;
+                const int score = run_item_i32_pipe(p, q, B, blk, sigma, lg, lane, wv, half, lds_wave, bnd_wg, prog, red);
+                if (wv == 0 && (uint32_t)lane < gl)
+                    p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
+            }
+        }
+        return;
+    }
     for (;;) {
         uint32_t it = 0;
         if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK32], 1u);

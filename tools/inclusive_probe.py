@@ -14,21 +14,24 @@ ad = np.concatenate([[0], np.cumsum(m[:-1], dtype=np.int64)]).astype(np.uint32)
 ctx = capi.Context(1, [0]); ctx.set_scoring(submat.load("blosum62"), 10, 2, 16); ctx.set_queries(a, m, ad)
 chunks = [shard.chunk(k) for k in range(len(shard.mine))]
 res = [ctx.chunk_upload(c["b"], c["n"], c["disp"], 16) for c in chunks]
-for rep in range(2):
-    ctx.wait(); t = time.perf_counter()
-    for h in res: ctx.chunk_search(h, None)
-    ctx.wait(); print(f"resident pass {1e3*(time.perf_counter()-t):.2f} ms")
+def resident(n):
+    for rep in range(n):
+        ctx.wait(); t = time.perf_counter()
+        for h in res: ctx.chunk_search(h, None)
+        ctx.wait(); print(f"resident pass {1e3*(time.perf_counter()-t):.2f} ms")
+resident(3)
 bufs = [[capi.pinned_copy(c[k]) for k in ("b", "n", "disp")] + [capi.HostBuffer((nq, len(c["n"]) * 16), np.int32)] for c in chunks]
-for rep in range(3):
+for rep in range(5):
+    if rep == 3: resident(3)
     ctx.wait(); T0 = time.perf_counter(); log = []
     def call(name, f):
         t = time.perf_counter(); r = f(); log.append((name, 1e3 * (t - T0), 1e3 * (time.perf_counter() - t))); return r
     hs = [call(f"upload{k}", lambda k=k: ctx.chunk_upload(bufs[k][0].a, bufs[k][1].a, bufs[k][2].a, 16, wait=False)) for k in range(min(2, len(bufs)))]
     for k in range(len(bufs)):
-        call(f"search{k}", lambda: ctx.chunk_search(hs[k], bufs[k][3].a if rep < 2 else None))
+        call(f"search{k}", lambda: ctx.chunk_search(hs[k], bufs[k][3].a if rep < 2 or rep == 4 else None))
         call(f"release{k}", lambda: ctx.chunk_release(hs[k]))
         if k + 2 < len(bufs):
             hs.append(call(f"upload{k+2}", lambda: ctx.chunk_upload(bufs[k+2][0].a, bufs[k+2][1].a, bufs[k+2][2].a, 16, wait=False)))
     call("wait", lambda: ctx.wait())
-    print(f"inclusive pass {rep} ({'with' if rep < 2 else 'without'} score tables): {1e3*(time.perf_counter()-T0):.2f} ms")
+    print(f"inclusive pass {rep} ({'with' if rep < 2 or rep == 4 else 'without'} score tables): {1e3*(time.perf_counter()-T0):.2f} ms")
     for name, at, dur in log: print(f"   {name:10s} at {at:8.2f} ms took {dur:8.2f} ms")
