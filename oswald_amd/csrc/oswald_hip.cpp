@@ -445,7 +445,7 @@ int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     const Kind kinds[2] = {
         {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16,
          i32 ? 24.0 : first_pass_is_frame(ctx) ? 7.5 : 8.5, 1.0},
-        q8 ? Kind{OSW_RMAX8, OSW_LDS_ROWS8, 26.0, 1.0} // SWAR 8-bit pairs: 44 instructions per row of a 2 x 2 tile, most of them at ~2.4 cycles: as 26 full-cost ones; one pass, wave items only
+        q8 ? Kind{OSW_RMAX8, OSW_LDS_ROWS8, 21.4, 1.0} // SWAR 8-bit pairs: 40 instructions per row of a 2 x 2 tile in 90.9 cycles (profiles/r04_oprate_q8.txt): as 21.4 slots of 4.25 cycles; one pass, wave items only
            : Kind{OSW_RMAX16, OSW_LDS_ROWS16 / 2, first_pass_is_frame(ctx) ? 6.5 : 7.5, 2.0}};
     struct Entity { uint32_t m, id, kind; };
     std::vector<Entity> ents;

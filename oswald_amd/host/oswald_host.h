@@ -109,9 +109,10 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
 // cpu_vector_length: the command line's -v -- 16 selects the SSE4.1 kernel (the reference's default host path), 32 the AVX2 one.
 void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int vector_length, const int8_t *submat, int open_gap,
                         int extend_gap, int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length = 32,
-                        const std::atomic<bool> *cancel = nullptr, std::atomic<uint64_t> *padded_residues_done = nullptr);
-// cancel: when it becomes true the groups not yet started are skipped (their scores stay untouched); padded_residues_done
-// accumulates n[g] x 16 of every group finished (what the hybrid mode's calibration measures the host's speed on).
+                        const std::atomic<bool> *cancel = nullptr, std::atomic<uint64_t> *cells_done = nullptr);
+// cancel: when it becomes true the groups not yet started are skipped and a group in progress is left at its next query
+// (scores not computed stay untouched); cells_done accumulates query length x n[g] x 16 of every (group, query) finished
+// (what the hybrid mode's calibration measures the host's speed on).
 
 std::vector<std::string> load_database_headers(const std::string &sequences_filename, uint64_t sequences_count);
 // The titles of the given sequences only (any order, duplicates allowed): one pass over the mapped file instead of

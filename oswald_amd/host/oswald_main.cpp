@@ -359,17 +359,17 @@ int do_search_hybrid(Options &o)
     // test scores go to a table of their own and are dropped: the accelerator fills the same columns for good.  The
     // host's test is called off when the accelerator's is over (1 % of a 1 M-sequence database keeps four host threads
     // busy for a quarter of a minute; an MI355X is rated after 50 ms and needs 0.4 s for the whole database): -p is an
-    // upper bound here, and the host is rated on the groups it did finish (at least one).
+    // upper bound here, and the host is rated on the (group, query) pairs it did finish (at least one).
     double test_gpu_time = 0, test_cpu_time = 0, gpu_gcups = 0;
     uint64_t gpu_done = 0;
     const double tick_test = dwalltime();
     std::atomic<bool> call_off{false}, host_done{false};
-    std::atomic<uint64_t> host_test_residues{0};
+    std::atomic<uint64_t> host_test_cells{0};
     {
         std::vector<int32_t> test_scores(nq * test_groups * W, 0);
         std::thread host_test([&] {
             const double t = dwalltime();
-            cpu_groups(0, test_groups, test_scores.data(), test_groups * W, 0, &call_off, &host_test_residues);
+            cpu_groups(0, test_groups, test_scores.data(), test_groups * W, 0, &call_off, &host_test_cells);
             test_cpu_time = dwalltime() - t;
             host_done.store(true);
         });
@@ -383,8 +383,8 @@ int do_search_hybrid(Options &o)
             gpu_done = g1;
             if (dt >= 0.02) break;
         }
-        // (at least one finished group to rate the host on)
-        while (host_test_residues.load() == 0 && !host_done.load()) {
+        // (at least one finished (group, query) to rate the host on)
+        while (host_test_cells.load() == 0 && !host_done.load()) {
             struct timespec ts = {0, 1000000};
             nanosleep(&ts, nullptr);
             if (dwalltime() - (tick_test + test_gpu_time) > 60.0) break; // (a host that cannot finish one group in a minute is rated 0)
@@ -392,7 +392,7 @@ int do_search_hybrid(Options &o)
         call_off.store(true);
         host_test.join();
     }
-    const double cpu_gcups = q.Q * (double)host_test_residues.load() / (std::max(test_cpu_time, 1e-9) * 1e9);
+    const double cpu_gcups = (double)host_test_cells.load() / (std::max(test_cpu_time, 1e-9) * 1e9); // every (group, query) the host finished
     printf("Test DB percentage:\t\t%.4lf%% \n", o.test_db_percentage);
     printf("CPU estimated speed:\t\t%.2lf GCUPS\n", cpu_gcups);
     printf("FPGA estimated speed:\t\t%.2lf GCUPS\n", gpu_gcups);
@@ -666,7 +666,7 @@ int main(int argc, char *argv[])
         {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (accepted for compatibility) (default: 256).", 3},
         {"num_fpgas", 'f', "<integer>", 0, "Number of GPUs (the reference's number of FPGAs) (default: 1).", 3},
         {"max_chunk_size", 'k', "<integer>", 0, "Maximum chunk size on the accelerator (bytes, default: 134217728).", 3},
-        {"db_percentage", 'p', "<integer>", 0, "Database percentage for testing computational power (hybrid mode only) (default: 0.01).", 3},
+        {"db_percentage", 'p', "<integer>", 0, "Database percentage for testing computational power (hybrid mode only) (default: 0.01).  An upper bound in this build: the host's test is called off once the GPU's is over, and the host is rated on what it finished.", 3},
         {"top", 'r', "<integer>", 0, "Number of scores to show (default: 10).", 3},
         {0}};
     Options o;

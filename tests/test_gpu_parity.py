@@ -699,6 +699,64 @@ def test_process_level_communicator_at_world_size_one(oracle):
             np.testing.assert_array_equal(ix[q], wi)
 
 
+def test_process_level_communicator_two_ranks_on_two_gpus(oracle):
+    """Two ranks of a job, one GPU each, joined by oswald_hip_comm_init_rank (here: two threads of this process, each
+    with a context of its own, where the box has two GPUs; skipped on the one-GPU test box, runs by itself on a
+    multi-GPU node).  Each rank searches half of the database under the dealt shard rule; oswald_hip_topr all-gathers the
+    two lists over RCCL and BOTH ranks must come back with the top r of the whole database in the reference's order."""
+    import threading
+    from oswald_amd import capi, multigpu
+    if capi.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d)" % capi.device_count())
+    qs = synth.make_queries([33, 60, 150], seed=161)
+    NSEQ = 1500
+    L, R, O = random_db(NSEQ, seed=163, max_len=80, queries=qs[-1:], homologs=3)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    bfull, nfull, dfull = dblayout.interleave(sl, sr, so, 16)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    whole = expect(oracle, qs, bfull, nfull, dfull.astype(np.uint32), 16, sm, 10, 2)
+    ident = capi.comm_unique_id()
+    r, out, err = 40, [None, None], [None, None]
+
+    def rank(k):
+        try:
+            pos = multigpu.dealt_positions(NSEQ, 2, k)
+            ls = sl[pos]
+            off = np.zeros(len(pos) + 1, np.int64)
+            np.cumsum(ls, out=off[1:])
+            res = np.concatenate([sr[so[p]:so[p + 1]] for p in pos])
+            b, n, disp = dblayout.interleave(ls, res, off, 16)
+            with capi.Context(1, [k]) as ctx:
+                ctx.comm_init_rank(ident, 2, k)
+                info = ctx.comm_info()
+                assert info["process_ranks"] == 2 and info["process_rank"] == k
+                ctx.set_scoring(sm, 10, 2)
+                ctx.set_queries(a, m, ad)
+                h = ctx.chunk_upload(b, n, disp.astype(np.uint32), 16)
+                ctx.chunk_set_index(h, 0, len(pos), pos)
+                for rep in range(2):
+                    ctx.topr_begin(r)
+                    ctx.chunk_search(h, None)
+                    out[k] = ctx.topr(r)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            err[k] = e
+
+    th = [threading.Thread(target=rank, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a rank hangs in the collective"
+    assert err == [None, None], err
+    for k in range(2):
+        sc, ix = out[k]
+        for q in range(len(qs)):
+            ws, wi = dblayout.topr_reference_order(whole[q, :NSEQ], r)
+            np.testing.assert_array_equal(sc[q], ws)
+            np.testing.assert_array_equal(ix[q], wi)
+
+
 def test_api_misuse_of_the_round3_entry_points(hip_ctx):
     """oswald_hip_topr / _topr_begin / _chunk_set_index / _merge_candidates report misuse through the return code."""
     from oswald_amd import capi

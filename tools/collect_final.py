@@ -12,10 +12,13 @@ for f in sorted(os.listdir(src)):
         if lines:
             with open(os.path.join(dst, f"r{rnd}_{f}"), "w") as o:
                 json.dump(json.loads(lines[-1]), o, indent=1)
-for a, b in (("shard_balance.txt", f"r{rnd}_shard_balance_1gpu.txt"), ("cli_1m.txt", f"r{rnd}_cli_1m_phases.txt"), ("oprate_q8.txt", f"r{rnd}_oprate_q8.txt")):
+for a, b in (("shard_balance.txt", f"r{rnd}_shard_balance_1gpu.txt"), ("cli_1m.txt", f"r{rnd}_cli_1m_phases.txt"), ("oprate_q8.txt", f"r{rnd}_oprate_q8.txt"),
+             ("oprate4.txt", f"r{rnd}_oprate4_valu_issue.txt"), ("q1_tail.txt", f"r{rnd}_q1_c5_tail.txt"), ("startup.txt", f"r{rnd}_cli_startup.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 with open(os.path.join(dst, f"r{rnd}_pytest_gpu_tail.txt"), "w") as o:
     o.write("".join(open(os.path.join(src, "pytest_gpu.log")).readlines()[-3:]))
-for wl, nseq, label in (("c2", "1000000", "c4_1gpu"), ("c3", "100000", "c3_int8"), ("c5", "100000", "c5")):
-    subprocess.check_call([sys.executable, os.path.join(root, "tools", "collect_prof.py"), rnd, wl, nseq, label])
+for wl, nseq, label in (("c2", "1000000", "c4_1gpu"), ("c2", "100000", "c2"), ("c3", "100000", "c3_int8"), ("c5", "100000", "c5"), ("q1", "100000", "q1_100k"), ("q1", "1000000", "q1_1m")):
+    rc = subprocess.call([sys.executable, os.path.join(root, "tools", "collect_prof.py"), rnd, wl, nseq, label])
+    if rc:
+        print(f"collect_final: the rocprofv3 summary of {wl} {nseq} was NOT collected (rc {rc})")

@@ -1,21 +1,36 @@
 #!/bin/bash
-# tools/final_validation.sh -- the round's evidence in one GPU call: the -m gpu suite, the bench lines the documents
-# quote, the multi-rank rehearsal, the shard-balance prediction, rocprofv3 summaries.  Everything lands under
-# gpurun_out/final/ (scratch); tools/collect_final.py copies what is cited into profiles/.
+# tools/final_validation.sh [ROUND] -- the round's evidence in one GPU call: the -m gpu suite, smoke, the bench lines the
+# documents quote, the multi-rank rehearsal, the shard-balance prediction, the escalation workloads, rocprofv3 summaries,
+# the microbenchmarks.  Everything lands under gpurun_out/final/ (scratch); tools/collect_final.py ROUND copies what is
+# cited into profiles/.  The profile passes come FIRST: they write the traffic files of the sources being validated, so
+# that the bench lines behind them carry roofline.traffic.
+R=${1:-04}
 OUT=gpurun_out/final
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
+for spec in "c2 1000000" "c2 100000" "c3 100000" "c5 100000" "q1 100000" "q1 1000000"; do
+  bash tools/profile_gpu.sh $spec > $OUT/prof_$(echo $spec | tr ' ' '_').log 2>&1; echo "profile $spec rc=$?"
+  cp gpurun_out/prof_$(echo $spec | tr ' ' '_')/traffic_*.json profiles/ 2>/dev/null   # (in this box's copy of the tree: bench.py below reads them)
+done
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
-b() { name=$1; shift; python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "bench $name rc=$? $(python -c "import json;d=json.load(open('$OUT/bench_$name.json'));print(d['value'],d['ms_per_step'],d['roofline']['kernel_ms'],d.get('top_equals_single_gpu_golden'))" 2>/dev/null)"; }
+b() { name=$1; shift; python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "bench $name rc=$? $(python -c "import json;l=[x for x in open('$OUT/bench_$name.json').read().split(chr(10)) if x.startswith('{')];d=json.loads(l[-1]);print(d['value'],d['ms_per_step'],d['roofline']['kernel_ms'],d['roofline']['traffic'],d.get('top_equals_single_gpu_golden'))" 2>/dev/null)"; }
 b c4_1gpu --steps 20 --warmup 5
+b c4_1gpu_comm --steps 20 --warmup 5 --comm --cpu-seconds 0
 b c2 --nseq 100000 --steps 20 --warmup 5
 b c3_int8 --workload c3 --steps 10 --warmup 2
 b c3_int16 --workload c3 --cell-bits 16 --steps 20 --warmup 5 --cpu-seconds 0
 b c5 --workload c5 --steps 20 --warmup 5
-b q1 --workload q1 --steps 50 --warmup 10
+b c5_1m --workload c5 --nseq 1000000 --steps 5 --warmup 1 --cpu-seconds 0
+b q1_100k --workload q1 --steps 50 --warmup 10
+b q1_1m --workload q1 --nseq 1000000 --steps 20 --warmup 5 --cpu-seconds 0
+b hi --workload hi --steps 5 --warmup 1 --cpu-seconds 10
+b hi8 --workload hi8 --steps 8 --warmup 2 --cpu-seconds 10
+b c2_int32 --nseq 100000 --cell-bits 32 --steps 3 --warmup 1 --cpu-seconds 0
 OSWALD_BENCH_BACKEND=gloo MASTER_PORT=29641 python bench.py --gpus 4 --steps 5 --warmup 1 --cpu-seconds 0 > $OUT/bench_gloo4.json 2> $OUT/bench_gloo4.err; echo "gloo4 rc=$?"
 OSWALD_BENCH_BACKEND=gloo MASTER_PORT=29642 python bench.py --gpus 4 --shard-rule reference --steps 5 --warmup 1 --cpu-seconds 0 > $OUT/bench_gloo4_reference_rule.json 2> $OUT/bench_gloo4_reference_rule.err; echo "gloo4 reference rule rc=$?"
 python tests/shard_balance_gpu.py 2 4 8 > $OUT/shard_balance.txt 2>&1; echo "shard balance rc=$?"; cat $OUT/shard_balance.txt
-for spec in "c2 1000000" "c3 100000" "c5 100000"; do bash tools/profile_gpu.sh $spec > $OUT/prof_$(echo $spec | tr ' ' '_').log 2>&1; echo "profile $spec rc=$?"; done
+tools/q1_tail.sh > $OUT/q1_tail.txt 2>&1; echo "q1 tail rc=$?"
 timeout -k 10 200 ./tools/oprate_q8 > $OUT/oprate_q8.txt 2>&1
+timeout -k 10 200 ./tools/oprate4 > $OUT/oprate4.txt 2>&1
 python tools/cli_e2e.py 1000000 > $OUT/cli_1m.txt 2>&1; echo "cli e2e rc=$?"; tail -5 $OUT/cli_1m.txt
+tools/startup_probe.sh > $OUT/startup.txt 2>&1
