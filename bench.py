@@ -283,7 +283,7 @@ def main():
         row_cycles = ROW_CYCLES[cell_bits][1 if nq > 1 else 0]
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / row_cycles) * 128.0 / 1e9
         kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
-        traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None)
+        traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None, DTYPE[cell_bits])
         cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1",
                     "hi": "escalation-heavy (int16 -> int32)", "hi8": "escalation-heavy (int8 -> int16)"}[args.workload]
         if cfg_name == "C4" and world == 1:
@@ -329,6 +329,7 @@ def main():
         # (FPGAsearch.c:80 -> :276: uploads + kernels + download of the score table).  The host buffers are pinned
         # (the reference allocates its own 64-byte aligned "for DMA", sequences.h:15, FPGAsearch.c:69-74), and the
         # upload of chunk k+1 is queued while chunk k is being searched (the library's upload stream), as the CLI does.
+        pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=True)    # (untimed: the slots this leg uploads into get their device buffers here, as oswald_hip_reserve / the first chunk of a long run would)
         result["pcie_inclusive"] = pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=True)
         result["pcie_inclusive_pageable"] = pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=False)["gcups"]
         if args.cpu_seconds > 0 and world == 1 and chunks:  # reported at N = 1 only
@@ -403,7 +404,7 @@ def check_top_golden(args, nseq_total, strong, world, top):
     return bool(np.array_equal(np.array(g["scores"])[:, :r], sc[:, :r]) and np.array_equal(np.array(g["index"])[:, :r], ix[:, :r]))
 
 
-def measured_traffic(workload_name, nseq):
+def measured_traffic(workload_name, nseq, dtype=None):
     """HBM bytes per launch of the DP kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
     runs, see tools/profile_gpu.sh and DESIGN.md for the unit and the gfx950 correction) committed under
     profiles/ for this exact workload -- and for THIS kernel source: the summary carries a digest of the
@@ -416,6 +417,8 @@ def measured_traffic(workload_name, nseq):
             t = json.load(f)
     except (OSError, ValueError):
         return None, "no PMC summary committed for this workload"
+    if dtype is not None and t.get("dtype") not in (None, dtype):
+        return None, f"the PMC summary committed for this workload was measured on the {t.get('dtype')} cells"
     if t.get("source_digest") != source_digest():
         print(f"bench.py: {path} was measured on other kernel sources (digest {t.get('source_digest')} != {source_digest()}); "
               "traffic not reported -- re-run tools/profile_gpu.sh", file=sys.stderr, flush=True)

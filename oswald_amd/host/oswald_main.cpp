@@ -630,7 +630,7 @@ int do_search(Options &o)
         }
     }
     const double workTime = dwalltime() - tick;
-    lap("search (timed region)");
+    if (phases) { fprintf(stderr, "[oswald] %-34s %8.3f ms\n", "search (timed region), total", workTime * 1e3); tp = dwalltime(); }
     oswald_hip_finalize(ctx);
     lap("device release");
 
