@@ -329,7 +329,6 @@ def main():
         # (FPGAsearch.c:80 -> :276: uploads + kernels + download of the score table).  The host buffers are pinned
         # (the reference allocates its own 64-byte aligned "for DMA", sequences.h:15, FPGAsearch.c:69-74), and the
         # upload of chunk k+1 is queued while chunk k is being searched (the library's upload stream), as the CLI does.
-        pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=True)    # (untimed: the slots this leg uploads into get their device buffers here, as oswald_hip_reserve / the first chunk of a long run would)
         result["pcie_inclusive"] = pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=True)
         result["pcie_inclusive_pageable"] = pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=False)["gcups"]
         if args.cpu_seconds > 0 and world == 1 and chunks:  # reported at N = 1 only
@@ -348,35 +347,44 @@ def main():
 
 def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned):
     """SURVEY 8(d)'s timed region on rank 0's chunks: H2D of the interleaved chunk + re-tile + search + D2H of the
-    whole int32 score table, chunk k+1 uploading while chunk k is searched."""
+    whole int32 score table, uploads two chunks ahead of the search.  pinned: the host buffers are page-locked memory
+    from the library (oswald_hip_host_alloc), allocated and filled once and used for an untimed pass first -- a
+    long-running caller allocates its DMA buffers once (the reference: posix_memalign, FPGAsearch.c:69-74), and the first
+    DMA through a fresh page-locked allocation, like the first search into a fresh chunk slot, costs milliseconds."""
     from oswald_amd import capi
     keep, bufs, outs = [], [], []
     for c in chunks:
-        if pinned:   # page-locked buffers from the library (oswald_hip_host_alloc), filled before the clock starts
+        if pinned:
             hb = [capi.pinned_copy(c[k]) for k in ("b", "n", "disp")] + [capi.HostBuffer((nq, len(c["n"]) * 16), np.int32)]
             keep += hb
             bufs.append((hb[0].a, hb[1].a, hb[2].a)); outs.append(hb[3].a)
         else:
             bufs.append((c["b"], c["n"], c["disp"])); outs.append(np.zeros((nq, len(c["n"]) * 16), np.int32))
-    ctx.wait()
-    t0 = time.perf_counter()  # (rank 0's chunks; the other ranks idle at the final barrier meanwhile)
-    # two chunks ahead: the copies of chunk k+2 run beside the search of chunk k, its re-tile when that search drains, and
-    # the host plans and queues the search of chunk k+1 meanwhile
-    hs = [ctx.chunk_upload(*bufs[0], 16, wait=False)] if bufs else []
-    for k in range(len(bufs)):
-        ctx.chunk_search(hs[k], outs[k])             # waits for ITS upload only; queued behind the search before it
-        ctx.chunk_release(hs[k])                     # the slot is re-used once the device is through with it
-        for j in ((1, 2) if k == 0 else (k + 2,)):   # (the first search starts as soon as its own upload is in)
-            if j < len(bufs):
-                hs.append(ctx.chunk_upload(*bufs[j], 16, wait=False))
-    ctx.wait()
-    t = time.perf_counter() - t0
+
+    def one_pass():
+        ctx.wait()
+        t0 = time.perf_counter()  # (rank 0's chunks; the other ranks idle at the final barrier meanwhile)
+        # two chunks ahead: the copies of chunk k+2 run beside the search of chunk k, its re-tile when that search drains, and
+        # the host plans and queues the search of chunk k+1 meanwhile
+        hs = [ctx.chunk_upload(*bufs[0], 16, wait=False)] if bufs else []
+        for k in range(len(bufs)):
+            ctx.chunk_search(hs[k], outs[k])             # waits for ITS upload only; queued behind the search before it
+            ctx.chunk_release(hs[k])                     # the slot is re-used once the device is through with it
+            for j in ((1, 2) if k == 0 else (k + 2,)):   # (the first search starts as soon as its own upload is in)
+                if j < len(bufs):
+                    hs.append(ctx.chunk_upload(*bufs[j], 16, wait=False))
+        ctx.wait()
+        return time.perf_counter() - t0
+
+    one_pass()          # untimed: device buffers of the slots, first DMA through the host buffers
+    t = min(one_pass(), one_pass())
     pcie_inclusive.last_scores = [np.array(o) for o in outs] if pinned else outs   # (the pinned buffers go back to the library)
     for hb in keep:
         hb.close()
     return {"gcups": round(sum_m * d_local / t / 1e9, 1), "ms": round(t * 1e3, 2),
             "what": "SURVEY 8(d)'s timed region on rank 0's chunks (reference FPGAsearch.c:80-276): H2D of the interleaved chunk + re-tile + search + D2H of "
-                    "all int32 scores; uploads two chunks ahead of the search; " + ("page-locked host buffers (oswald_hip_host_alloc)" if pinned else "pageable host memory")}
+                    "all int32 scores; uploads two chunks ahead of the search; best of two passes behind an untimed one; "
+                    + ("page-locked host buffers (oswald_hip_host_alloc)" if pinned else "pageable host memory")}
 
 
 def golden_path(args, nseq_total):

@@ -15,5 +15,5 @@ env = dict(os.environ, OSWALD_DEBUG_PHASES="1")
 for label, extra in (("group cache", {}), ("interleave from .seq", {"OSWALD_NO_GROUP_CACHE": "1"})):
     t = time.time(); p = subprocess.run([cli, "-O", "search", "-m", "0", "-q", f"{tmp}/q.fasta", "-d", f"{tmp}/db"], capture_output=True, text=True, env=dict(env, **extra)); print(f"search wall ({label})", round(time.time()-t,2), "s rc", p.returncode)
     print(p.stderr)
-print("\n".join(l for l in p.stdout.split("\n") if l.startswith(("Search time", "Search speed", "Database size"))))
+    print("\n".join(l for l in p.stdout.split("\n") if l.startswith(("Search time", "Search speed", "Database size"))))
 print(p.stdout.split("Query no.")[1][:400] if "Query no." in p.stdout else p.stderr[-500:])
