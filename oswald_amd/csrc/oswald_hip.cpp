@@ -796,7 +796,7 @@ int oswald_hip_host_alloc(size_t bytes, void **ptr)
     if (!ptr) return fail(OSWALD_HIP_EINVAL, "null out-pointer");
     *ptr = nullptr;
     if (bytes == 0) return 0;
-    HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocPortable));
     return 0;
 }
 
@@ -1071,7 +1071,7 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
         c.sub_cols = nullptr;
         c.sub_cols_cap = 0;
         const size_t want = (size_t)c.nblocks * 128 + (size_t)c.nblocks * 16 + 128;
-        HIP_TRY(hipHostMalloc((void **)&c.sub_cols, want * sizeof(uint16_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&c.sub_cols, want * sizeof(uint16_t), hipHostMallocPortable));
         c.sub_cols_cap = want;
     }
     HIP_TRY(c.st_b.reserve(vD + 64));
@@ -1082,7 +1082,7 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
         c.blocks_pin = nullptr;
         c.blocks_pin_cap = 0;
         const size_t want = (size_t)c.nblocks + c.nblocks / 8 + 16;
-        HIP_TRY(hipHostMalloc((void **)&c.blocks_pin, want * sizeof(OswBlock), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&c.blocks_pin, want * sizeof(OswBlock), hipHostMallocPortable));
         c.blocks_pin_cap = want;
     }
     if (c.nblocks) memcpy(c.blocks_pin, blocks.data(), c.nblocks * sizeof(OswBlock));
@@ -1406,7 +1406,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         (void)hipGetLastError(); // (an unknown -- pageable -- pointer is reported as an error by some runtimes)
         if (bytes >= (1u << 20) && !ctx->tun.no_pin && !pinned_already) {
             const auto t0 = std::chrono::steady_clock::now();
-            if (hipHostRegister(scores_out, bytes, hipHostRegisterDefault) == hipSuccess) d.registered.push_back(scores_out);
+            if (hipHostRegister(scores_out, bytes, hipHostRegisterPortable) == hipSuccess) d.registered.push_back(scores_out);
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (ms > 5.0 && g_debug_slow) fprintf(stderr, "[oswald_hip] slow hipHostRegister: %zu bytes took %.1f ms\n", bytes, ms);
             else (void)hipGetLastError(); // e.g. already pinned by the caller: the plain copy below is still correct
@@ -1586,6 +1586,7 @@ int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *
         NCCL_TRY(ncclGroupStart());
         for (Device &d : ctx->dev) {
             if (d.comm_rank < 0) continue;
+            (void)hipSetDevice(d.id);
             const ncclResult_t nr = ncclAllGather(d.top_run[d.top_cur].p, d.top_gather.p, cnt, ncclUint64, d.comm, d.stream);
             if (nr != ncclSuccess) { (void)ncclGroupEnd(); return fail(OSWALD_HIP_ECOMM, "ncclAllGather (GPU %d): %s", d.id, ncclGetErrorString(nr)); }
         }
@@ -1608,7 +1609,7 @@ int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *
         if (ctx->top_host) (void)hipHostFree(ctx->top_host);
         ctx->top_host = nullptr;
         ctx->top_host_bytes = 0;
-        HIP_TRY(hipHostMalloc(&ctx->top_host, out_cnt * 8, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&ctx->top_host, out_cnt * 8, hipHostMallocPortable));
         ctx->top_host_bytes = out_cnt * 8;
     }
     HIP_TRY(osw_launch_topr_untag((const key_t *)root.top_run[root.top_cur].p, nq, R, r, (int32_t *)root.top_final.p, (uint32_t *)root.top_final.p + out_cnt, root.stream));
