@@ -654,6 +654,34 @@ def test_context_level_topr_over_chunks_and_devices(oracle, dealt, two_devices):
     assert len(np.unique(whole[0, :NSEQ])) < NSEQ // 4   # ties are present
 
 
+@pytest.mark.parametrize("qlens", [[4300], [6100, 1500], [2990, 5000, 3700]])
+def test_int32_rerun_pipeline_over_many_long_items(hip_ctx, oracle, qlens):
+    """The int32 re-run as a workgroup pipeline (osw_sw_i32, round 4): wave w of a workgroup runs rounds w, w+4, ... of ONE
+    (query, sequence), the boundary row going from wave to wave through the spill scratch.  Near-copies of long queries
+    (self-scores 16 000 .. 33 000: beyond the column-frame cell's 22 256, some beyond the plain cell's 30 576), next to
+    each other in the sorted database so that both sequences of a lane pair and several lanes of a block are re-run,
+    queries of 12 .. 24 rounds (not multiples of four), shorter sequences around them; every score against the AVX2 port
+    (int8 -> int16 -> int32 like the reference's host path)."""
+    qs = synth.make_queries(qlens, seed=171)
+    rng = np.random.default_rng(173)
+    seqs = [synth.random_residues(9000 + i, 0, int(l)) for i, l in enumerate(rng.integers(30, 900, size=150))]
+    k = 0
+    for q in qs:
+        for rate in (0.0, 0.02, 0.05, 0.10, 0.20, 0.35):
+            for cut in (0, 137):                      # whole copies and copies that lack their first residues
+                seqs.append(synth.mutate(np.asarray(q[cut:], np.uint8), rate, 4242 + k))
+                k += 1
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 32, round_to=1)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 32, sm, 10, 2, resident=True)
+    a, m, ad = pack_queries(qs)
+    want, stage = oracle.search_chunk_simd(a, m, ad, b, n, disp, 32, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    if max(qlens) >= 6000:      # beyond the ceiling of either int16 cell: the int32 tier ran
+        assert want.max() > 30576 and hip_ctx.rerun_counts()[1] >= 1
+
+
 def test_process_level_communicator_at_world_size_one(oracle):
     """oswald_hip_comm_unique_id / _comm_init_rank / _comm_info: the gather of a multi-process job (one rank per GPU;
     SURVEY 8e) runs inside the C ABI -- ncclCommInitRank, then every oswald_hip_topr all-gathers the ranks' lists and
