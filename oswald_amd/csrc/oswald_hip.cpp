@@ -877,6 +877,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_i32(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_i32r(a, 8, d.stream);
             if (r == hipSuccess) r = osw_launch_q8(a, 1, d.stream);
             if (r == hipSuccess) r = hipStreamSynchronize(d.stream);
             scratch.release();
@@ -1328,7 +1329,9 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         HIP_TRY(launch_single(as, grid, d.stream));
     }
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.d, d.stream));
-    HIP_TRY(osw_launch_i32(a, std::min<uint32_t>(d.grid, 1024u), d.stream));
+    // cell_bits 32: the whole plan on the int32 kernel; else: the re-run of what reached the int16 cells' ceiling (queue on the device)
+    if (ctx->cell_bits == 32) HIP_TRY(osw_launch_i32(a, std::min<uint32_t>(d.grid, 1024u), d.stream));
+    else HIP_TRY(osw_launch_i32r(a, d.grid * (OSW_WG_THREADS / 64), d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
     if (int r = topr_after_search(ctx, d, c)) return r;

@@ -140,6 +140,7 @@ struct OswSearchArgs {
 // host-side launchers, defined in sw_kernels.hip
 hipError_t osw_launch_pk16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_i32r(const OswSearchArgs &a, uint32_t regions, hipStream_t s); // the re-run queue: workgroups of eight waves, one item each
 hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);

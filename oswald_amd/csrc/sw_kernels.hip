@@ -1256,31 +1256,53 @@ static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, u
     const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
     uint32_t hand_h = 0, hand_f = 0, hand_c = dummy;
     const uint32_t nsteps = ncols + G - 1;
+    // The inputs of a step -- the column's residues and, behind a first round, the boundary entry of the round before --
+    // are loaded OSW_PIPE_AHEAD steps ahead: a re-run item has one wave per SIMD (its workgroup is alone on its CU more
+    // often than not), so nothing else hides the latency of a load issued in the step that needs it (20 ms for the 133
+    // items of bench.py --workload hi, four times what the instructions take).
+    constexpr uint32_t AHEAD = 4;
+    static_assert(OSW_PIPE_BATCH % AHEAD == 0, "a batch is whole groups of prefetched steps");
+    uint32_t cq[AHEAD];
+    uint2 bq[AHEAD];
+    auto wait_for = [&](uint32_t cols) { // columns 0 .. cols-1 of round rho - 1 (published under the tag rho) are stored and visible
+        const uint32_t need = (rho << 20) | (cols < ncols ? cols : ncols);
+        while (*prog_src < need) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto load_step = [&](uint32_t t, uint32_t &c, uint2 &bb) {
+        c = dummy;
+        bb = make_uint2(0u, 0u);
+        if (t < ncols) {
+            c = tb[(size_t)t * 64];
+            if (!first) bb = colr[(size_t)t * gl];
+        }
+    };
+    if (!first) wait_for(AHEAD);
+#pragma unroll
+    for (uint32_t k = 0; k < AHEAD; ++k) load_step(k, cq[k], bq[k]);
 #pragma unroll 1
     for (uint32_t t0 = 0; t0 < nsteps; t0 += OSW_PIPE_BATCH) {
         const uint32_t t1 = t0 + OSW_PIPE_BATCH < nsteps ? t0 + OSW_PIPE_BATCH : nsteps;
-        if (!first) {
-            // the batch reads the boundary columns t0 .. min(t1, ncols) - 1 of round rho - 1 (published under the tag rho)
-            const uint32_t need = (rho << 20) | (t1 < ncols ? t1 : ncols);
-            while (*prog_src < need) __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
+        if (!first) wait_for(t1 + AHEAD); // the batch consumes columns < t1 and loads ahead up to column t1 + AHEAD - 1
 #pragma unroll 1
-        for (uint32_t t = t0; t < t1; ++t) {
-            uint32_t codes = dummy, topb = 0, fb = 0;
-            if (t < ncols) {
-                codes = tb[(size_t)t * 64];
-                if (!first) { const uint2 b = colr[(size_t)t * gl]; topb = b.x; fb = b.y; }
-            }
-            if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
-            int f = (int)fb, hl;
-            C::template column<R>(base, codes, half, D, E, top_prev, f, hl, goe, ge, score);
-            top_prev = (int)topb;
-            if (!last && t + 1 >= G && glast) colw[(size_t)(t + 1 - G) * gl] = make_uint2((uint32_t)hl, (uint32_t)f);
-            if (G > 1) {
-                hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, hl);
-                hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, f);
-                hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
+        for (uint32_t tg = t0; tg < t1; tg += AHEAD) {
+#pragma unroll
+            for (uint32_t k = 0; k < AHEAD; ++k) {
+                const uint32_t t = tg + k;
+                if (t < t1) {
+                    uint32_t codes = cq[k], topb = bq[k].x, fb = bq[k].y;
+                    load_step(t + AHEAD, cq[k], bq[k]);
+                    if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
+                    int f = (int)fb, hl;
+                    C::template column<R>(base, codes, half, D, E, top_prev, f, hl, goe, ge, score);
+                    top_prev = (int)topb;
+                    if (!last && t + 1 >= G && glast) colw[(size_t)(t + 1 - G) * gl] = make_uint2((uint32_t)hl, (uint32_t)f);
+                    if (G > 1) {
+                        hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, hl);
+                        hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, f);
+                        hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
+                    }
+                }
             }
         }
         if (!last) {
@@ -1292,6 +1314,7 @@ static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, u
 }
 
 // one (query, sequence half) on the workgroup: -> the score, valid in the lanes of group 0 of EVERY wave
+template <int NW> // waves of the workgroup = depth of the pipeline
 static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma, uint32_t lg,
                                                         int lane, int wv, int half, uint2 *lds_wave, uint2 *bnd_wg, volatile uint32_t *prog, int *red)
 {
@@ -1303,11 +1326,11 @@ static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, 
     const OswPlan plan = osw_plan(p.qlen[q], G, C::kLdsRows, C::kRows);
     const uint2 *prof_q = p.prof + (size_t)p.prof_off[q] * 32u;
     uint2 *mine = (uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)wv * p.bnd_stride));
-    const uint2 *prev = (const uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)((wv + 3) & 3) * p.bnd_stride));
+    const uint2 *prev = (const uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)((wv + NW - 1) % NW) * p.bnd_stride));
     if (lane == 0) prog[wv] = 0;
     __syncthreads();
     int score = 0;
-    for (uint32_t rho = (uint32_t)wv; rho < plan.rounds; rho += OSW_WG_THREADS / 64) {
+    for (uint32_t rho = (uint32_t)wv; rho < plan.rounds; rho += NW) {
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
         __builtin_amdgcn_wave_barrier();
         fill_profile_slice<uint2>(prof_q, rb0, R / 4, G, rb_end, lds_wave, (uint32_t)lane, 64u);
@@ -1315,7 +1338,7 @@ static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, 
         __builtin_amdgcn_wave_barrier();
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_wave + g * (R * C::kRowBytes + (uint32_t)sizeof(uint2)));
         const bool first = rho == 0, last = rho + 1 == plan.rounds;
-        volatile uint32_t *ps = prog + ((wv + 3) & 3), *pm = prog + wv;
+        volatile uint32_t *ps = prog + ((wv + NW - 1) % NW), *pm = prog + wv;
         switch (R) {
         case 4: sw_round_pipe_i32<4>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
         case 8: sw_round_pipe_i32<8>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
@@ -1333,7 +1356,7 @@ static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, 
     red[wv * 64 + lane] = score;
     __syncthreads();
     int best = red[lane];
-    for (int w = 1; w < OSW_WG_THREADS / 64; ++w) best = red[w * 64 + lane] > best ? red[w * 64 + lane] : best;
+    for (int w = 1; w < NW; ++w) best = red[w * 64 + lane] > best ? red[w * 64 + lane] : best;
     __syncthreads(); // (red and prog are free for the next item)
     return best;
 }
@@ -1351,36 +1374,8 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
     uint2 *lds_wave = lds_prof[wv];
-    // the queue length was produced by the previous kernel on this stream
-    const uint32_t nitems = p.force_all ? p.nitems : p.counters_ovf[0];
-    const uint2 *items = p.force_all ? p.items + (size_t)p.nitems_wg * 4 : p.ovf_items;
-
-    if (!p.force_all) {
-        // the re-run queue: few, long items -- a workgroup per item, its four waves a pipeline over the item's rounds
-        __shared__ uint32_t prog[OSW_WG_THREADS / 64];
-        __shared__ uint32_t wg_it;
-        __shared__ int red[OSW_WG_THREADS];
-        uint2 *bnd_wg = p.bnd + (size_t)blockIdx.x * (OSW_WG_THREADS / 64) * p.bnd_stride;
-        for (;;) {
-            if (threadIdx.x == 0) wg_it = atomicAdd(&p.counters[OSW_CTR_WORK32], 1u);
-            __syncthreads();
-            const uint32_t it = wg_it;
-            __syncthreads();
-            if (it >= nitems) break;
-            const uint2 item = items[it];
-            const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
-            const uint32_t hm = OSW_ITEM_HALVES(item.x);
-            const OswBlock blk = p.blocks[B];
-            const uint32_t gl = 64u >> lg;
-            for (int half = 0; half < 2; ++half) {
-                if (!((hm >> half) & 1u)) continue;
-                const int score = run_item_i32_pipe(p, q, B, blk, sigma, lg, lane, wv, half, lds_wave, bnd_wg, prog, red);
-                if (wv == 0 && (uint32_t)lane < gl)
-                    p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
-            }
-        }
-        return;
-    }
+    const uint32_t nitems = p.nitems;                  // cell_bits = 32: the item list of the plan (wave items)
+    const uint2 *items = p.items + (size_t)p.nitems_wg * 4;
     for (;;) {
         uint32_t it = 0;
         if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK32], 1u);
@@ -1395,6 +1390,43 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearc
             if (!((hm >> half) & 1u)) continue;
             const int score = run_item<CellI32>(p, p.prof, q, B, blk, sigma, lg, lane, half, false, lds_wave, bnd_wave, p.goe, p.ge);
             if ((uint32_t)lane < gl)
+                p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
+        }
+    }
+}
+
+// The re-run queue of a search (what reached the int16 cells' ceiling): few, long items -- a workgroup of EIGHT waves per
+// item, a pipeline over the item's rounds (sw_round_pipe_i32); two waves per SIMD hide each other's latencies.  The queue
+// length was produced by the kernels before it on this stream.  Wave w of workgroup b uses spill region 8 b + w: the grid
+// is at most an eighth of the regions (osw_launch_i32r).
+#define OSW_I32R_WAVES 8
+extern "C" __global__ __launch_bounds__(OSW_I32R_WAVES * 64) void osw_sw_i32r(OswSearchArgs p)
+{
+    extern __shared__ uint2 lds_dyn[]; // OSW_I32R_WAVES profile slices of OSW_LDS_ROWS32 rows (139 KB: above the static limit)
+    __shared__ uint32_t prog[OSW_I32R_WAVES];
+    __shared__ uint32_t wg_it;
+    __shared__ int red[OSW_I32R_WAVES * 64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint2 *lds_wave = lds_dyn + (size_t)wv * (OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8);
+    uint2 *bnd_wg = p.bnd + (size_t)blockIdx.x * OSW_I32R_WAVES * p.bnd_stride;
+    const uint32_t nitems = p.counters_ovf[0];
+    const uint2 *items = p.ovf_items;
+    for (;;) {
+        if (threadIdx.x == 0) wg_it = atomicAdd(&p.counters[OSW_CTR_WORK32], 1u);
+        __syncthreads();
+        const uint32_t it = wg_it;
+        __syncthreads();
+        if (it >= nitems) break;
+        const uint2 item = items[it];
+        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y;
+        const uint32_t hm = OSW_ITEM_HALVES(item.x);
+        const OswBlock blk = p.blocks[B];
+        const uint32_t gl = 64u >> lg;
+        for (int half = 0; half < 2; ++half) {
+            if (!((hm >> half) & 1u)) continue;
+            const int score = run_item_i32_pipe<OSW_I32R_WAVES>(p, q, B, blk, sigma, lg, lane, wv, half, lds_wave, bnd_wg, prog, red);
+            if (wv == 0 && (uint32_t)lane < gl)
                 p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
         }
     }
@@ -1846,6 +1878,20 @@ hipError_t osw_launch_build_pair_profile8(const uint2 *prof, const uint32_t *pro
 hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 {
     hipLaunchKernelGGL(osw_sw_i32, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// the re-run of the int32 queue: `regions` spill regions exist on the device (one per wave of a DP launch, two launches)
+hipError_t osw_launch_i32r(const OswSearchArgs &a, uint32_t regions, hipStream_t s)
+{
+    static const size_t lds = (size_t)OSW_I32R_WAVES * (OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8) * sizeof(uint2);
+    static hipError_t attr = hipFuncSetAttribute((const void *)osw_sw_i32r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return attr;
+    uint32_t grid = regions / OSW_I32R_WAVES;
+    if (grid > 512u) grid = 512u;
+    if (grid == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(osw_sw_i32r, dim3(grid), dim3(OSW_I32R_WAVES * 64), lds, s, a);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }
