@@ -1034,8 +1034,16 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
             return fail(OSWALD_HIP_EINVAL, "group %u runs past the chunk (disp %u + %u*%u > %llu)", g, disp[g], n[g], W, (unsigned long long)vD);
     Device &d = ctx->dev[dev];
     HIP_TRY(hipSetDevice(d.id));
+    // A free slot whose buffers are large enough already (the smallest such), else a new one: growing a buffer frees the
+    // old one, and hipFree waits for the device -- i.e. for whatever search is running beside this upload.
     int slot = -1;
-    for (size_t i = 0; i < d.chunks.size(); ++i) if (!d.chunks[i].live && !d.chunks[i].upload_pending) { slot = (int)i; break; }
+    for (size_t i = 0; i < d.chunks.size(); ++i) {
+        const Chunk &k = d.chunks[i];
+        if (k.live || k.upload_pending || k.st_b.cap < vD + 64) continue;
+        if (slot < 0 || k.st_b.cap < d.chunks[slot].st_b.cap) slot = (int)i;
+    }
+    if (slot < 0)
+        for (size_t i = 0; i < d.chunks.size(); ++i) if (!d.chunks[i].live && !d.chunks[i].upload_pending && !d.chunks[i].st_b.p) { slot = (int)i; break; } // (never used)
     if (slot < 0) { d.chunks.emplace_back(); slot = (int)d.chunks.size() - 1; }
     Chunk &c = d.chunks[slot];
     PhaseTimer pt(ctx->tun.debug_phases);
@@ -1537,6 +1545,9 @@ int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r)
             if (bytes > d.top_run[k].cap) HIP_TRY(hipStreamSynchronize(d.stream)); // (growing frees the old list: nothing may still be reading it)
             HIP_TRY(d.top_run[k].reserve(bytes));
         }
+        // the candidates of a chunk's partitions (at most 64 per score row), sized once: growing it behind a launched search
+        // would wait for that search (hipFree)
+        HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * 64 * r * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(d.top_run[0].p, 0, bytes, d.stream)); // key 0 = none; ordered behind whatever still reads the old list
     }
     ctx->topr_r = r;

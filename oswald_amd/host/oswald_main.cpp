@@ -516,6 +516,51 @@ std::vector<std::vector<Piece>> dealt_pieces(const oswald::Database &db, unsigne
     return per_dev;
 }
 
+// The first piece of a device is what nothing can hide: its upload, its re-tile and the planning of its search all happen
+// before the device has anything to do (7 ms of a 349-ms search at 1 M sequences).  A piece of more than 32 MiB is
+// therefore cut into a head of about a twelfth of its bytes -- whole 128-sequence blocks; in a sorted database its
+// shortest sequences, a search of ~10 ms -- and the rest, which comes in and is planned while the head is searched.
+void split_first_piece(std::vector<Piece> &v)
+{
+    // (OSWALD_SPLIT_FIRST_PIECE_BYTES: the size from which a first piece is cut; a test hook -- the test databases are small)
+    const char *env = getenv("OSWALD_SPLIT_FIRST_PIECE_BYTES");
+    const uint64_t min_bytes = env ? strtoull(env, nullptr, 10) : (32ull << 20);
+    if (v.empty() || v[0].bytes < min_bytes || v[0].ngroups < 24) return;
+    const uint64_t W = oswald::kFpgaVectorLength;
+    const Piece &p = v[0];
+    uint32_t g = 0;
+    while (g + 8 < p.ngroups && p.disp[g] < p.bytes / 12) g += 8;
+    if (g == 0 || g + 8 >= p.ngroups) return;
+    const uint64_t head_seqs = (uint64_t)g * W;
+    if (head_seqs >= p.nvalid) return; // (cannot happen in a sorted database: the padding lanes are at the very end)
+    Piece head, rest;
+    head.b = p.b; head.bytes = p.disp[g]; head.n = p.n; head.disp = p.disp; head.ngroups = g;
+    rest.b = p.b + p.disp[g]; rest.bytes = p.bytes - p.disp[g]; rest.n = p.n + g; rest.ngroups = p.ngroups - g;
+    rest.owned_disp.resize(rest.ngroups);
+    for (uint32_t k = 0; k < rest.ngroups; ++k) rest.owned_disp[k] = p.disp[g + k] - p.disp[g];
+    head.first_index = p.first_index; head.nvalid = (uint32_t)head_seqs;
+    rest.first_index = p.first_index + (uint32_t)head_seqs; rest.nvalid = p.nvalid - (uint32_t)head_seqs;
+    if (!p.index_map.empty()) {
+        head.index_map.assign(p.index_map.begin(), p.index_map.begin() + head_seqs);
+        rest.index_map.assign(p.index_map.begin() + head_seqs, p.index_map.end());
+    }
+    // (the residues stay where they are: in the mapped cache, or in the piece's own buffer, which moves into `rest`)
+    Piece old = std::move(v[0]);
+    rest.owned_b = std::move(old.owned_b);
+    rest.owned_n = std::move(old.owned_n);
+    const std::vector<uint32_t> old_disp = std::move(old.owned_disp);
+    if (!old_disp.empty()) { // the head's displacements were the old piece's own vector: keep a copy of its first g entries
+        head.owned_disp.assign(old_disp.begin(), old_disp.begin() + g);
+        head.disp = nullptr;
+    }
+    v[0] = std::move(rest);
+    v.insert(v.begin(), std::move(head));
+    // pointers into moved vectors: moving a std::vector keeps its buffer, so b / n still point at the residues / lengths;
+    // the displacement tables are re-pointed here
+    v[0].disp = v[0].owned_disp.empty() ? v[0].disp : v[0].owned_disp.data();
+    v[1].disp = v[1].owned_disp.data();
+}
+
 int do_search(Options &o)
 {
     if (o.execution_mode == 2) return do_search_host_only(o);
@@ -554,6 +599,7 @@ int do_search(Options &o)
     std::vector<std::vector<Piece>> pieces;
     if (device_top) {
         pieces = o.num_devices > 1 ? dealt_pieces(db, o.num_devices, o.max_chunk_size, std::max(o.cpu_threads, 1)) : contiguous_pieces(db);
+        for (auto &v : pieces) split_first_piece(v);
         lap("deal blocks to the devices");
     }
     std::vector<int32_t> scores;
@@ -591,8 +637,12 @@ int do_search(Options &o)
             }
             lap("  queue uploads of a round");
         };
-        // the first search starts as soon as its own upload is in; the uploads of the next two rounds follow while it runs
-        upload(0);
+        // The first search starts as soon as its own upload is in.  Behind the search of round k the upload of round k+1
+        // is queued if it is not yet, and -- from the second round on, when a search of full length is running -- that of
+        // round k+2 (with pageable sources an upload call holds the host for the milliseconds of its staging: behind the
+        // short head search only the one upload the next search waits for).
+        size_t next_up = 0;
+        upload(next_up++);
         for (size_t k = 0; k < rounds; ++k) {
             std::vector<int> &cur = h[k % 3];
             for (unsigned d = 0; d < pieces.size(); ++d)
@@ -600,8 +650,8 @@ int do_search(Options &o)
             lap("  queue searches of a round");
             for (unsigned d = 0; d < pieces.size(); ++d)
                 if (cur[d] >= 0) check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release"); // (the upload has landed; the device re-uses the slot when it is through with it)
-            if (k == 0 && rounds > 1) upload(1);
-            if (k + 2 < rounds) upload(k + 2);
+            const size_t ahead = k == 0 ? k + 1 : k + 2;
+            while (next_up <= ahead && next_up < rounds) upload(next_up++);
         }
         // top lists of all queries (inside the timed region: they stand for the download of the score table)
         std::vector<int32_t> ms(nq * o.top);

@@ -154,6 +154,19 @@ def test_cli_several_devices_deal_the_database(tmp_path, ids):
         assert len(a) == 4 and all(len(x["hits"]) == int(r) for x in a)
         assert a == b
         assert f"Number of FPGAs:\t\t{ndev}\n" in many.stdout
+    # ... and with every device's first piece cut into a head and the rest (what the tool does from 32 MiB on, so that the
+    # rest comes in while the head is searched): the same report, with one device and with several
+    cut = dict(os.environ, OSWALD_SPLIT_FIRST_PIECE_BYTES="20000", OSWALD_DEBUG_PHASES="1")
+    one_cut = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-r", "15"] + common, capture_output=True, text=True, env=cut)
+    many_cut = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-r", "15", "-f", str(ndev)] + common, capture_output=True, text=True,
+                              env=dict(cut, OSWALD_DEVICE_IDS=ids))
+    ref15 = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-r", "15"] + common, capture_output=True, text=True)
+    assert one_cut.returncode == 0 and many_cut.returncode == 0, one_cut.stderr + many_cut.stderr
+    assert parse_report(one_cut.stdout) == parse_report(ref15.stdout) == parse_report(many_cut.stdout)
+    # (one more round of searches than without the cut: the head)
+    assert one_cut.stderr.count("queue searches of a round") == subprocess.run(
+        [hostlib.CLI, "-O", "search", "-m", "0", "-r", "15"] + common, capture_output=True, text=True,
+        env=dict(os.environ, OSWALD_DEBUG_PHASES="1")).stderr.count("queue searches of a round") + 1
 
 
 def test_cli_chunk_size_is_clamped_to_device_memory(tmp_path):
