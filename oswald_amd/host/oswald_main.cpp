@@ -429,7 +429,19 @@ struct Piece {
     const uint32_t *disp = nullptr;
     uint32_t ngroups = 0, first_index = 0, nvalid = 0;
     std::vector<uint32_t> index_map;          // dealt pieces: database index of every sequence (not one contiguous run)
-    std::vector<uint8_t> owned_b;             // dealt pieces: their groups copied together
+    // dealt pieces: their groups copied together, in page-locked memory from the library (oswald_hip_host_alloc: the
+    // upload of a piece is then plain asynchronous DMA and its call returns at once -- with N devices driven by one
+    // thread, N pageable uploads would be staged one after the other before the last device gets its search)
+    struct PinnedBytes {
+        uint8_t *p = nullptr;
+        PinnedBytes() = default;
+        PinnedBytes(const PinnedBytes &) = delete;
+        PinnedBytes &operator=(const PinnedBytes &) = delete;
+        PinnedBytes(PinnedBytes &&o) noexcept : p(o.p) { o.p = nullptr; }
+        PinnedBytes &operator=(PinnedBytes &&o) noexcept { if (this != &o) { release(); p = o.p; o.p = nullptr; } return *this; }
+        ~PinnedBytes() { release(); }
+        void release() { if (p) (void)oswald_hip_host_free(p); p = nullptr; }
+    } owned_b;
     std::vector<uint16_t> owned_n;
     std::vector<uint32_t> owned_disp;
 };
@@ -494,7 +506,7 @@ std::vector<std::vector<Piece>> dealt_pieces(const oswald::Database &db, unsigne
                 bytes += gb;
                 ++k;
             }
-            p.owned_b.resize(bytes);
+            { void *mem = nullptr; check(oswald_hip_host_alloc(bytes, &mem), "page-locked piece buffer"); p.owned_b.p = (uint8_t *)mem; }
             for (size_t i = k0; i < k; ++i) {
                 const uint64_t g = gl[i];
                 p.owned_n.push_back(groups[g].n);
@@ -508,11 +520,11 @@ std::vector<std::vector<Piece>> dealt_pieces(const oswald::Database &db, unsigne
             p.bytes = bytes;
             // copy the groups together (the units are contiguous runs of the mapped cache)
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
-            for (long g = 0; g < (long)p.ngroups; ++g) memcpy(p.owned_b.data() + p.owned_disp[g], groups[gl[k0 + g]].b, (size_t)p.owned_n[g] * W);
+            for (long g = 0; g < (long)p.ngroups; ++g) memcpy(p.owned_b.p + p.owned_disp[g], groups[gl[k0 + g]].b, (size_t)p.owned_n[g] * W);
             per_dev[d].push_back(std::move(p));
         }
     }
-    for (auto &v : per_dev) for (Piece &p : v) { p.b = p.owned_b.data(); p.n = p.owned_n.data(); p.disp = p.owned_disp.data(); }
+    for (auto &v : per_dev) for (Piece &p : v) { p.b = p.owned_b.p; p.n = p.owned_n.data(); p.disp = p.owned_disp.data(); }
     return per_dev;
 }
 

@@ -17,7 +17,8 @@ def source_digest():
     return h.hexdigest()[:16]
 
 DP = ("osw_sw_s16q", "osw_sw_s16", "osw_sw_pk16q", "osw_sw_pk16", "osw_sw_q8")  # first-pass DP kernels (int16 cells; 8-bit cells + their int16 re-run)
-KERNELS = DP + ("osw_sw_i32", "osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
+RERUN32 = ("osw_sw_i32r", "osw_sw_i32")   # the int32 re-run of a search (round 4: its own kernel, workgroups of eight waves); cell_bits 32 runs osw_sw_i32
+KERNELS = DP + RERUN32 + ("osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
 
 
 def find(sub, pattern):
@@ -46,7 +47,9 @@ if f:
 f = find("stats", "*kernel_trace.csv")
 if f:
     # the library launches every kernel once on empty queues at bring-up (one workgroup): not part of a search
-    allrows = [r for r in csv.DictReader(open(f)) if int(r.get("Grid_Size_X", "0") or 0) > 256 or not r.get("Kernel_Name", "").startswith("osw_sw_")]
+    def one_workgroup(r):
+        return int(r.get("Grid_Size_X", "0") or 0) <= int(r.get("Workgroup_Size_X", "256") or 256)
+    allrows = [r for r in csv.DictReader(open(f)) if not (r.get("Kernel_Name", "").startswith("osw_sw_") and one_workgroup(r))]
     def kname(r):
         return r.get("Kernel_Name", "").split("(")[0].strip()
     for kn in DP:
@@ -57,14 +60,21 @@ if f:
                                       "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"), "lds": rows[0].get("LDS_Block_Size")}
     # one search step = the pair launch and the single-query launch side by side (two streams) + the int32 re-run:
     # span from the first start to the last end of the k-th dispatches
-    dp = {kn: sorted([r for r in allrows if kname(r) == kn], key=lambda r: int(r["Start_Timestamp"])) for kn in DP + ("osw_sw_i32",)}
-    nstep = len(dp["osw_sw_i32"])
+    dp = {kn: sorted([r for r in allrows if kname(r) == kn], key=lambda r: int(r["Start_Timestamp"])) for kn in DP + RERUN32}
+    nstep = max(len(dp[kn]) for kn in RERUN32)   # every chunk search ends with one launch of the re-run kernel
+    # the launches of the TIMED steps only: bench.py runs its warm-up steps first and its upload-inclusive passes last
+    # (searches into fresh slots, uploads beside them), and times neither with its HIP events
+    b0 = bench_line("stats")
+    k0, k1 = 0, nstep
+    if b0:
+        per_step = int(round(b0["roofline"].get("launches_per_step") or 1))
+        k0, k1 = per_step * int(b0["warmup"]), min(nstep, per_step * (int(b0["warmup"]) + int(b0["steps"])))
     spans = []
-    for k in range(nstep):
+    for k in range(k0, k1):
         rs = [dp[kn][k] for kn in dp if len(dp[kn]) == nstep]
         spans.append(max(int(r["End_Timestamp"]) for r in rs) - min(int(r["Start_Timestamp"]) for r in rs))
     if spans:
-        summary["dp_step_span"] = {"steps": len(spans), "avg_ms": sum(spans) / len(spans) / 1e6, "min_ms": min(spans) / 1e6, "max_ms": max(spans) / 1e6,
+        summary["dp_step_span"] = {"steps": len(spans), "dispatch_groups": [k0, k1], "avg_ms": sum(spans) / len(spans) / 1e6, "min_ms": min(spans) / 1e6, "max_ms": max(spans) / 1e6,
                                    "what": "pair kernel + single-query kernel (concurrent) + osw_sw_i32 of one search; compare with bench.py roofline.kernel_ms"}
 
 
@@ -78,8 +88,8 @@ def pmc(sub):
         name = next((x for x in KERNELS if k.split("(")[0].strip() == x), None)
         if not name:
             continue
-        if name.startswith("osw_sw_") and int(r.get("Grid_Size", "0") or 0) <= 256:
-            continue  # bring-up launch on empty queues
+        if name.startswith("osw_sw_") and int(r.get("Grid_Size", "0") or 0) <= int(r.get("Workgroup_Size", "256") or 256):
+            continue  # bring-up launch on empty queues (one workgroup)
         c = r["Counter_Name"]
         v = float(r["Counter_Value"])
         e = res.setdefault(name, {}).setdefault(c, [0.0, set()])
@@ -135,8 +145,8 @@ if clk:
                                  "cycles_per_instruction_per_simd_at_2p4GHz": 2.4e9 * clk[dom]["trace_avg_ms"] * 1e-3 * 1024.0 / nv,
                                  "raw_issue_fraction": 2.0 / cyc}
 try:
-    fs = sum(summary["pmc_fetch"].get(k, {}).get("FETCH_SIZE", {}).get("per_dispatch", 0.0) for k in DP + ("osw_sw_i32",))
-    ws = sum(summary["pmc_write"].get(k, {}).get("WRITE_SIZE", {}).get("per_dispatch", 0.0) for k in DP + ("osw_sw_i32",))
+    fs = sum(summary["pmc_fetch"].get(k, {}).get("FETCH_SIZE", {}).get("per_dispatch", 0.0) for k in DP + RERUN32)
+    ws = sum(summary["pmc_write"].get(k, {}).get("WRITE_SIZE", {}).get("per_dispatch", 0.0) for k in DP + RERUN32)
     if fs == 0 and ws == 0:
         raise KeyError("no DP kernel counters")
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts 64 B per
