@@ -68,7 +68,7 @@ ROW_CYCLES = {16: (30.5, 25.3), 32: (102.0, 102.0), 8: (45.45, 45.45)}
 DTYPE = {16: "int16", 32: "int32", 8: "int8"}
 CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells",
               8: "int8 cells (four 7-bit SWAR cells per register) with int16 re-run of what leaves their range, int32 above"}
-KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/q8_cell.h", "oswald_amd/csrc/oswald_hip.cpp")
+KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/q8_cell.h", "oswald_amd/csrc/osw_planner.inc")
 
 
 def parse():

@@ -186,7 +186,13 @@ struct Chunk {
     bool has_index = false;
     uint32_t first_index = 0, nvalid = 0;
     std::shared_ptr<const std::vector<uint32_t>> index_map; // host copy: source of the (asynchronous) upload below
-    DevBuf index_map_dev;
+    // the index map on the device: two buffers in turn (a slot re-used while its last search -- which reads the old map --
+    // is still running gets the other one), copied on the DMA-only copy stream (a copy queued on the search stream would
+    // hold the caller until the running search is over: the host copy is pageable); ev_map: the copy has landed
+    DevBuf index_map_dev[2];
+    int map_cur = 0;
+    bool map_pending = false;
+    hipEvent_t ev_map = nullptr;
 };
 
 struct EventPair { hipEvent_t a, b, c, d; bool c_used; }; // a..b: all DP launches of a chunk search; c..d: the int16 re-run of the 8-bit pass (c_used); d..b: the int32 re-run
@@ -288,62 +294,6 @@ int offset8_of(const oswald_hip_ctx *ctx)
 }
 bool first_pass_is_q8(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 8 && offset8_of(ctx) >= 0; }
 
-// Pair up queries of similar length (sorted by length, neighbours): a pair costs 7.5 instructions per row of
-// the LONGER query for one sequence, two singles 8.5 per row for two sequences, so pairing pays when the
-// shorter one is longer than ~0.8 of the longer one -- in instructions.  In cycles the pair row is cheaper still
-// (25.3 against 30.5 per row: the single-query cell keeps a packed add and a v_perm_b32), and every single query costs
-// a second launch beside the pair launch: the margin on the pair's cost is 0.95 since round 3 (was 1.03), which pairs
-// all twenty queries of the BASELINE set -- 100 000 sequences: 11 360 -> 11 540 GCUPS, 1 M: 11 790 -> 11 760
-// (tools/sweep_pairs.sh).
-// OSWALD_HIP_PAIRS=0 disables it, =2 pairs every neighbour (test hook).
-void plan_pairs(oswald_hip_ctx *ctx)
-{
-    const uint32_t nq = ctx->nq;
-    const std::vector<uint16_t> &m = ctx->m;
-    const bool fr = first_pass_is_frame(ctx); // 6.5 instead of 7.5 instructions per row; +1 v_perm_b32 for two sequences per lane
-    const double pair_row = fr ? 6.5 : 7.5, single_row = fr ? 7.5 : 8.5;
-    ctx->pair_q.clear(); ctx->pair_off.clear(); ctx->pair_len.clear(); ctx->singles.clear();
-    ctx->pair_rowblocks = 0; ctx->pair_max_rowblocks = 1;
-    int mode = ctx->tun.pairs;
-    if (first_pass_is_q8(ctx)) mode = 2; // the 8-bit cell works on query pairs only: pair every neighbour (a leftover query runs in int16)
-    const double margin = ctx->tun.pair_margin;
-    std::vector<uint32_t> order(nq);
-    for (uint32_t q = 0; q < nq; ++q) order[q] = q;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return m[x] < m[y]; });
-    // cheapest set of neighbour pairs in length order (dynamic programme over the sorted list):
-    // a single costs single_row x m, a pair 2 x pair_row x (longer m) (x margin: padding, second pass)
-    std::vector<double> best(nq + 1, 0.0);
-    std::vector<uint8_t> paired(nq + 1, 0); // paired[k]: the optimum for the first k queries ends in a pair
-    for (uint32_t k = 1; k <= nq; ++k) {
-        best[k] = best[k - 1] + single_row * m[order[k - 1]];
-        if (mode > 0 && k >= 2) {
-            const double mb = m[order[k - 1]];
-            const double c2 = best[k - 2] + 2.0 * pair_row * margin * mb;
-            const bool ok = mode >= 2 ? mb > 0 && ((k & 1u) == (nq & 1u)) : mb >= 64;
-            if (ok && (mode >= 2 || c2 < best[k])) { best[k] = c2; paired[k] = 1; }
-        }
-    }
-    std::vector<uint8_t> is_pair_end(nq + 1, 0);
-    for (uint32_t k = nq; k > 0;) {
-        if (paired[k]) { is_pair_end[k] = 1; k -= 2; } else k -= 1;
-    }
-    for (uint32_t k = 0; k < nq;) {
-        if (k + 2 <= nq && is_pair_end[k + 2]) {
-            const uint32_t mb = m[order[k + 1]], rb = std::max(1u, (mb + 3u) / 4u);
-            ctx->pair_q.push_back(order[k]);
-            ctx->pair_q.push_back(order[k + 1]);
-            ctx->pair_len.push_back((uint16_t)mb);
-            ctx->pair_off.push_back(ctx->pair_rowblocks);
-            ctx->pair_rowblocks += rb;
-            ctx->pair_max_rowblocks = std::max(ctx->pair_max_rowblocks, rb);
-            k += 2;
-        } else {
-            ctx->singles.push_back(order[k]);
-            k += 1;
-        }
-    }
-}
-
 int check_dev(oswald_hip_ctx *ctx, int dev)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
@@ -428,251 +378,8 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     return 0;
 }
 
-// Work queues of a chunk for the current query set.  An item is (entity, block, sub-block,
-// geometry G); an entity is a single query (osw_sw_pk16 / osw_sw_i32) or a pair of queries
-// sharing a lane (osw_sw_pk16q).  G = 1 is a whole 128-sequence block on one wave; a heavier
-// item (many strips x many columns) is cut into G sub-blocks of 128/G sequences whose G strips
-// run side by side in the wave, so that no item is longer than a fraction of a wave's fair
-// share of the launch.  The heaviest ones become workgroup items: four sub-blocks on the four
-// waves of a workgroup sharing one 4x larger profile slice (taller rounds at high G).
-// Cost model in VALU issue slots: passes x (columns + pipeline fill) x (9|10 per row + ~10 per
-// column step and round).  Heaviest first within each class.
-int build_items(oswald_hip_ctx *ctx, Device &d, Chunk &c)
-{
-    if (c.items_version == ctx->queries_version && c.items_bits == ctx->cell_bits) return 0; // (a change of scoring that changes the 8-bit eligibility bumps queries_version)
-    const bool i32 = ctx->cell_bits == 32, q8 = first_pass_is_q8(ctx);
-    struct Kind { uint32_t rmax, ldsr; double row_cost, passes; };
-    const Kind kinds[2] = {
-        {i32 ? (uint32_t)OSW_RMAX32 : (uint32_t)OSW_RMAX16, i32 ? (uint32_t)OSW_LDS_ROWS32 : (uint32_t)OSW_LDS_ROWS16,
-         i32 ? 24.0 : first_pass_is_frame(ctx) ? 7.5 : 8.5, 1.0},
-        q8 ? Kind{OSW_RMAX8, OSW_LDS_ROWS8, 21.4, 1.0} // SWAR 8-bit pairs: 40 instructions per row of a 2 x 2 tile in 90.9 cycles (profiles/r04_oprate_q8.txt): as 21.4 slots of 4.25 cycles; one pass, wave items only
-           : Kind{OSW_RMAX16, OSW_LDS_ROWS16 / 2, first_pass_is_frame(ctx) ? 6.5 : 7.5, 2.0}};
-    struct Entity { uint32_t m, id, kind; };
-    std::vector<Entity> ents;
-    if (i32) {
-        for (uint32_t q = 0; q < ctx->nq; ++q) ents.push_back({ctx->m[q], q, 0});
-    } else {
-        for (uint32_t q : ctx->singles) ents.push_back({ctx->m[q], q, 0});
-        for (uint32_t k = 0; k < ctx->pair_len.size(); ++k) ents.push_back({ctx->pair_len[k], k, 1});
-    }
-    const uint32_t ne = (uint32_t)ents.size();
-    const uint32_t wgx = OSW_WG_THREADS / 64;
-    const Tunables &tun = ctx->tun;
-    const double col_cost = tun.col_cost; // issue slots per column step besides the cells
-    auto item_cost = [&](const Entity &e, uint32_t lg, uint32_t ncols, bool wg) {
-        const Kind &kd = kinds[e.kind];
-        const OswPlan pl = osw_plan(e.m, 1u << lg, wg ? kd.ldsr * wgx : kd.ldsr, kd.rmax);
-        const double rows = 4.0 * (pl.base * pl.rounds + pl.extra); // rows per lane group over all rounds
-        return kd.passes * (double)(ncols + (1u << lg)) * (kd.row_cost * rows + col_cost * pl.rounds);
-    };
-    // widest useful geometry per entity: strips of >= min_rows rows and no lane group entirely past the query
-    auto lg_limit = [&](const Entity &e, bool wg, uint32_t min_rows) {
-        const Kind &kd = kinds[e.kind];
-        const uint32_t lds_rows = wg ? kd.ldsr * wgx : kd.ldsr;
-        uint32_t lg = 0;
-        while (lg < 6) {
-            const uint32_t G2 = 2u << lg;
-            const OswPlan pl = osw_plan(e.m, G2, lds_rows, kd.rmax);
-            if (G2 * osw_plan_maxrows(pl) > lds_rows || 4 * pl.base < min_rows || G2 * min_rows > pl.m4) break;
-            ++lg;
-        }
-        return lg;
-    };
-    // Default geometry of an entity: as many lane groups as it has full strips, so that the groups hand
-    // their bottom rows to each other in registers and (almost) nothing spills to HBM.  If that fits a
-    // wave's private LDS slice it is a wave item with one round; longer queries run as workgroup items
-    // with the 4x larger shared slice.
-    struct Mode { bool wg; uint32_t lg; };
-    std::vector<Mode> def(ne);
-    std::vector<uint32_t> lgmax(ne), lgmax_wg(ne), lg_full_wave(ne);
-    double total = 0;
-    for (uint32_t k = 0; k < ne; ++k) {
-        const Kind &kd = kinds[ents[k].kind];
-        lgmax[k] = lg_limit(ents[k], false, 8);
-        lgmax_wg[k] = (i32 || (q8 && ents[k].kind == 1)) ? 0 : lg_limit(ents[k], true, 4);
-        const uint32_t m4 = std::max(4u, (ents[k].m + 3u) & ~3u);
-        // widest geometries that still run full-height strips (G * rmax rows fit the LDS slice)
-        uint32_t full_wave = 0, full_wg = 0;
-        while ((kd.rmax << (full_wave + 1)) <= kd.ldsr) ++full_wave;
-        while ((kd.rmax << (full_wg + 1)) <= kd.ldsr * wgx) ++full_wg;
-        lg_full_wave[k] = std::min(full_wave, lgmax[k]);
-        uint32_t lg = 0;
-        while ((kd.rmax << lg) < m4 && lg < full_wg) ++lg; // smallest G with G*rmax >= m4
-        if (lg <= full_wave || lgmax_wg[k] < 2) def[k] = {false, std::min(std::min(lg, full_wave), lgmax[k])};
-        else def[k] = {true, std::max(2u, std::min(lg, lgmax_wg[k]))};
-        for (uint32_t b = 0; b < c.nblocks; ++b)
-            total += (double)(1u << def[k].lg) * item_cost(ents[k], def[k].lg, c.ncols4_alloc[b] * 4, def[k].wg);
-    }
-    const uint32_t grid_eff = tun.grid_per_cu ? std::min<uint32_t>(d.grid, (uint32_t)d.prop.multiProcessorCount * tun.grid_per_cu) : d.grid; // (-DOSW_DIAG sweep)
-    const double nwaves = (double)(q8 ? d.grid_q8 : grid_eff) * wgx; // (8-bit mode: the pairs, the bulk of the work, run on the 8-bit kernel's larger grid)
-    const double target = std::max(total / nwaves / tun.target_div, 4.0e4);
-    // test hooks: OSWALD_HIP_FORCE_LG=k runs every item at geometry G = 2^k,
-    // OSWALD_HIP_FORCE_WG=1 / 0 forces / forbids workgroup items
-    int force_lg = tun.force_lg, force_wg = tun.force_wg;
-    // below wg_min_cols columns a workgroup item becomes wave items, below wg_wide_cols it keeps G <= 8 -- for query
-    // PAIRS (two barriers per round and the wider pipeline fill cost more than the spill they save on short blocks:
-    // C2 -6 % with every block a workgroup item).  SINGLE queries take workgroup items for every block (round 3): their
-    // wave items hold a quarter of a block each -- with one query and 100 000 sequences that is half of a wave's whole
-    // share of the launch, far too coarse for the end of it -- and at G = 4 a long query needs four times the rounds
-    // (C5 8 700 -> 9 220, Q1 7 400 -> 7 800 GCUPS; profiles/r03_sweep_queue_order.txt).
-    const uint32_t wg_min_cols_kind[2] = {tun.wg_min_cols_single, tun.wg_min_cols}, wg_wide_cols_kind[2] = {tun.wg_wide_cols_single, tun.wg_wide_cols};
-    if (i32) force_wg = 0; // the int32 kernel has no workgroup phase
-    struct It { double cost; uint32_t x, b; };
-    std::vector<It> its[2], its_wg[2];
-    c.max_lg = 0;
-    c.planned_spill_bytes = 0;
-    // strip-boundary spill of an item: every round boundary writes and reads back {H, F} = 8 B per column and lane of a group
-    auto spill_bytes = [&](const Entity &e, uint32_t lg, uint32_t ncols, bool wg) {
-        const Kind &kd = kinds[e.kind];
-        const OswPlan pl = osw_plan(e.m, 1u << lg, wg ? kd.ldsr * wgx : kd.ldsr, kd.rmax);
-        return kd.passes * (double)(pl.rounds - 1) * (double)ncols * (double)(64u >> lg) * 8.0 * 2.0;
-    };
-    for (uint32_t k = 0; k < ne; ++k)
-        for (uint32_t b = 0; b < c.nblocks; ++b) {
-            const Entity &e = ents[k];
-            const uint32_t ncols = c.ncols4_alloc[b] * 4;
-            bool wg = def[k].wg;
-            uint32_t lg = def[k].lg;
-            // the block's boundary row must fit the wave's spill region: (columns + pad) x lanes per group
-            uint32_t lg_scratch = 0;
-            while (lg_scratch < 6 && ((uint64_t)ncols + OSW_SCRATCH_PAD_COLS) * (64u >> lg_scratch) > d.bnd_stride) ++lg_scratch;
-            // (-DOSW_DIAG sweep, OSWALD_HIP_WG_MINROUNDS: entities whose wave plan would spill at wg_min_rounds - 1 or more round
-            // boundaries stay workgroup items also on short blocks, down to OSWALD_HIP_WG_MINCOLS_LONG columns)
-            const bool many_rounds = tun.wg_min_rounds > 0 && ncols >= tun.wg_min_cols_long &&
-                                     osw_plan(e.m, 1u << lg_full_wave[k], kinds[e.kind].ldsr, kinds[e.kind].rmax).rounds >= tun.wg_min_rounds;
-            const uint32_t wg_min_cols = wg_min_cols_kind[e.kind], wg_wide_cols = wg_wide_cols_kind[e.kind];
-            if (wg && ncols < wg_min_cols && !many_rounds) {
-                // short block: the pipeline fill of a wide geometry (G columns per round) would cost more
-                // than the spill it saves; run as wave items at the widest full-height geometry (G = 4; 2 for pairs)
-                wg = false;
-                lg = lg_full_wave[k];
-            } else if (wg && ncols < wg_wide_cols && lg > 3) {
-                lg = 3; // medium block: 8 groups
-            }
-            double cost = item_cost(e, lg, ncols, wg);
-            if (cost > target) {
-                // too long for one wave's share: widen the geometry (shorter critical path, somewhat less
-                // efficient).  Among the geometries that fit the target take the one with the least total
-                // work; if none fits, the one with the shortest critical path.
-                double best_fit_work = -1, best_cost = cost;
-                bool fwg = wg, cwg = wg;
-                uint32_t flg = lg, clg = lg;
-                auto consider = [&](bool w, uint32_t g2) {
-                    const double ck = item_cost(e, g2, ncols, w), work = ck * (double)(1u << g2);
-                    if (ck <= target && (best_fit_work < 0 || work < best_fit_work)) { best_fit_work = work; fwg = w; flg = g2; }
-                    if (ck < best_cost) { best_cost = ck; cwg = w; clg = g2; }
-                };
-                if (!wg) for (uint32_t g2 = lg + 1; g2 <= lgmax[k]; ++g2) consider(false, g2);
-                if (!i32 && !(q8 && e.kind == 1)) for (uint32_t g2 = std::max(2u, wg ? lg + 1 : 2u); g2 <= lgmax_wg[k]; ++g2) consider(true, g2);
-                if (best_fit_work >= 0) { wg = fwg; lg = flg; } else { wg = cwg; lg = clg; }
-            }
-            if (force_lg >= 0) { lg = (uint32_t)force_lg; wg = false; }
-            if (force_wg == 1) { wg = true; if (lg < 2) lg = 2; }
-            if (force_wg == 0 || (q8 && e.kind == 1)) wg = false; // (the 8-bit kernel has no workgroup phase)
-            if (lg < lg_scratch) lg = lg_scratch;
-            // hard limit of a geometry: G strips of (at least) 4 rows must fit the profile slice in LDS
-            {
-                const Kind &kd = kinds[e.kind];
-                if (!wg && (4u << lg) > kd.ldsr && !i32 && !(q8 && e.kind == 1) && force_wg != 0 && (4u << lg) <= kd.ldsr * wgx && lg >= 2) wg = true;
-                while ((4u << lg) > (wg ? kd.ldsr * wgx : kd.ldsr) && lg > 0) --lg;
-                if (lg < lg_scratch) return fail(OSWALD_HIP_EINVAL, "a sequence block of %u columns does not fit the spill scratch at any geometry", ncols);
-            }
-            const uint32_t G = 1u << lg;
-            c.max_lg = std::max(c.max_lg, lg);
-            // an item runs to the last real residue of its own sub-block (workgroup item: of its four sub-blocks)
-            const uint16_t *sc = c.sub_cols + (size_t)b * 128 + (G - 1);
-            if (wg) for (uint32_t s = 0; s < G; s += 4) its_wg[e.kind].push_back({item_cost(e, lg, std::max(std::max(sc[s], sc[s + 1]), std::max(sc[s + 2], sc[s + 3])), wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
-            else for (uint32_t s = 0; s < G; ++s) its[e.kind].push_back({item_cost(e, lg, sc[s], wg), OSW_ITEM_PACK(e.id, s, lg, 3u), b});
-            for (uint32_t s = 0; s < G; ++s) c.planned_spill_bytes += (uint64_t)spill_bytes(e, lg, sc[s], wg);
-        }
-    auto by_cost = [](const It &x, const It &y) { return x.cost > y.cost; };
-    // issue priority of the long items (see set_wave_prio in sw_kernels.hip)
-    double planned = 0;
-    for (int kd = 0; kd < 2; ++kd) {
-        std::stable_sort(its[kd].begin(), its[kd].end(), by_cost);
-        std::stable_sort(its_wg[kd].begin(), its_wg[kd].end(), by_cost);
-        for (const It &i : its[kd]) planned += i.cost;
-        for (const It &i : its_wg[kd]) planned += i.cost * 4;
-    }
-    const double fair = planned / nwaves;
-    const bool no_prio = tun.no_prio;
-    auto prio_of = [&](double cost) { return no_prio ? 0u : cost > fair / 2 ? 3u : cost > fair / 4 ? 2u : cost > fair / 8 ? 1u : 0u; };
-    // Phase 1 of a launch is ONE queue of workgroup entries, heaviest first (longest-processing-time order): a
-    // workgroup item (four sub-blocks of one item on the four waves, shared profile slice), or a QUAD of four
-    // independent wave items of similar cost -- the wave items that are heavy compared with a wave's fair share of
-    // the launch.  (They used to wait in the wave queue until every workgroup item was done: a wave item worth 0.7
-    // of the fair share that starts at 60 % of the launch defines its end.)  Phase 2, the per-wave queue, keeps
-    // the light wave items that fill the tail.  An entry is four item slots, one per wave; slot.y bit 31 marks a
-    // workgroup item, slot.y == OSW_ITEM_NONE an empty slot of the last quad.
-    const double quad_frac = tun.quad_frac; // 0.5; measured: 0.25 costs C2 6 % (waves in step), 1.0 loses the gain on C5
-    struct Entry { double cost; uint2 slot[4]; };
-    std::vector<uint2> flat[2];
-    uint32_t n_entries[2] = {0, 0}, n_wave[2] = {0, 0}, n_quads[2] = {0, 0};
-    for (int kd = 0; kd < 2; ++kd) {
-        std::vector<Entry> ent;
-        ent.reserve(its_wg[kd].size() + its[kd].size() / 4 + 1);
-        for (const It &i : its_wg[kd]) {
-            Entry e;
-            e.cost = i.cost;
-            for (uint32_t w = 0; w < 4; ++w) e.slot[w] = make_uint2((i.x + (w << 16)) | (prio_of(i.cost) << 30), i.b | OSW_ITEM_WG_FLAG);
-            ent.push_back(e);
-        }
-        size_t heavy = 0;
-        while (!i32 && !(q8 && kd == 1) && heavy < its[kd].size() && its[kd][heavy].cost >= quad_frac * fair) ++heavy;
-        for (size_t k = 0; k < heavy; k += 4) {
-            Entry e;
-            e.cost = its[kd][k].cost;
-            for (uint32_t w = 0; w < 4; ++w) {
-                if (k + w < heavy) { const It &i = its[kd][k + w]; e.slot[w] = make_uint2(i.x | (prio_of(i.cost) << 30), i.b); }
-                else e.slot[w] = make_uint2(0u, OSW_ITEM_NONE);
-            }
-            ent.push_back(e);
-            n_quads[kd]++;
-        }
-        std::stable_sort(ent.begin(), ent.end(), [](const Entry &x, const Entry &y) { return x.cost > y.cost; });
-        flat[kd].reserve(ent.size() * 4 + its[kd].size() - heavy);
-        for (const Entry &e : ent) for (uint32_t w = 0; w < 4; ++w) flat[kd].push_back(e.slot[w]);
-        for (size_t k = heavy; k < its[kd].size(); ++k) flat[kd].push_back(make_uint2(its[kd][k].x | (prio_of(its[kd][k].cost) << 30), its[kd][k].b));
-        n_entries[kd] = (uint32_t)ent.size();
-        n_wave[kd] = (uint32_t)(its[kd].size() - heavy);
-    }
-    c.nitems_wg = n_entries[0];
-    c.nitems = n_wave[0];
-    c.nitems_q_wg = n_entries[1];
-    c.nitems_q = n_wave[1];
-    if (q8 && c.nitems_q_wg) return fail(OSWALD_HIP_ERUNTIME, "planner produced workgroup entries for the 8-bit kernel");
-    if (tun.debug_plan) {
-        fprintf(stderr, "[oswald_hip] plan: %zu single queries, %zu query pairs, total %.3g slots, %.0f waves, target %.3g, max lg %u\n",
-                i32 ? (size_t)ctx->nq : ctx->singles.size(), i32 ? (size_t)0 : ctx->pair_len.size(), total, nwaves, target, c.max_lg);
-        for (int kd = 0; kd < 2; ++kd) {
-            double sw = 0, sg = 0;
-            for (const It &i : its[kd]) sw += i.cost;
-            for (const It &i : its_wg[kd]) sg += i.cost * 4;
-            fprintf(stderr, "[oswald_hip]   %s: wave items %zu (sum %.3g, max %.3g; %u quads in phase 1, %u in the wave queue), workgroup items %zu (sum %.3g, max %.3g), fair share %.3g\n", kd ? "pairs  " : "singles",
-                    its[kd].size(), sw, its[kd].empty() ? 0.0 : its[kd][0].cost, n_quads[kd], n_wave[kd], its_wg[kd].size(), sg, its_wg[kd].empty() ? 0.0 : its_wg[kd][0].cost, fair);
-            uint32_t hist[2][8] = {{0}};
-            for (const It &i : its[kd]) hist[0][OSW_ITEM_LG(i.x)]++;
-            for (const It &i : its_wg[kd]) hist[1][OSW_ITEM_LG(i.x)]++;
-            for (int w = 0; w < 2; ++w)
-                for (int g2 = 0; g2 < 7; ++g2)
-                    if (hist[w][g2]) fprintf(stderr, "[oswald_hip]     %s lg=%d: %u items\n", w ? "workgroup" : "wave", g2, hist[w][g2]);
-        }
-    }
-    HIP_TRY(c.items.reserve(flat[0].size() * sizeof(uint2) + 16));
-    HIP_TRY(c.items_q.reserve(flat[1].size() * sizeof(uint2) + 16));
-    // worst case of the overflow queue: every sequence of every query at the int16 ceiling
-    const size_t ovf_bytes = (size_t)ctx->nq * c.nblocks * 128 * sizeof(uint2) + 16;
-    if (ovf_bytes > (64ull << 30)) return fail(OSWALD_HIP_EINVAL, "%u queries x %u sequence blocks in one chunk need a %zu-byte overflow queue; search in smaller chunks or query sets", ctx->nq, c.nblocks, ovf_bytes);
-    HIP_TRY(c.ovf.reserve(ovf_bytes));
-    if (q8) HIP_TRY(c.ovf8.reserve(ovf_bytes)); // worst case: every quad of lanes queues both of its queries, four slots each
-    HIP_TRY(c.scores.reserve((size_t)ctx->nq * c.score_stride * sizeof(int32_t) + 16));
-    if (!flat[0].empty()) HIP_TRY(hipMemcpyAsync(c.items.p, flat[0].data(), flat[0].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
-    if (!flat[1].empty()) HIP_TRY(hipMemcpyAsync(c.items_q.p, flat[1].data(), flat[1].size() * sizeof(uint2), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(hipStreamSynchronize(d.stream));
-    c.items_version = ctx->queries_version;
-    c.items_bits = ctx->cell_bits;
-    return 0;
-}
+// plan_pairs(), build_items(): the planner (a file of its own: see its header)
+#include "osw_planner.inc"
 
 // after the stream has been synchronised: the downloads are done, unpin the callers' tables
 void release_registered(Device &d)
@@ -755,9 +462,10 @@ int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     if (c.nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "chunk index: nvalid %u exceeds the chunk's %u lanes", c.nvalid, c.ngroups * c.W);
     if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0 || c.nvalid == 0) return 0; // nothing was searched: nothing to add
     if (!d.top_run[0].p || !d.top_run[1].p) return fail(OSWALD_HIP_ESTATE, "oswald_hip_topr_begin has not prepared device %d", d.id);
+    if (c.map_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_map, 0)); c.map_pending = false; } // the chunk's index map has landed
     HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * osw_topr_parts(c.nvalid) * r * sizeof(unsigned long long)));
     HIP_TRY(osw_launch_topr_fold_chunk((const int32_t *)c.scores.p, c.score_stride, c.nvalid, r, ctx->nq,
-                                       c.index_map ? (const uint32_t *)c.index_map_dev.p : nullptr, c.first_index, (unsigned long long *)d.topr_cand.p,
+                                       c.index_map ? (const uint32_t *)c.index_map_dev[c.map_cur].p : nullptr, c.first_index, (unsigned long long *)d.topr_cand.p,
                                        (const unsigned long long *)d.top_run[d.top_cur].p, (unsigned long long *)d.top_run[d.top_cur ^ 1].p, d.stream));
     d.top_cur ^= 1;
     d.top_any = true;
@@ -934,7 +642,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         }
         if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev.release(); }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); if (c.ev_map) (void)hipEventDestroy(c.ev_map); c.ev_map = nullptr; }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
                           &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
@@ -1513,7 +1221,8 @@ int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t
     if (nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "nvalid %u exceeds the chunk's %u lanes", nvalid, c.ngroups * c.W);
     if (!index_map && (uint64_t)first_index + nvalid > 0xffffffffull) return fail(OSWALD_HIP_EINVAL, "database indices must fit 32 bits");
     HIP_TRY(hipSetDevice(d.id));
-    if (c.index_map) { // the old map may still be on its way to the device, into the buffer the new one is about to take
+    if (c.index_map) { // a map given twice to the same upload: the old one may still be on its way, or being read by a search of the chunk
+        HIP_TRY(hipStreamSynchronize(d.stream_copy));
         HIP_TRY(hipStreamSynchronize(d.stream));
         c.index_map.reset();
     }
@@ -1523,8 +1232,12 @@ int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t
         // the map goes to the device (the chunk's top list is selected there, on database keys); the host copy is the
         // source of that asynchronous upload and lives as long as the chunk's index does
         c.index_map = std::make_shared<const std::vector<uint32_t>>(index_map, index_map + nvalid);
-        HIP_TRY(c.index_map_dev.reserve((size_t)nvalid * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpyAsync(c.index_map_dev.p, c.index_map->data(), (size_t)nvalid * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        c.map_cur ^= 1;
+        if (!c.ev_map) HIP_TRY(hipEventCreateWithFlags(&c.ev_map, hipEventDisableTiming));
+        HIP_TRY(c.index_map_dev[c.map_cur].reserve((size_t)nvalid * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(c.index_map_dev[c.map_cur].p, c.index_map->data(), (size_t)nvalid * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream_copy));
+        HIP_TRY(hipEventRecord(c.ev_map, d.stream_copy));
+        c.map_pending = true;
     }
     c.has_index = true;
     return 0;
@@ -1632,6 +1345,7 @@ int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *
         HIP_TRY(hipSetDevice(d.id));
         HIP_TRY(hipStreamSynchronize(d.stream));
         HIP_TRY(hipStreamSynchronize(d.stream_down));
+        if (!d.retired_maps.empty()) HIP_TRY(hipStreamSynchronize(d.stream_copy)); // (their copies ran on the copy stream)
         for (Chunk &c : d.chunks) c.down_pending = false;
         release_registered(d);
     }

@@ -39,7 +39,7 @@ GROUPS = (
          scratch=0, min_asm_uses=100),
 )
 KERNELS = tuple(k for g in GROUPS for k in g["kernels"])
-SOURCES = ("sw_kernels.hip", "sw_kernels.h", "q8_cell.h", "oswald_hip.cpp")
+SOURCES = ("sw_kernels.hip", "sw_kernels.h", "q8_cell.h", "oswald_hip.cpp", "osw_planner.inc")
 
 
 def hipcc_path():

@@ -6,7 +6,7 @@ import csv, glob, hashlib, json, os, sys
 
 out, wl, nseq = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/q8_cell.h", "oswald_amd/csrc/oswald_hip.cpp")  # = bench.py
+KERNEL_SOURCES = ("oswald_amd/csrc/sw_kernels.hip", "oswald_amd/csrc/sw_kernels.h", "oswald_amd/csrc/q8_cell.h", "oswald_amd/csrc/osw_planner.inc")  # = bench.py
 
 
 def source_digest():
