@@ -19,7 +19,11 @@
  *   - host buffers stay owned by the caller; the layer copies what it needs
  *     before the call returns unless the name says _async, in which case the
  *     buffers must stay valid until oswald_hip_wait().
- *   - one caller thread at a time per context; any thread may be that caller.
+ *   - one caller thread at a time per context DEVICE; any thread may be that caller.  The per-device calls (chunk
+ *     upload / set_index / search / release / topr, wait on one device, stats) touch only their device's state and may
+ *     be made concurrently for different devices of a context -- the CLI drives N GPUs from N threads, so that no
+ *     device waits for another one's search to be planned.  Context-level calls (init, finalize, set_scoring,
+ *     set_queries, topr_begin, topr, comm_*, wait on all devices) need every other caller out of the context.
  *   - database residues use the preprocessed alphabet (0..22, dummy 23,
  *     reference host/src/sequences.c:165-175, sequences.h:16-17) and the
  *     reference's interleaved group layout b[disp[g] + j*W + lane]

@@ -1885,8 +1885,9 @@ hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 // the re-run of the int32 queue: `regions` spill regions exist on the device (one per wave of a DP launch, two launches)
 hipError_t osw_launch_i32r(const OswSearchArgs &a, uint32_t regions, hipStream_t s)
 {
-    static const size_t lds = (size_t)OSW_I32R_WAVES * (OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8) * sizeof(uint2);
-    static hipError_t attr = hipFuncSetAttribute((const void *)osw_sw_i32r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)OSW_I32R_WAVES * (OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8) * sizeof(uint2);
+    // (per launch: the attribute belongs to the function ON THE CURRENT DEVICE; a context may drive several)
+    const hipError_t attr = hipFuncSetAttribute((const void *)osw_sw_i32r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;
     uint32_t grid = regions / OSW_I32R_WAVES;
     if (grid > 512u) grid = 512u;

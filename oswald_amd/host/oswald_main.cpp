@@ -640,6 +640,9 @@ int do_search(Options &o)
         std::vector<std::vector<int>> h(3, std::vector<int>(o.num_devices, -1));
         auto upload = [&](size_t k) {
             std::vector<int> &hk = h[k % 3];
+            // one thread per device (the C ABI allows concurrent calls for DIFFERENT devices of a context): with N devices
+            // driven one after the other, device N-1 would get its search N-1 plans late (~1 ms each)
+#pragma omp parallel for num_threads((int)pieces.size()) schedule(static, 1) if (pieces.size() > 1)
             for (unsigned d = 0; d < pieces.size(); ++d) {
                 hk[d] = -1;
                 if (k >= pieces[d].size()) continue;
@@ -657,11 +660,13 @@ int do_search(Options &o)
         upload(next_up++);
         for (size_t k = 0; k < rounds; ++k) {
             std::vector<int> &cur = h[k % 3];
-            for (unsigned d = 0; d < pieces.size(); ++d)
-                if (cur[d] >= 0) check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search");
+#pragma omp parallel for num_threads((int)pieces.size()) schedule(static, 1) if (pieces.size() > 1)
+            for (unsigned d = 0; d < pieces.size(); ++d) {
+                if (cur[d] < 0) continue;
+                check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search"); // (waits for ITS upload, plans, launches)
+                check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release");        // (the upload has landed; the device re-uses the slot when it is through with it)
+            }
             lap("  queue searches of a round");
-            for (unsigned d = 0; d < pieces.size(); ++d)
-                if (cur[d] >= 0) check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release"); // (the upload has landed; the device re-uses the slot when it is through with it)
             const size_t ahead = k == 0 ? k + 1 : k + 2;
             while (next_up <= ahead && next_up < rounds) upload(next_up++);
         }
