@@ -748,6 +748,8 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     for (size_t i = 0; i < d.chunks.size(); ++i) {
         const Chunk &k = d.chunks[i];
         if (k.live || k.upload_pending || k.st_b.cap < vD + 64) continue;
+        const size_t need_scores = (size_t)ctx->nq * ((ngroups + OSW_BLOCK_SEQS / W - 1) / (OSW_BLOCK_SEQS / W)) * OSW_BLOCK_SEQS * sizeof(int32_t);
+        if (k.scores.cap && k.scores.cap < need_scores + 16) continue; // (its score table and re-run queues would have to grow too)
         if (slot < 0 || k.st_b.cap < d.chunks[slot].st_b.cap) slot = (int)i;
     }
     if (slot < 0)
