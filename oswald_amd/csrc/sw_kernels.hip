@@ -96,13 +96,31 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 #define OSW_VLF0 "v165"
 #define OSW_VLH1 "v166"
 #define OSW_VLF1 "v167"
-#define OSW_INFLIGHT "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
-// ... and the compiler is given v0..v159 only (amdgpu_num_vgpr caps what its register allocator may use; the kernel's
-// register count still comes out as 168 -- three waves per SIMD -- because the asm statements clobber v160..v167): the
+// ... and, since round 4, the registers the cells of a column work through besides their per-row state:
+#define OSW_VT "v159"   // a row's temporary (u = H - gap penalty)
+#define OSW_PA0 "v150"  // profile buffer A: the substitution scores of one 4-row block (ds_read_b128, or two ds_read_b64)
+#define OSW_PA1 "v151"
+#define OSW_PA2 "v152"
+#define OSW_PA3 "v153"
+#define OSW_PA_LO "v[150:151]"
+#define OSW_PA_HI "v[152:153]"
+#define OSW_PA_ALL "v[150:153]"
+#define OSW_PB0 "v154"  // profile buffer B: the next block's (the two alternate)
+#define OSW_PB1 "v155"
+#define OSW_PB2 "v156"
+#define OSW_PB3 "v157"
+#define OSW_PB_LO "v[154:155]"
+#define OSW_PB_HI "v[156:157]"
+#define OSW_PB_ALL "v[154:157]"
+#define OSW_PS0 "v148"  // sequence-pair cell: the (first, second sequence) score pair of a row, made by v_perm_b32 one row ahead
+#define OSW_PS1 "v149"
+#define OSW_INFLIGHT "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+// ... and the compiler is given v0..v147 only (amdgpu_num_vgpr caps what its register allocator may use; the kernel's
+// register count still comes out as 168 -- three waves per SIMD -- because the asm statements clobber the fixed ones): the
 // fixed registers are out of its reach by construction, not by the luck of an allocation order (round 2 had them at
 // v120..v127 inside the compiler's range; with a larger budget the allocator did park temporaries there between asm
 // statements).  tools/isa_check.py verifies it on the ISA.
-#define OSW_COMPILER_VGPRS __attribute__((amdgpu_num_vgpr(160)))
+#define OSW_COMPILER_VGPRS __attribute__((amdgpu_num_vgpr(148)))
 
 // ---------------------------------------------------------------------------
 // The cell, hand-scheduled.  State per row r: E[r] and D[r] = H(i0+r-1, j-1),
@@ -132,51 +150,6 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 //   floor (the value of "zero"): B in both halves; profile: the plain int16 one
 // ---------------------------------------------------------------------------
 #define OSW_I16B_BIAS 0x04000400u
-#define OSW_I16B_ROW_EVEN(FREG, x, xn, Er, Dn, s_next, ge, goe)                              \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
-                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
-                     "v_pk_sub_u16 %[t], %[Dn_], %[goe_] clamp\n\t"                          \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[b_]\n\t"                       \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[b_]"                     \
-                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn)         \
-                     : [x_] "v"(x), [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe), [b_] "s"(OSW_I16B_BIAS) \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-#define OSW_I16B_ROW_ODD(FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, goe)                       \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile("v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp\n\t"                         \
-                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
-                     "v_pk_sub_u16 %[t], %[Dn_], %[goe_] clamp\n\t"                          \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
-                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[Dn_]\n\t"                  \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[b_]\n\t"                       \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[b_]"                     \
-                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
-                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [goe_] "s"(goe), [b_] "s"(OSW_I16B_BIAS) \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-#define OSW_I16B_ROW_LAST(FREG, x, Er, hl, Dp, sc, ge, goe)                                  \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile("v_pk_maximum3_f16 %[hl_], %[x_], %[E_], " FREG "\n\t"                  \
-                     "v_pk_sub_u16 %[E_], %[E_], %[ge_] clamp\n\t"                           \
-                     "v_pk_sub_u16 %[t], %[hl_], %[goe_] clamp\n\t"                          \
-                     "v_pk_sub_u16 " FREG ", " FREG ", %[ge_] clamp\n\t"                     \
-                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[hl_]\n\t"                  \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[b_]\n\t"                       \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[b_]"                     \
-                     : [hl_] "=&v"(hl), [t] "=&v"(t_), [E_] "+v"(Er), [sc_] "+v"(sc)         \
-                     : [x_] "v"(x), [Dp_] "v"(Dp), [ge_] "s"(ge), [goe_] "s"(goe), [b_] "s"(OSW_I16B_BIAS) \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
 
 // ---------------------------------------------------------------------------
 // "Column frame" variant of the biased int16 cell: 6.5 instructions per row.
@@ -195,142 +168,247 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // cell), and a sequence scoring 22256 or more is re-run in int32: the largest
 // pattern of a sequence that stays below is 22255 + 1024 + 8192, and a diagonal
 // sum adds at most 127 + ge to it: below 0x7C00.
-//   x, Dn, E, F, sc as above; u_ in go_ slot: gap open; fl1: the floor operand
+// The subtracts are plain 32-bit VOP2 on the packed pair: gfx950 issues v_add_u32 / v_sub_u32 in ~2 cycles against
+// ~4 for any VOP3P instruction (profiles/r02_oprate_valu_issue.txt; in the cell's mix a row goes from 27.7 to
+// 25.3 cycles, profiles/r02_oprate2_valu_mix.txt).  They are exact whenever no borrow crosses the halves:
+// every H, E, F pattern is >= 1024 >= go, ge (the kernel checks go <= 1024; ge <= 64 anyway).  The diagonal add is a
+// v_add_u32 too when the profile stores its (S_lo, S_hi) pairs as the 32-bit INTEGER S_lo + 65536 * S_hi (query-pair
+// profile, osw_build_pair_profile), so that the sum is right in both halves although S_lo may be negative; the
+// sequence-pair cell assembles its score pairs with v_perm_b32 and keeps the packed add.
 // ---------------------------------------------------------------------------
 #define OSW_I16S_FRAME_MAX 8192u
-// The three adds / subtracts of a row exist in two spellings.  VOP3P packed 16-bit (saturating), and plain
-// 32-bit VOP2 on the packed pair: gfx950 issues v_add_u32 / v_sub_u32 in ~2 cycles against ~4 for any VOP3P
-// instruction (profiles/r02_oprate_valu_issue.txt; in the cell's mix a row goes from 27.7 to 25.3 cycles,
-// profiles/r02_oprate2_valu_mix.txt).  The 32-bit forms are exact whenever no borrow / carry crosses the
-// halves: every H, E, F pattern is >= 1024 >= go, ge (the kernel checks go <= 1024; ge <= 64 anyway), and
-// the diagonal add takes a profile whose (S_lo, S_hi) pairs are stored as the 32-bit INTEGER S_lo + 65536 * S_hi
-// (query-pair profile, osw_build_pair_profile), so that the sum is right in both halves although S_lo may be
-// negative; the sequence-pair cell assembles its score pairs with v_perm_b32 and keeps the packed add.
-#define OSW_ADD_PK "v_pk_add_i16 %[xn_], %[Dn_], %[sn_] clamp"
-#define OSW_ADD_32 "v_add_u32 %[xn_], %[Dn_], %[sn_]"
-#define OSW_SUBU_PK(H) "v_pk_sub_u16 %[t], " H ", %[go_] clamp"
-#define OSW_SUBU_32(H) "v_subrev_u32 %[t], %[go_], " H
-#define OSW_SUBF_PK(F) "v_pk_sub_u16 " F ", " F ", %[ge_] clamp"
-#define OSW_SUBF_32(F) "v_subrev_u32 " F ", %[ge_], " F
 
-#define OSW_I16S_ROW_EVEN(ADD, SUBU, SUBF, FREG, x, xn, Er, Dn, s_next, ge, go, fl1)         \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile(ADD "\n\t"                                                              \
-                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     SUBU("%[Dn_]") "\n\t"                                                   \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     SUBF(FREG)                                                              \
-                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn)         \
-                     : [x_] "v"(x), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
-                     : OSW_INFLIGHT);                                                        \
+// ---------------------------------------------------------------------------
+// The rows as text.  A block of four rows is ONE asm statement (round 4; it was one per row).  gfx950 has a
+// forwarding hazard behind instructions that write part of a register (SDWA dst_sel, op_sel), and LLVM's hazard
+// recogniser, which cannot see into an asm statement, assumes every statement ends in one: it puts an `s_nop 0` in front
+// of any instruction or statement that touches a register the statement before it defines -- outputs and clobbers alike,
+// other asm statements in between counting for nothing.  With a statement per row, per load and per wait that was 73-75
+// s_nop in a 48-row column, ~0.9 cycles each at three waves per SIMD (tools/oprate4.hip, probe fs_nop; the statements
+// all end in full 32-bit writes: none has the hazard).  With the loads, the waits and the v_perm_b32 inside the block
+// statement -- the profile buffers and the temporaries are fixed registers for that -- 15 are left.
+//   register / operand names are strings: XN = diagonal sum of the next row (out), DN = D[r+1] (in: H(r, j-1), out:
+//   H(r, j)), SN = score pair of the next row, X = this row's diagonal sum, E = E[r]; HOOK = text issued behind the
+//   add (v_perm_b32, loads, waits), SCMAX = the half instruction of the running / column maximum or ""
+// ---------------------------------------------------------------------------
+#define OSW_TADD_PK(XN, DN, SN) "v_pk_add_i16 " XN ", " DN ", " SN " clamp\n\t"
+#define OSW_TADD_32(XN, DN, SN) "v_add_u32 " XN ", " DN ", " SN "\n\t"
+#define OSW_SCMAX(SC, SCI, DP, DN) "v_pk_maximum3_f16 " SC ", " SCI ", " DP ", " DN "\n\t"
+// plain biased cell (go_ slot: open + extend; fl_: the bias, a constant)
+#define OSW_B_ROW(ADD, XN, DN, SN, X, E, HOOK, SCMAX)                              \
+    ADD(XN, DN, SN) HOOK                                                           \
+    "v_pk_maximum3_f16 " DN ", " X ", " E ", " OSW_VF "\n\t"                       \
+    "v_pk_sub_u16 " E ", " E ", %[ge_] clamp\n\t"                                  \
+    "v_pk_sub_u16 " OSW_VT ", " DN ", %[go_] clamp\n\t"                            \
+    "v_pk_sub_u16 " OSW_VF ", " OSW_VF ", %[ge_] clamp\n\t"                        \
+    SCMAX                                                                          \
+    "v_pk_maximum3_f16 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                       \
+    "v_pk_maximum3_f16 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]\n\t"
+#define OSW_B_ROW_LAST(HL, X, E, SCMAX)                                            \
+    "v_pk_maximum3_f16 " HL ", " X ", " E ", " OSW_VF "\n\t"                       \
+    "v_pk_sub_u16 " E ", " E ", %[ge_] clamp\n\t"                                  \
+    "v_pk_sub_u16 " OSW_VT ", " HL ", %[go_] clamp\n\t"                            \
+    "v_pk_sub_u16 " OSW_VF ", " OSW_VF ", %[ge_] clamp\n\t"                        \
+    SCMAX                                                                          \
+    "v_pk_maximum3_f16 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                       \
+    "v_pk_maximum3_f16 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]"
+// column-frame cell (go_ slot: gap open; fl_: the floor of the next column's frame, a register)
+#define OSW_S_ROW_T(ADD, PAUSE, XN, DN, SN, X, E, HOOK, SCMAX)                      \
+    ADD(XN, DN, SN) HOOK                                                           \
+    "v_pk_maximum3_f16 " DN ", " X ", " E ", " OSW_VF "\n\t"                       \
+    "v_subrev_u32 " OSW_VT ", %[go_], " DN "\n\t" PAUSE                            \
+    SCMAX                                                                          \
+    "v_pk_maximum3_f16 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                       \
+    "v_pk_maximum3_f16 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]\n\t"             \
+    "v_subrev_u32 " OSW_VF ", %[ge_], " OSW_VF "\n\t" PAUSE
+#define OSW_S_ROW(ADD, XN, DN, SN, X, E, HOOK, SCMAX) OSW_S_ROW_T(ADD, "", XN, DN, SN, X, E, HOOK, SCMAX)
+// ... with a one-cycle pause behind each of the two subtracts: the query-pair kernel's row.  The rate at which three
+// waves get these rows through a SIMD depends on where a wave steps aside (tools/oprate5.hip: 25.5 - 27.5 cycles per
+// row over the placements of an s_nop 0, 26.2 with none; behind a 32-bit VOP2 it helps, behind a VOP3P it hurts); in
+// the kernel (profiles/r04_nop_sweep.txt) no pause costs the pair kernel 3.5 %, this placement is the best of the 14
+// tried, and the sequence-pair kernel (a v_perm_b32 per row on top) is best with none.
+#define OSW_S_ROWP(ADD, XN, DN, SN, X, E, HOOK, SCMAX) OSW_S_ROW_T(ADD, "s_nop 0\n\t", XN, DN, SN, X, E, HOOK, SCMAX)
+#define OSW_S_ROW_LAST(HL, X, E, SCMAX)                                            \
+    "v_pk_maximum3_f16 " HL ", " X ", " E ", " OSW_VF "\n\t"                       \
+    "v_subrev_u32 " OSW_VT ", %[go_], " HL "\n\t"                                  \
+    SCMAX                                                                          \
+    "v_pk_maximum3_f16 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                       \
+    "v_pk_maximum3_f16 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]\n\t"             \
+    "v_subrev_u32 " OSW_VF ", %[ge_], " OSW_VF
+
+// Four rows of a QUERY-PAIR cell: C1..C3 = the score pairs of the block's rows 1..3 (its profile buffer's .y .z .w),
+// N0 = row 0 of the next block (the other buffer's .x); MID = the load of the block after next into this block's
+// buffer (all of it has been read by then) and the wait for the next block's, in front of the last row.
+#define OSW_SC_RUN(DP, DN) OSW_SCMAX("%[sc_]", "%[sc_]", DP, DN)
+#define OSW_SC_START(DP, DN) OSW_SCMAX("%[sc_]", DP, DN, DN) /* first odd row of a column-frame column: starts the column maximum */
+#define OSW_QP_ROWS3(ROW, ADD, C1, C2, C3, SC1)                                    \
+    ROW(ADD, "%[xb_]", "%[D1_]", C1, "%[x_]", "%[E0_]", "", "")                    \
+    ROW(ADD, "%[x_]", "%[D2_]", C2, "%[xb_]", "%[E1_]", "", SC1("%[D1_]", "%[D2_]")) \
+    ROW(ADD, "%[xb_]", "%[D3_]", C3, "%[x_]", "%[E2_]", "", "")
+#define OSW_QP_MID(ROW, ADD, C1, C2, C3, N0, SC1, MID)                             \
+    OSW_QP_ROWS3(ROW, ADD, C1, C2, C3, SC1) MID                                    \
+    ROW(ADD, "%[x_]", "%[D4_]", N0, "%[xb_]", "%[E3_]", "", OSW_SC_RUN("%[D3_]", "%[D4_]"))
+#define OSW_QP_LAST(ROW, ROWL, ADD, C1, C2, C3, SC1)                               \
+    OSW_QP_ROWS3(ROW, ADD, C1, C2, C3, SC1)                                        \
+    ROWL("%[hl_]", "%[xb_]", "%[E3_]", OSW_SC_RUN("%[D3_]", "%[hl_]"))
+#define OSW_QP_LD(BUF) "ds_read_b128 " BUF ", %[a0_] offset:%[off_]\n\ts_waitcnt lgkmcnt(1)\n\t"
+#define OSW_WAIT0 "s_waitcnt lgkmcnt(0)\n\t"
+
+// Four rows of a SEQUENCE-PAIR cell.  A buffer holds {lo.x, lo.y, hi.x, hi.y}: rows (0,1) and (2,3) of the lane's
+// first and of its second sequence; v_perm_b32 pairs them up, one row ahead of their use, in OSW_PS0 / OSW_PS1 in
+// turn.  On entry OSW_PS0 holds the pair of the block's row 1; on exit that of the next block's row 1.
+#define OSW_PERM_A(PS, HI, LO) "v_perm_b32 " PS ", " HI ", " LO ", %[sela_]\n\t" /* rows 0 / 2 of a buffer half */
+#define OSW_PERM_B(PS, HI, LO) "v_perm_b32 " PS ", " HI ", " LO ", %[selb_]\n\t" /* rows 1 / 3 */
+#define OSW_SP_ROWS2(ROW, ADD, CLOY, CHIY, SC1, MID)                               \
+    ROW(ADD, "%[xb_]", "%[D1_]", OSW_PS0, "%[x_]", "%[E0_]", OSW_PERM_A(OSW_PS1, CHIY, CLOY), "") \
+    ROW(ADD, "%[x_]", "%[D2_]", OSW_PS1, "%[xb_]", "%[E1_]", OSW_PERM_B(OSW_PS0, CHIY, CLOY) MID, SC1("%[D1_]", "%[D2_]"))
+#define OSW_SP_MID(ROW, ADD, CLOY, CHIY, NLOX, NHIX, SC1, MID)                     \
+    OSW_SP_ROWS2(ROW, ADD, CLOY, CHIY, SC1, MID)                                   \
+    ROW(ADD, "%[xb_]", "%[D3_]", OSW_PS0, "%[x_]", "%[E2_]", OSW_PERM_A(OSW_PS1, NHIX, NLOX), "") \
+    ROW(ADD, "%[x_]", "%[D4_]", OSW_PS1, "%[xb_]", "%[E3_]", OSW_PERM_B(OSW_PS0, NHIX, NLOX), OSW_SC_RUN("%[D3_]", "%[D4_]"))
+#define OSW_SP_LAST(ROW, ROWL, ADD, CLOY, CHIY, SC1)                               \
+    OSW_SP_ROWS2(ROW, ADD, CLOY, CHIY, SC1, "")                                    \
+    ROW(ADD, "%[xb_]", "%[D3_]", OSW_PS0, "%[x_]", "%[E2_]", "", "")               \
+    ROWL("%[hl_]", "%[xb_]", "%[E3_]", OSW_SC_RUN("%[D3_]", "%[hl_]"))
+#define OSW_SP_LD(LO, HI) "ds_read_b64 " LO ", %[a0_] offset:%[off_]\n\tds_read_b64 " HI ", %[a1_] offset:%[off_]\n\ts_waitcnt lgkmcnt(2)\n\t"
+
+// the statement around a block's text: rows RB*4 .. RB*4+3 of the strip
+#define OSW_BLOCK_STMT_MID(TXT, SCC, FLC)                                                                                        \
+    asm volatile(TXT                                                                                                             \
+                 : [x_] "+v"(x), [xb_] "=&v"(xb), [E0_] "+v"(E[RB * 4]), [E1_] "+v"(E[RB * 4 + 1]), [E2_] "+v"(E[RB * 4 + 2]),   \
+                   [E3_] "+v"(E[RB * 4 + 3]), [D1_] "+v"(D[RB * 4 + 1]), [D2_] "+v"(D[RB * 4 + 2]), [D3_] "+v"(D[RB * 4 + 3]),   \
+                   [D4_] "+v"(D[RB * 4 + 4]), [sc_] SCC(sc)                                                                      \
+                 : [a0_] "v"(a0), [a1_] "v"(a1), [off_] "i"((RB + 2) * BLOCK_BYTES), [ge_] "s"(ge), [go_] "s"(go), [fl_] FLC(fl),  \
+                   [sela_] "s"(0x05040100u), [selb_] "s"(0x07060302u)                                                            \
+                 : "memory", OSW_INFLIGHT)
+#define OSW_BLOCK_STMT_LAST(TXT, SCC, FLC)                                                                                       \
+    asm volatile(TXT                                                                                                             \
+                 : [x_] "+v"(x), [xb_] "=&v"(xb), [E0_] "+v"(E[RB * 4]), [E1_] "+v"(E[RB * 4 + 1]), [E2_] "+v"(E[RB * 4 + 2]),   \
+                   [E3_] "+v"(E[RB * 4 + 3]), [D1_] "+v"(D[RB * 4 + 1]), [D2_] "+v"(D[RB * 4 + 2]), [D3_] "+v"(D[RB * 4 + 3]),   \
+                   [hl_] "=&v"(hl), [sc_] SCC(sc)                                                                                \
+                 : [ge_] "s"(ge), [go_] "s"(go), [fl_] FLC(fl), [sela_] "s"(0x05040100u), [selb_] "s"(0x07060302u)               \
+                 : "memory", OSW_INFLIGHT)
+
+// One block of either cell kind with buffers CUR* (this block's) and NXT* (the next one's); SC1 = how the block's
+// first odd row folds into the maximum (OSW_SC_RUN, or OSW_SC_START in block 0 of the column-frame cell)
+#define OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, C0, C1, C2, C3, CLO, CHI, CALL, N0, N1, N2, N3)                           \
+    do {                                                                                                                         \
+        if constexpr (!SEQ) {                                                                                                    \
+            if constexpr (LAST) OSW_BLOCK_STMT_LAST(OSW_QP_LAST(ROW, ROWL, ADD, C1, C2, C3, SC1), SCC1, FLC);                    \
+            else if constexpr (LD) OSW_BLOCK_STMT_MID(OSW_QP_MID(ROW, ADD, C1, C2, C3, N0, SC1, OSW_QP_LD(CALL)), SCC1, FLC);    \
+            else OSW_BLOCK_STMT_MID(OSW_QP_MID(ROW, ADD, C1, C2, C3, N0, SC1, OSW_WAIT0), SCC1, FLC);                            \
+        } else {                                                                                                                 \
+            if constexpr (LAST) OSW_BLOCK_STMT_LAST(OSW_SP_LAST(ROW, ROWL, ADD, C1, C3, SC1), SCC1, FLC);                        \
+            else if constexpr (LD) OSW_BLOCK_STMT_MID(OSW_SP_MID(ROW, ADD, C1, C3, N0, N2, SC1, OSW_SP_LD(CLO, CHI)), SCC1, FLC); \
+            else OSW_BLOCK_STMT_MID(OSW_SP_MID(ROW, ADD, C1, C3, N0, N2, SC1, OSW_WAIT0), SCC1, FLC);                            \
+        }                                                                                                                        \
+    } while (0)
+#define OSW_BLOCK_EVEN(ROW, ROWL, ADD, SC1, SCC1, FLC) \
+    OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, OSW_PA0, OSW_PA1, OSW_PA2, OSW_PA3, OSW_PA_LO, OSW_PA_HI, OSW_PA_ALL, OSW_PB0, OSW_PB1, OSW_PB2, OSW_PB3)
+#define OSW_BLOCK_ODD(ROW, ROWL, ADD, SC1, SCC1, FLC) \
+    OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, OSW_PB0, OSW_PB1, OSW_PB2, OSW_PB3, OSW_PB_LO, OSW_PB_HI, OSW_PB_ALL, OSW_PA0, OSW_PA1, OSW_PA2, OSW_PA3)
+
+// The head of a column: LDS addresses of the lane's residue(s), the loads of blocks 0 and 1, the first diagonal sum
+// (and, for the sequence-pair cell, the score pairs of rows 0 and 1).  VC = the residue register of the step.
+#define OSW_QP_HEAD(ADD, VC, LD1)                                                  \
+    "v_bfe_u32 %[a0_], " VC ", %[sh_], 8\n\t"                                      \
+    "v_lshl_add_u32 %[a0_], %[a0_], 1, %[base_]\n\t"                               \
+    "ds_read_b128 " OSW_PA_ALL ", %[a0_]\n\t"                                      \
+    LD1                                                                            \
+    ADD("%[x_]", "%[tp_]", OSW_PA0)
+#define OSW_QP_HEAD_LD1 "ds_read_b128 " OSW_PB_ALL ", %[a0_] offset:%[off_]\n\ts_waitcnt lgkmcnt(1)\n\t"
+#define OSW_SP_HEAD(ADD, VC, LD1)                                                  \
+    "v_add_u32_sdwa %[a0_], %[base_], " VC " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+    "v_add_u32_sdwa %[a1_], %[base_], " VC " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+    "ds_read_b64 " OSW_PA_LO ", %[a0_]\n\t"                                        \
+    "ds_read_b64 " OSW_PA_HI ", %[a1_]\n\t"                                        \
+    LD1                                                                            \
+    OSW_PERM_A(OSW_PS1, OSW_PA2, OSW_PA0)                                          \
+    OSW_PERM_B(OSW_PS0, OSW_PA2, OSW_PA0)                                          \
+    ADD("%[x_]", "%[tp_]", OSW_PS1)
+#define OSW_SP_HEAD_LD1 "ds_read_b64 " OSW_PB_LO ", %[a0_] offset:%[off_]\n\tds_read_b64 " OSW_PB_HI ", %[a1_] offset:%[off_]\n\ts_waitcnt lgkmcnt(2)\n\t"
+#define OSW_HEAD_STMT(TXT)                                                                                                       \
+    asm volatile(TXT                                                                                                             \
+                 : [a0_] "=&v"(a0), [a1_] "=&v"(a1), [x_] "=&v"(x)                                                               \
+                 : [base_] "v"(base), [tp_] "v"(top_prev), [sh_] "s"(sh), [off_] "i"(BLOCK_BYTES), [sela_] "s"(0x05040100u),     \
+                   [selb_] "s"(0x07060302u)                                                                                      \
+                 : "memory", OSW_INFLIGHT)
+#define OSW_HEAD_BODY(ADD)                                                                                                       \
+    do {                                                                                                                         \
+        if constexpr (!SEQ) {                                                                                                    \
+            if constexpr (P == 0 && NB > 1) OSW_HEAD_STMT(OSW_QP_HEAD(ADD, OSW_VC0, OSW_QP_HEAD_LD1));                           \
+            else if constexpr (P == 0) OSW_HEAD_STMT(OSW_QP_HEAD(ADD, OSW_VC0, OSW_WAIT0));                                      \
+            else if constexpr (NB > 1) OSW_HEAD_STMT(OSW_QP_HEAD(ADD, OSW_VC1, OSW_QP_HEAD_LD1));                                \
+            else OSW_HEAD_STMT(OSW_QP_HEAD(ADD, OSW_VC1, OSW_WAIT0));                                                            \
+        } else {                                                                                                                 \
+            if constexpr (P == 0 && NB > 1) OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC0, OSW_SP_HEAD_LD1));                           \
+            else if constexpr (P == 0) OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC0, OSW_WAIT0));                                      \
+            else if constexpr (NB > 1) OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC1, OSW_SP_HEAD_LD1));                                \
+            else OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC1, OSW_WAIT0));                                                            \
+        }                                                                                                                        \
     } while (0)
 
-#define OSW_I16S_ROW_ODD(ADD, SUBU, SUBF, FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1)  \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile(ADD "\n\t"                                                              \
-                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     SUBU("%[Dn_]") "\n\t"                                                   \
-                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[Dn_]\n\t"                  \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     SUBF(FREG)                                                              \
-                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "+v"(sc) \
-                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-// first odd row of a column: starts the column maximum (sc is written, not read)
-#define OSW_I16S_ROW_ODD1(ADD, SUBU, SUBF, FREG, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1) \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile(ADD "\n\t"                                                              \
-                     "v_pk_maximum3_f16 %[Dn_], %[x_], %[E_], " FREG "\n\t"                  \
-                     SUBU("%[Dn_]") "\n\t"                                                   \
-                     "v_pk_maximum3_f16 %[sc_], %[Dp_], %[Dn_], %[Dn_]\n\t"                  \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     SUBF(FREG)                                                              \
-                     : [xn_] "=&v"(xn), [t] "=&v"(t_), [E_] "+v"(Er), [Dn_] "+v"(Dn), [sc_] "=&v"(sc) \
-                     : [x_] "v"(x), [Dp_] "v"(Dp), [sn_] "v"(s_next), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-#define OSW_I16S_ROW_LAST(SUBU, SUBF, FREG, x, Er, hl, Dp, sc, ge, go, fl1)                  \
-    do {                                                                                     \
-        v2s t_;                                                                              \
-        asm volatile("v_pk_maximum3_f16 %[hl_], %[x_], %[E_], " FREG "\n\t"                  \
-                     SUBU("%[hl_]") "\n\t"                                                   \
-                     "v_pk_maximum3_f16 %[sc_], %[sc_], %[Dp_], %[hl_]\n\t"                  \
-                     "v_pk_maximum3_f16 %[E_], %[E_], %[t], %[fl_]\n\t"                      \
-                     "v_pk_maximum3_f16 " FREG ", " FREG ", %[t], %[fl_]\n\t"                \
-                     SUBF(FREG)                                                              \
-                     : [hl_] "=&v"(hl), [t] "=&v"(t_), [E_] "+v"(Er), [sc_] "+v"(sc)         \
-                     : [x_] "v"(x), [Dp_] "v"(Dp), [ge_] "s"(ge), [go_] "s"(go), [fl_] "v"(fl1) \
-                     : OSW_INFLIGHT);                                                        \
-    } while (0)
-
-// Cell arithmetic policies: the row forms on input set P (0: even column, 1: odd
-// column) and what a finished score means.
-//   row<P, ODD>: x in/out, Dp = H of the row above (= D[r]); odd rows fold two rows' H into the running maximum
+// Cell arithmetic policies: the blocks of a column and what a finished score means.
+//   head<P, NB, SEQ>: a0 / a1 out (LDS addresses), x out (diagonal sum of row 0); sh = bit offset of the lane's residue
+//   block<RB, NB, SEQ>: rows RB*4..RB*4+3 of NB*4; x in/out, hl out (last block), sc = running / column maximum
 struct ArithI16B {
     static constexpr int kCeiling = 31600 - 1024; // true score from which a sequence is re-run in int32
     static constexpr bool kShifted = false;
     static constexpr uint32_t kFloor = OSW_I16B_BIAS;
-    template <int P, bool ODD, bool FIRST = false>
-    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t goe, v2s /*aux*/)
+    template <int P, int NB, bool SEQ>
+    static __device__ __forceinline__ void head(uint32_t base, uint32_t sh, v2s top_prev, uint32_t &a0, uint32_t &a1, v2s &x)
     {
-        v2s xn;
-        if constexpr (ODD) OSW_I16B_ROW_ODD(OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, goe);
-        else OSW_I16B_ROW_EVEN(OSW_VF, x, xn, Er, Dn, s_next, ge, goe);
-        x = xn;
+        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        OSW_HEAD_BODY(OSW_TADD_PK);
     }
-    template <int P>
-    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t ge, uint32_t goe, v2s /*aux*/)
+    template <int RB, int NB, bool SEQ>
+    static __device__ __forceinline__ void block(uint32_t a0, uint32_t a1, v2s (&D)[NB * 4], v2s (&E)[NB * 4], v2s &x, v2s &hl, v2s &sc, uint32_t ge,
+                                                 uint32_t go, v2s /*aux*/)
     {
-        OSW_I16B_ROW_LAST(OSW_VF, x, Er, hl, Dp, sc, ge, goe);
+        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        constexpr bool LAST = RB == NB - 1, LD = RB + 2 < NB;
+        const uint32_t fl = OSW_I16B_BIAS;
+        v2s xb;
+        if constexpr ((RB & 1) == 0) OSW_BLOCK_EVEN(OSW_B_ROW, OSW_B_ROW_LAST, OSW_TADD_PK, OSW_SC_RUN, "+v", "s");
+        else OSW_BLOCK_ODD(OSW_B_ROW, OSW_B_ROW_LAST, OSW_TADD_PK, OSW_SC_RUN, "+v", "s");
     }
-    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0) { return __builtin_elementwise_add_sat(top_prev, s0); }
     static __device__ __forceinline__ int to_int(short bits) { return (int)bits - 1024; }
     // at or past the threshold -- or any pattern the maximum may have turned into a NaN of either sign
     static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 31600u; }
 };
 
-// `goe` carries the gap OPEN penalty for this cell, `aux` the floor of the next column's frame, and the rows
-// accumulate the COLUMN maximum (in the column's frame) into `sc`; sw_round_fast turns it into a true score.
-// INTSUM: the profile stores its score pairs as 32-bit integer sums (see OSW_ADD_32): the diagonal add is a
+// `go` carries the gap OPEN penalty for this cell, `fl` the floor of the next column's frame, and the rows
+// accumulate the COLUMN maximum (in the column's frame) into `sc` (written, not read, by block 0); sw_round_fast turns
+// it into a true score.  INTSUM: the profile stores its score pairs as 32-bit integer sums: the diagonal add is a
 // v_add_u32 too; otherwise only the two subtracts are.
 template <bool INTSUM>
 struct ArithI16S {
     static constexpr int kCeiling = 22256; // true score from which a sequence is re-run in int32 (31600 - 1024 - 8192 - 128)
     static constexpr uint32_t kFloor = OSW_I16B_BIAS;
     static constexpr bool kShifted = true;
-    template <int P, bool ODD, bool FIRST = false>
-    static __device__ __forceinline__ void row(v2s &x, v2s &Er, v2s &Dn, v2s Dp, v2s &sc, v2s s_next, uint32_t ge, uint32_t go, v2s fl1)
+    template <int P, int NB, bool SEQ>
+    static __device__ __forceinline__ void head(uint32_t base, uint32_t sh, v2s top_prev, uint32_t &a0, uint32_t &a1, v2s &x)
     {
-        v2s xn;
+        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        if constexpr (INTSUM) OSW_HEAD_BODY(OSW_TADD_32);
+        else OSW_HEAD_BODY(OSW_TADD_PK);
+    }
+    template <int RB, int NB, bool SEQ>
+    static __device__ __forceinline__ void block(uint32_t a0, uint32_t a1, v2s (&D)[NB * 4], v2s (&E)[NB * 4], v2s &x, v2s &hl, v2s &sc, uint32_t ge,
+                                                 uint32_t go, v2s fl)
+    {
+        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        constexpr bool LAST = RB == NB - 1, LD = RB + 2 < NB;
+        v2s xb;
         if constexpr (INTSUM) {
-            if constexpr (ODD && FIRST) OSW_I16S_ROW_ODD1(OSW_ADD_32, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
-            else if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_ADD_32, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
-            else OSW_I16S_ROW_EVEN(OSW_ADD_32, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, s_next, ge, go, fl1);
+            if constexpr (RB == 0) OSW_BLOCK_EVEN(OSW_S_ROWP, OSW_S_ROW_LAST, OSW_TADD_32, OSW_SC_START, "=&v", "v");
+            else if constexpr ((RB & 1) == 0) OSW_BLOCK_EVEN(OSW_S_ROWP, OSW_S_ROW_LAST, OSW_TADD_32, OSW_SC_RUN, "+v", "v");
+            else OSW_BLOCK_ODD(OSW_S_ROWP, OSW_S_ROW_LAST, OSW_TADD_32, OSW_SC_RUN, "+v", "v");
         } else {
-            if constexpr (ODD && FIRST) OSW_I16S_ROW_ODD1(OSW_ADD_PK, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
-            else if constexpr (ODD) OSW_I16S_ROW_ODD(OSW_ADD_PK, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, Dp, sc, s_next, ge, go, fl1);
-            else OSW_I16S_ROW_EVEN(OSW_ADD_PK, OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, xn, Er, Dn, s_next, ge, go, fl1);
+            if constexpr (RB == 0) OSW_BLOCK_EVEN(OSW_S_ROW, OSW_S_ROW_LAST, OSW_TADD_PK, OSW_SC_START, "=&v", "v");
+            else if constexpr ((RB & 1) == 0) OSW_BLOCK_EVEN(OSW_S_ROW, OSW_S_ROW_LAST, OSW_TADD_PK, OSW_SC_RUN, "+v", "v");
+            else OSW_BLOCK_ODD(OSW_S_ROW, OSW_S_ROW_LAST, OSW_TADD_PK, OSW_SC_RUN, "+v", "v");
         }
-        x = xn;
-    }
-    template <int P>
-    static __device__ __forceinline__ void row_last(v2s x, v2s &Er, v2s Dp, v2s &hl, v2s &sc, uint32_t ge, uint32_t go, v2s fl1)
-    {
-        OSW_I16S_ROW_LAST(OSW_SUBU_32, OSW_SUBF_32, OSW_VF, x, Er, hl, Dp, sc, ge, go, fl1);
-    }
-    static __device__ __forceinline__ v2s first_diag(v2s top_prev, v2s s0)
-    {
-        if constexpr (INTSUM) return as_v2s(as_u32(top_prev) + as_u32(s0));
-        else return __builtin_elementwise_add_sat(top_prev, s0);
     }
     static __device__ __forceinline__ int to_int(short bits) { return (int)(uint16_t)bits; } // the running score is a true one
     static __device__ __forceinline__ bool over(short bits) { return (uint16_t)bits >= 22256u; }
@@ -353,90 +431,32 @@ struct CellSeqPair {
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
 
-    // Four rows of substitution scores for both sequences of the lane: two
-    // ds_read_b64 (one per sequence) + four v_perm_b32 that pair up (lo, hi).
-    // The loads are inline asm so that they stay single ds_read_b64: the
-    // compiler would fuse neighbouring row-blocks into ds_read2_b64, whose
-    // 32-bank addressing makes residue codes c and c+16 collide (measured:
-    // 2.5 conflict cycles per LDS instruction); ds_read_b64 sees 64 banks and
-    // the 32 codes x 8 B of a row-block are conflict-free.  Loads run two
-    // batches ahead; the compiler does not count inline-asm loads, so the
-    // waits are explicit (all but the newest 2 = the batch issued last).
-    struct Raw { u32x2 lo, hi; };
-    template <int RB>
-    static __device__ __forceinline__ void ld(uint32_t a_lo, uint32_t a_hi, Raw &r)
-    {
-        asm volatile("ds_read_b64 %0, %2 offset:%4\n\t"
-                     "ds_read_b64 %1, %3 offset:%4"
-                     : "=&v"(r.lo), "=&v"(r.hi)
-                     : "v"(a_lo), "v"(a_hi), "i"(RB * 256)
-                     : "memory", OSW_INFLIGHT);
-    }
-    template <int Newest>
-    static __device__ __forceinline__ void landed(Raw &r)
-    {
-        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.lo), "+v"(r.hi)::OSW_INFLIGHT);
-        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r.lo), "+v"(r.hi)::OSW_INFLIGHT);
-    }
-    static __device__ __forceinline__ void pair_up(const Raw &r, T (&s)[4])
-    {
-        s[0] = as_v2s(__builtin_amdgcn_perm(r.hi.x, r.lo.x, 0x05040100u));
-        s[1] = as_v2s(__builtin_amdgcn_perm(r.hi.x, r.lo.x, 0x07060302u));
-        s[2] = as_v2s(__builtin_amdgcn_perm(r.hi.y, r.lo.y, 0x05040100u));
-        s[3] = as_v2s(__builtin_amdgcn_perm(r.hi.y, r.lo.y, 0x07060302u));
-    }
-
-    template <int R, int RB, int P>
-    struct Batch {
-        // s = scores of this row-block (paired), r1 = raw next block (in flight); once r1 has been
-        // paired up its registers take the load of the block after it (one block ahead is enough:
-        // a block is ~35 VALU instructions, LDS latency a fraction of that)
-        static __device__ __forceinline__ void run(uint32_t a_lo, uint32_t a_hi, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge,
-                                                   T &score, T (&s)[4], Raw &r1, T aux)
-        {
-            T sn[4];
-            if constexpr (RB + 1 < R / 4) {
-                landed<0>(r1);
-                pair_up(r1, sn);
-                if constexpr (RB + 2 < R / 4) ld<RB + 2>(a_lo, a_hi, r1);
-            }
-            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s[1], ge, goe, aux);
-            A::template row<P, true, RB == 0>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s[2], ge, goe, aux);
-            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s[3], ge, goe, aux);
-            if constexpr (RB + 1 < R / 4) {
-                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn[0], ge, goe, aux);
-                Batch<R, RB + 1, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, sn, r1, aux);
-            } else {
-                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe, aux);
-            }
-        }
-    };
-
     // One database column against the R rows of the strip, inputs in register set P:
     //   residues {8*code of the lane's first sequence, 8*code of the second} in bytes 0 / 1 of
     //   the set's C register (8*code = byte offset of the code's profile entry), F(i0, j) in its
     //   F register (out: F(i0+R, j)).  base = LDS byte address of the lane's profile slice;
     //   top_prev = H(i0-1, j-1); hl = H(i0+R-1, j).
+    // Four rows of substitution scores for both sequences of the lane are two ds_read_b64 (one per
+    // sequence; single ones: a ds_read2_b64's 32-bank addressing makes residue codes c and c+16
+    // collide, measured 2.5 conflict cycles per LDS instruction, while ds_read_b64 sees 64 banks and
+    // the 32 codes x 8 B of a row-block are conflict-free) + four v_perm_b32 that pair up (lo, hi);
+    // the loads run two blocks ahead, inside the blocks' statements (ArithI16*::block).
+    template <int R, int RB>
+    struct Blocks {
+        static __device__ __forceinline__ void run(uint32_t a0, uint32_t a1, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge, T &score, T aux)
+        {
+            A::template block<RB, R / 4, true>(a0, a1, D, E, x, hl, score, ge, goe, aux);
+            if constexpr (RB + 1 < R / 4) Blocks<R, RB + 1>::run(a0, a1, D, E, x, hl, goe, ge, score, aux);
+        }
+    };
     template <int R, int P>
     static __device__ __forceinline__ void column(uint32_t base, int /*half*/, T (&D)[R], T (&E)[R], T top_prev, T &hl, GapT goe, GapT ge,
                                                   T &score, T aux)
     {
-        uint32_t a_lo, a_hi;
-        if constexpr (P == 0)
-            asm volatile("v_add_u32_sdwa %0, %2, " OSW_VC0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                         "v_add_u32_sdwa %1, %2, " OSW_VC0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
-                         : "=&v"(a_lo), "=&v"(a_hi) : "v"(base) : OSW_INFLIGHT);
-        else
-            asm volatile("v_add_u32_sdwa %0, %2, " OSW_VC1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                         "v_add_u32_sdwa %1, %2, " OSW_VC1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
-                         : "=&v"(a_lo), "=&v"(a_hi) : "v"(base) : OSW_INFLIGHT);
-        Raw r0, r1;
-        T s[4];
-        ld<0>(a_lo, a_hi, r0);
-        if constexpr (R / 4 > 1) { ld<1>(a_lo, a_hi, r1); landed<2>(r0); } else { landed<0>(r0); }
-        pair_up(r0, s);
-        T x = A::first_diag(top_prev, s[0]);
-        Batch<R, 0, P>::run(a_lo, a_hi, D, E, x, hl, goe, ge, score, s, r1, aux);
+        uint32_t a0, a1;
+        T x;
+        A::template head<P, R / 4, true>(base, 0u, top_prev, a0, a1, x);
+        Blocks<R, 0>::run(a0, a1, D, E, x, hl, goe, ge, score, aux);
     }
 };
 
@@ -466,60 +486,24 @@ struct CellQueryPair {
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
 
-    template <int RB>
-    static __device__ __forceinline__ void ld(uint32_t a, u32x4 &r)
-    {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(a), "i"(RB * 512) : "memory", OSW_INFLIGHT);
-    }
-    template <int Newest>
-    static __device__ __forceinline__ void landed(u32x4 &r)
-    {
-        if constexpr (Newest == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)::OSW_INFLIGHT);
-        else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r)::OSW_INFLIGHT);
-    }
-
-    template <int R, int RB, int P>
-    struct Batch {
-        static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge, T &score,
-                                                   u32x4 &r0, u32x4 &r1, T aux)
+    // profile entry of the lane's residue: 16 B per code = 2 x (8*code); the loads run two blocks ahead, inside
+    // the blocks' statements (ArithI16*::block)
+    template <int R, int RB>
+    struct Blocks {
+        static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge, T &score, T aux)
         {
-            // r0 = this row-block (landed; .x was used by the row above), r1 = next (in flight); r0 takes
-            // the load of the block after next as soon as its last score has been read
-            T s1 = as_v2s(r0.y), s2 = as_v2s(r0.z), s3 = as_v2s(r0.w);
-            A::template row<P, false>(x, E[RB * 4 + 0], D[RB * 4 + 1], D[RB * 4 + 0], score, s1, ge, goe, aux);
-            A::template row<P, true, RB == 0>(x, E[RB * 4 + 1], D[RB * 4 + 2], D[RB * 4 + 1], score, s2, ge, goe, aux);
-            A::template row<P, false>(x, E[RB * 4 + 2], D[RB * 4 + 3], D[RB * 4 + 2], score, s3, ge, goe, aux);
-            if constexpr (RB + 1 < R / 4) {
-                if constexpr (RB + 2 < R / 4) { ld<RB + 2>(a, r0); landed<1>(r1); } else { landed<0>(r1); }
-                T sn = as_v2s(r1.x);
-                A::template row<P, true>(x, E[RB * 4 + 3], D[RB * 4 + 4], D[RB * 4 + 3], score, sn, ge, goe, aux);
-                Batch<R, RB + 1, P>::run(a, D, E, x, hl, goe, ge, score, r1, r0, aux);
-            } else {
-                A::template row_last<P>(x, E[RB * 4 + 3], D[RB * 4 + 3], hl, score, ge, goe, aux);
-            }
+            A::template block<RB, R / 4, false>(a, a, D, E, x, hl, score, ge, goe, aux);
+            if constexpr (RB + 1 < R / 4) Blocks<R, RB + 1>::run(a, D, E, x, hl, goe, ge, score, aux);
         }
     };
-
     template <int R, int P>
     static __device__ __forceinline__ void column(uint32_t base, int half, T (&D)[R], T (&E)[R], T top_prev, T &hl, GapT goe, GapT ge,
                                                   T &score, T aux)
     {
-        // profile entry of the lane's residue: 16 B per code = 2 x (8*code)
-        uint32_t a;
-        const uint32_t sh = (uint32_t)half * 8u;
-        if constexpr (P == 0)
-            asm volatile("v_bfe_u32 %0, " OSW_VC0 ", %2, 8\n\t"
-                         "v_lshl_add_u32 %0, %0, 1, %1"
-                         : "=&v"(a) : "v"(base), "s"(sh) : OSW_INFLIGHT);
-        else
-            asm volatile("v_bfe_u32 %0, " OSW_VC1 ", %2, 8\n\t"
-                         "v_lshl_add_u32 %0, %0, 1, %1"
-                         : "=&v"(a) : "v"(base), "s"(sh) : OSW_INFLIGHT);
-        u32x4 r0, r1;
-        ld<0>(a, r0);
-        if constexpr (R / 4 > 1) { ld<1>(a, r1); landed<1>(r0); } else { landed<0>(r0); }
-        T x = A::first_diag(top_prev, as_v2s(r0.x));
-        Batch<R, 0, P>::run(a, D, E, x, hl, goe, ge, score, r0, r1, aux);
+        uint32_t a, unused;
+        T x;
+        A::template head<P, R / 4, false>(base, (uint32_t)half * 8u, top_prev, a, unused, x);
+        Blocks<R, 0>::run(a, D, E, x, hl, goe, ge, score, aux);
     }
 };
 
@@ -902,7 +886,8 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
 {
 #define OSW_ROUND_CASE(RR)                                                                                                      \
     case RR:                                                                                                                    \
-        if constexpr (std::is_same<C, CellQ8F>::value) sw_round_q8f<RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, goe, score); \
+        if constexpr (RR > C::kRows) break; /* taller than the cell's strips: never planned, not compiled */                    \
+        else if constexpr (std::is_same<C, CellQ8F>::value) sw_round_q8f<RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, goe, score); \
         else if constexpr (C::kFast) sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score); \
         else sw_round_plain<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);                  \
         break

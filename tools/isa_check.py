@@ -32,11 +32,11 @@ STAMP = os.path.join(ROOT, "oswald_amd", "liboswald_hip.isa.json")
 # parked before a round; inside the loops check_vmem_windows allows none)
 GROUPS = (
     dict(kernels=("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q"), define="OSW_INFLIGHT", file="sw_kernels.hip",
-         budget=168,   # three waves per SIMD; the compiler gets 160, the asm 8 more
-         scratch=32, min_asm_uses=1000),
+         budget=168,   # three waves per SIMD; the compiler gets 148, the asm statements 19 fixed ones (v158 is spare)
+         scratch=32, min_asm_uses=1000, nfixed=19),
     dict(kernels=("osw_sw_q8",), define="OSW8_INFLIGHT", file="q8_cell.h",
          budget=80,    # six waves per SIMD; the compiler gets 72, the asm 8 more
-         scratch=0, min_asm_uses=100),
+         scratch=0, min_asm_uses=100, nfixed=8),
 )
 KERNELS = tuple(k for g in GROUPS for k in g["kernels"])
 SOURCES = ("sw_kernels.hip", "sw_kernels.h", "q8_cell.h", "oswald_hip.cpp", "osw_planner.inc")
@@ -50,7 +50,7 @@ def hipcc_path():
 def reserved_registers(group=GROUPS[0]):
     m = re.search(r'#define %s (.*)' % group["define"], open(os.path.join(CSRC, group["file"])).read())
     regs = [int(x) for x in re.findall(r'"v(\d+)"', m.group(1))]
-    assert len(regs) == 8
+    assert len(regs) == group["nfixed"], (group["define"], regs)
     return set(regs)
 
 

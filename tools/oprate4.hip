@@ -18,6 +18,7 @@
 //   row                the column-frame cell's row, dependencies as in the kernel: add, max3, sub, max3, max3, sub (+1/2 max3)
 //   row_alls           the same row with the three VOP2 instructions as VOP3P (round 1's row)
 //   row_prio           the row with s_setprio 1 on the odd waves of a SIMD
+//   row4, row4n, row4n1, row4n3   the rows four to an asm statement, with no / s_nop 0 / s_nop 1 / s_nop 3 behind every row
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/oprate4 tools/oprate4.hip ; run: tools/oprate4 [probe-substring]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -130,6 +131,47 @@ ROW_PROBE(p_row, ROW_V2, 0)
 ROW_PROBE(p_row_alls, ROW_PK, 0)
 ROW_PROBE(p_row_prio, ROW_V2, 1)
 
+
+// The same 8 rows as two statements of four (no compiler-made s_nop between the rows of a statement), with nothing / an
+// s_nop 0 / an s_nop 1 behind every row: what the hazard recogniser's s_nop behind every asm statement costs (or buys).
+#define RTXT(xn, x, E, Dn, NOP)                                     \
+    "v_add_u32 " xn ", " Dn ", %[s]\n\t"                            \
+    "v_pk_maximum3_f16 " Dn ", " x ", " E ", %[Fc]\n\t"             \
+    "v_subrev_u32 %[t], %[go], " Dn "\n\t"                          \
+    "v_pk_maximum3_f16 " E ", " E ", %[t], %[fl]\n\t"               \
+    "v_pk_maximum3_f16 %[Fc], %[Fc], %[t], %[fl]\n\t"               \
+    "v_subrev_u32 %[Fc], %[ge], %[Fc]\n\t" NOP
+#define RMAXT(a, b) "v_pk_maximum3_f16 %[sc], %[sc], " a ", " b "\n\t"
+#define ROW4(e0, d1, d2, d3, d4, NOP)                                                                                              \
+    asm volatile(RTXT("%[xb]", "%[x]", "%[E0]", "%[D1]", NOP) RTXT("%[x]", "%[xb]", "%[E1]", "%[D2]", NOP) RMAXT("%[D1]", "%[D2]")  \
+                 RTXT("%[xb]", "%[x]", "%[E2]", "%[D3]", NOP) RTXT("%[x]", "%[xb]", "%[E3]", "%[D4]", NOP) RMAXT("%[D3]", "%[D4]")  \
+                 : [x] "+v"(xx), [xb] "=&v"(xn), [t] "=&v"(t), [E0] "+v"(E[e0]), [E1] "+v"(E[e0 + 1]), [E2] "+v"(E[e0 + 2]),       \
+                   [E3] "+v"(E[e0 + 3]), [D1] "+v"(D[d1]), [D2] "+v"(D[d2]), [D3] "+v"(D[d3]), [D4] "+v"(D[d4]), [Fc] "+v"(Fc),    \
+                   [sc] "+v"(sc)                                                                                                   \
+                 : [s] "v"(c1), [go] "v"(go), [ge] "v"(ge), [fl] "v"(fl));
+#define ROW4_PROBE(name, NOP)                                                                                     \
+    __global__ __launch_bounds__(256) void name(Stamp *out, uint32_t c1, uint32_t c2, int iters)                  \
+    {                                                                                                             \
+        extern __shared__ uint32_t pad_lds[];                                                                     \
+        if (iters < 0) pad_lds[threadIdx.x] = c1;                                                                 \
+        uint32_t x[16], D[8], E[8], Fc = c2, xx = c2, sc = c2, xn, t;                                             \
+        uint32_t go = 0x000a000au, ge = 0x00020002u, fl = c2;                                                     \
+        asm volatile("" : "+v"(go), "+v"(ge), "+v"(fl));                                                          \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) x[i] = 0;                                                  \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) { D[i] = c2 + threadIdx.x; E[i] = c2; }                     \
+        const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();        \
+        for (int it = 0; it < iters; ++it) {                                                                      \
+            ROW4(0, 1, 2, 3, 4, NOP) ROW4(4, 5, 6, 7, 0, NOP)                                                     \
+        }                                                                                                         \
+        x[0] = sc ^ xx ^ Fc;                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) x[1] ^= D[i] ^ E[i];                                        \
+        PROBE_EPILOGUE                                                                                            \
+    }
+ROW4_PROBE(p_row4, "")
+ROW4_PROBE(p_row4n, "s_nop 0\n\t")
+ROW4_PROBE(p_row4n1, "s_nop 1\n\t")
+ROW4_PROBE(p_row4n3, "s_nop 3\n\t")
+
 struct Probe { const char *name; void (*kern)(Stamp *, uint32_t, uint32_t, int); double per_iter; const char *what; };
 
 int main(int argc, char **argv)
@@ -144,6 +186,8 @@ int main(int argc, char **argv)
         {"fs_vop3", p_fs_vop3, 16, "F + v_max3_i32"}, {"fmov_s", p_fmov_s, 16, "v_mov_b32 + S"}, {"fs_nop", p_fs_nop, 16, "F + S + s_nop 0"},
         {"row", p_row, 52, "cell row, 3 VOP2 + 3.5 VOP3P (per 6.5 instructions)"}, {"row_alls", p_row_alls, 52, "cell row, all VOP3P"},
         {"row_prio", p_row_prio, 52, "cell row, odd waves at s_setprio 1"},
+        {"row4", p_row4, 52, "cell rows, four to a statement (no s_nop)"}, {"row4n", p_row4n, 52, "... with s_nop 0 behind every row"},
+        {"row4n1", p_row4n1, 52, "... with s_nop 1 behind every row"}, {"row4n3", p_row4n3, 52, "... with s_nop 3 behind every row"},
     };
     Stamp *o;
     (void)hipMalloc(&o, (size_t)cus * 8 * 4 * sizeof(Stamp));
