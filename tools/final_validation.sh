@@ -32,5 +32,6 @@ python tests/shard_balance_gpu.py 2 4 8 > $OUT/shard_balance.txt 2>&1; echo "sha
 tools/q1_tail.sh > $OUT/q1_tail.txt 2>&1; echo "q1 tail rc=$?"
 timeout -k 10 200 ./tools/oprate_q8 > $OUT/oprate_q8.txt 2>&1
 timeout -k 10 200 ./tools/oprate4 > $OUT/oprate4.txt 2>&1
+timeout -k 10 100 ./tools/oprate5 > $OUT/oprate5.txt 2>&1
 python tools/cli_e2e.py 1000000 > $OUT/cli_1m.txt 2>&1; echo "cli e2e rc=$?"; tail -5 $OUT/cli_1m.txt
 tools/startup_probe.sh > $OUT/startup.txt 2>&1
