@@ -191,12 +191,42 @@ def main():
     index_base = 0 if strong else rank * nseq_total      # weak mode: global index = shard base + sorted position
 
     ctx = capi.Context(1, [gpu])
+    gather_note = None
     if gather == "lib":
         # the gather lives in the C ABI: rank 0 makes the id, torch.distributed hands it round, every rank joins
-        ident = [capi.comm_unique_id() if rank == 0 else None]
+        lib_error = None
+        try:
+            ident = [capi.comm_unique_id() if rank == 0 else None]
+        except capi.OswaldHipError as e:
+            ident, lib_error = [None], str(e)
         if dist is not None:
             dist.broadcast_object_list(ident, src=0, device=coll_dev)
-        ctx.comm_init_rank(ident[0], world, rank)
+        if ident[0] is None:
+            lib_error = lib_error or "rank 0 could not make a communicator id"
+        elif os.environ.get("OSWALD_BENCH_FAIL_LIB_COMM"):   # test hook: no rank joins (tests/test_gpu_bench_contract.py)
+            lib_error = "OSWALD_BENCH_FAIL_LIB_COMM is set"
+        else:
+            try:
+                ctx.comm_init_rank(ident[0], world, rank)
+            except capi.OswaldHipError as e:
+                lib_error = str(e)
+        # Whether the library's communicator stands is decided by ALL ranks together (a flag through the RCCL group torch
+        # already has): either every rank gathers inside the C ABI or every rank gathers through torch.distributed --
+        # over RCCL in both cases, never over another backend.  `--gather lib` asked for by name does not degrade.
+        failed = 1 if lib_error else 0
+        if dist is not None:
+            flag = torch.tensor([failed], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = int(flag.item())
+        if failed:
+            why = lib_error or "another rank could not join the library's communicator"
+            if args.gather == "lib" or dist is None:
+                raise SystemExit(f"bench.py: the library's RCCL communicator could not be made on rank {rank}: {why}")
+            gather = "torch"
+            gather_note = ("oswald_hip_comm_init_rank failed (" + why[:200] + "): the ranks' lists are carried by torch.distributed.all_gather "
+                           "over the same RCCL backend instead of by oswald_hip_topr")
+            if rank == 0:
+                print("bench.py: " + gather_note, file=sys.stderr, flush=True)
     cell_bits = args.cell_bits or (8 if args.workload in ("c3", "hi8") else 16)
     ctx.set_scoring(sm, wl["go"], wl["ge"], cell_bits)
     ctx.set_queries(a, m, a_disp)
@@ -301,7 +331,7 @@ def main():
                        "queries": nq, "query_residues": sum_m, "db_sequences_total": nseq_total * (1 if strong else world),
                        "db_residues_total": int(d_total), "matrix": wl["matrix"], "gap_open": wl["go"], "gap_extend": wl["ge"],
                        "top": args.top, "sharding": shard_note, "shard_rule": args.shard_rule, "collective_backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 or gather == "lib" else None,
-                       "collective_note": None, "collective_ranks": coll_ranks,
+                       "collective_note": gather_note, "collective_ranks": coll_ranks,
                        "collective_via": ("liboswald_hip.so: ncclAllGather of nq x r tagged keys inside oswald_hip_topr, folded on the GPU (RCCL %d)" % ctx.comm_info()["rccl_version"]) if gather == "lib"
                                          else ("torch.distributed.all_gather" if world > 1 else None), "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -110,3 +110,13 @@ def test_bench_two_gpus_over_rccl(first_pass):
         assert ("liboswald_hip.so" in c["collective_via"]) == (extra[1] == "lib")
         assert d["top_equals_single_gpu_golden"] is True and d["top1_scores"] == gold
         assert d["value"] > 100
+    # the library's communicator cannot be made (test hook: no rank joins it): the ranks decide TOGETHER to carry their lists
+    # through torch.distributed -- still RCCL, and the line says so; asked for by name, `--gather lib` ends non-zero instead
+    d = _bench(common, dict(env, MASTER_PORT="29626", OSWALD_BENCH_FAIL_LIB_COMM="1"))
+    c = d["config"]
+    assert c["collective_backend"] == "RCCL (nccl)" and c["collective_ranks"] == 2 and c["collective_via"] == "torch.distributed.all_gather"
+    assert "oswald_hip_comm_init_rank failed" in c["collective_note"]
+    assert d["top_equals_single_gpu_golden"] is True and d["top1_scores"] == gold
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--gather", "lib"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(env, MASTER_PORT="29627", OSWALD_BENCH_FAIL_LIB_COMM="1"))
+    assert r.returncode != 0 and "communicator could not be made" in r.stderr

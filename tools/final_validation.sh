@@ -4,13 +4,21 @@
 # the microbenchmarks.  Everything lands under gpurun_out/final/ (scratch); tools/collect_final.py ROUND copies what is
 # cited into profiles/.  The profile passes come FIRST: they write the traffic files of the sources being validated, so
 # that the bench lines behind them carry roofline.traffic.
+# tools/final_validation.sh ROUND prof | bench: the two halves as two GPU calls (a call is limited to 20 minutes); after `prof`,
+# copy gpurun_out/prof_*/traffic_*.json into profiles/ in the build container so that the snapshot of `bench` holds them.
+# The tool binaries and the diag library come from `make -C tools` (build container).
 R=${1:-04}
+PART=${2:-all}
 OUT=gpurun_out/final
-rm -rf $OUT; mkdir -p $OUT
+if [ "$PART" != bench ]; then rm -rf $OUT; fi
+mkdir -p $OUT
+if [ "$PART" != bench ]; then
 for spec in "c2 1000000" "c2 100000" "c3 100000" "c5 100000" "q1 100000" "q1 1000000"; do
   bash tools/profile_gpu.sh $spec > $OUT/prof_$(echo $spec | tr ' ' '_').log 2>&1; echo "profile $spec rc=$?"
   cp gpurun_out/prof_$(echo $spec | tr ' ' '_')/traffic_*.json profiles/ 2>/dev/null   # (in this box's copy of the tree: bench.py below reads them)
 done
+fi
+if [ "$PART" = prof ]; then exit 0; fi
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 b() { name=$1; shift; python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "bench $name rc=$? $(python -c "import json;l=[x for x in open('$OUT/bench_$name.json').read().split(chr(10)) if x.startswith('{')];d=json.loads(l[-1]);print(d['value'],d['ms_per_step'],d['roofline']['kernel_ms'],d['roofline']['traffic'],d.get('top_equals_single_gpu_golden'))" 2>/dev/null)"; }
@@ -33,5 +41,6 @@ tools/q1_tail.sh > $OUT/q1_tail.txt 2>&1; echo "q1 tail rc=$?"
 timeout -k 10 200 ./tools/oprate_q8 > $OUT/oprate_q8.txt 2>&1
 timeout -k 10 200 ./tools/oprate4 > $OUT/oprate4.txt 2>&1
 timeout -k 10 100 ./tools/oprate5 > $OUT/oprate5.txt 2>&1
+timeout -k 10 100 ./tools/oprate6 > $OUT/oprate6.txt 2>&1
 python tools/cli_e2e.py 1000000 > $OUT/cli_1m.txt 2>&1; echo "cli e2e rc=$?"; tail -5 $OUT/cli_1m.txt
 tools/startup_probe.sh > $OUT/startup.txt 2>&1
