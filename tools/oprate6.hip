@@ -10,6 +10,10 @@
 //   d16     8 ds_read_u16_d16[_hi] per block from the SAME profile layout (codes c and c+16 share a bank for 4-byte-class reads)
 //   d16r    the same from a [row][32 codes] int16 layout (a row's 24 codes lie in 12 dwords: conflict-free)
 //   none    no loads, no perms (the VALU floor of the 6.5-instruction row)
+//   mix     the kernel's 2 ds_read_b64 + ONE 16-bit load per row that completes a pair in place, with 1 / 4 / 8 lane groups
+// TIMING ONLY: on this part (SRAM-ECC) a d16 load zeroes the other half of its register instead of keeping it (LABNOTES,
+// "What did not work" (1)), so the d16 forms do not compute the pairs they are priced for; the probe answers whether the
+// LDS could carry the pairing if they did.  Result (profiles/r04_oprate6_lds_pairing.txt): only with one lane group.
 // and reports core-clock cycles per row per SIMD (median / slowest / fastest SIMD of the chip), like tools/oprate4.hip.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/oprate6 tools/oprate6.hip ; run: tools/oprate6 [columns]
 #include <hip/hip_runtime.h>
