@@ -124,14 +124,32 @@ summary["pmc_write"] = pmc("write")
 summary["pmc_sq"] = pmc("sq")
 summary["pmc_sq2"] = pmc("sq2")
 summary["pmc_clk"] = pmc("clk")
-# effective core clock under the DP kernels' load: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration of the same kernel
-# in the trace pass (MI355X_MICROARCH.md "DVFS give-back"; within 3 % of the in-kernel clock on dispatches of >= 10 ms)
+# effective core clock under the DP kernels' load: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the duration of THE SAME
+# dispatch in the counter pass (its Start / End timestamps; MI355X_MICROARCH.md "DVFS give-back").  (Until the second session of
+# round 4 the counter was divided by the kernel's duration in the TRACE pass: a dispatch runs up to 25 % longer under counter
+# collection, so that quotient came out anywhere between 2.2 and 2.76 "GHz" for osw_sw_q8 from one box to the next.)
+def clk_per_dispatch():
+    f = find("clk", "*counter_collection.csv")
+    res = {}
+    if not f:
+        return res
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "").split("(")[0].strip()
+        if name not in DP or r.get("Counter_Name") != "GRBM_GUI_ACTIVE":
+            continue
+        if int(r.get("Grid_Size", "0") or 0) <= int(r.get("Workgroup_Size", "256") or 256):
+            continue  # bring-up launch on empty queues
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if dur >= 1000000:  # >= 1 ms
+            res.setdefault(name, []).append((float(r["Counter_Value"]), dur))
+    return res
 clk = {}
-for kn in DP:
-    g = summary["pmc_clk"].get(kn, {}).get("GRBM_GUI_ACTIVE", {}).get("per_dispatch")
+for kn, lst in clk_per_dispatch().items():
     tr = summary.get(kn + "_trace")
-    if g and tr and tr["avg_ms"] >= 1.0:
-        clk[kn] = {"ghz": g / 8.0 / (tr["avg_ms"] * 1e6), "gui_active_per_dispatch": g, "trace_avg_ms": tr["avg_ms"]}
+    if lst and tr:
+        g = [v / 8.0 / d for v, d in lst]
+        clk[kn] = {"ghz": sum(g) / len(g), "ghz_min": min(g), "ghz_max": max(g), "dispatches": len(g),
+                   "counter_pass_avg_ms": sum(d for _, d in lst) / len(lst) / 1e6, "trace_avg_ms": tr["avg_ms"]}
 if clk:
     summary["effective_clock"] = clk
     dom = max(clk, key=lambda k: clk[k]["trace_avg_ms"])
