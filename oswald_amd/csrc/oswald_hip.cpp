@@ -63,6 +63,8 @@ struct Tunables {
     int pairs = 1;                     // OSWALD_HIP_PAIRS=0|1|2: never pair / pair when cheaper / pair every neighbour
     bool debug_plan = false;           // OSWALD_HIP_DEBUG=1: print the work-queue plan
     bool debug_phases = false;         // OSWALD_HIP_DEBUG_PHASES=1: wall time of the host-side phases
+    bool plan_on_estimates = false;     // OSWALD_HIP_PLAN_EST=1 (experiment): every search is planned on the group-length extents
+    bool plan_waits_for_upload = false; // OSWALD_HIP_PLAN_WAITS=1 (test hook): a search waits for its chunk's upload and plans on the live extents (the behaviour before the second session of round 4)
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
@@ -86,6 +88,8 @@ void Tunables::refresh()
     pairs = (int)num("OSWALD_HIP_PAIRS", 1);
     debug_plan = flag("OSWALD_HIP_DEBUG");
     debug_phases = flag("OSWALD_HIP_DEBUG_PHASES");
+    plan_waits_for_upload = flag("OSWALD_HIP_PLAN_WAITS");
+    plan_on_estimates = flag("OSWALD_HIP_PLAN_EST");
     no_pin = flag("OSWALD_HIP_NO_PIN");
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
@@ -124,6 +128,21 @@ struct PhaseTimer {
     }
 };
 
+// ... and without any synchronisation of its own: which section of a call held the host (OSWALD_HIP_DEBUG_SLOW)
+struct HoldTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit HoldTimer(bool enabled) : on(enabled), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(n - t).count();
+        if (ms > 3.0) fprintf(stderr, "[oswald_hip] the host was held %.1f ms in: %s\n", ms, what);
+        t = n;
+    }
+};
+
 // A device buffer that only ever grows.
 struct DevBuf {
     void *p = nullptr;
@@ -152,7 +171,22 @@ struct Chunk {
     uint32_t score_stride = 0;   // nblocks*128
     uint32_t max_ncols4 = 0;     // largest stored extent of a block
     uint64_t total_col4 = 0;     // stored 4-column groups incl. the pad group per block
-    DevBuf tiled, blocks, sub_cols_buf, items, items_q, scores, ovf, ovf8;
+    DevBuf tiled, blocks, sub_cols_buf, scores, ovf, ovf8;
+    // The work queues, two sets in turn: a plan goes to the device on the copy stream AT ONCE, and since a search is planned
+    // while its chunk's upload is still on its way, the search of the slot's previous chunk may still be running -- and reading
+    // the set the plan before this one was copied into.  (The set before that is free: a slot is re-used only after
+    // oswald_hip_chunk_release, which returns when the released chunk's upload has landed, i.e. after the search of the chunk
+    // before it.)
+    DevBuf items_buf[2], items_q_buf[2];
+    int items_cur = 0;
+    // ... and their page-locked sources, so that the copy is asynchronous and the host never waits for the copy stream (whatever
+    // holds it: with a slot re-used beside a running search the plan's copy has been seen to wait for that search, 110 ms);
+    // the launches of the search wait for ev_items on the device instead
+    uint2 *items_pin[2] = {nullptr, nullptr};
+    size_t items_pin_cap[2] = {0, 0};   // entries (both queues, one behind the other)
+    hipEvent_t ev_items = nullptr;
+    DevBuf &items_dev() { return items_buf[items_cur]; }
+    DevBuf &items_q_dev() { return items_q_buf[items_cur]; }
     const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     // host copy of the live extents (see osw_retile16 / osw_block_extent), for the planner: PAGE-LOCKED, so that the copy
@@ -161,6 +195,12 @@ struct Chunk {
     // persistent search grid leaves no wave slot free) returned when that search was over, 114 ms later
     uint16_t *sub_cols = nullptr;
     size_t sub_cols_cap = 0;            // entries
+    // The same table as the host can tell it from the group lengths alone (every sequence as long as its group: at most 27
+    // columns of the reference's x28 padding + the spread inside a group too long): what the planner works with while the
+    // chunk's upload is still on its way -- it only ORDERS and SIZES the items by these figures, the kernels read the live
+    // extents on the device -- so that a search can be planned and queued behind an upload the host has not waited for.
+    std::vector<uint16_t> sub_cols_est;
+    bool items_exact = false;           // the item list was planned on the live extents
     std::vector<OswBlock> blocks_host;  // the block table as planned on the host ...
     OswBlock *blocks_pin = nullptr;     // ... and its page-locked copy, the source of the asynchronous upload
     size_t blocks_pin_cap = 0;
@@ -429,6 +469,14 @@ int finish_upload(Device &d, Chunk &c)
 
 void drain_events(Device &d)
 {
+    if (g_debug_slow && d.ev_used.size() > 1) { // (OSWALD_HIP_DEBUG_SLOW: how the searches of a pass lie on the device's time line)
+        for (size_t k = 0; k < d.ev_used.size(); ++k) {
+            float dur = 0, gap = 0;
+            (void)hipEventElapsedTime(&dur, d.ev_used[k].a, d.ev_used[k].b);
+            if (k + 1 < d.ev_used.size()) (void)hipEventElapsedTime(&gap, d.ev_used[k].b, d.ev_used[k + 1].a);
+            fprintf(stderr, "[oswald_hip] search %zu: %.3f ms on the device, %.3f ms to the next search's start\n", k, dur, gap);
+        }
+    }
     for (auto &e : d.ev_used) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { d.dp_ms += ms; d.dp_launches++; }
@@ -546,8 +594,22 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_up, hipStreamNonBlocking);
-        if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_copy, hipStreamNonBlocking);
-        if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_down, hipStreamNonBlocking);
+        // The two DMA-only streams are HIGH-PRIORITY streams.  Not for the priority: the runtime maps the streams of a priority
+        // class onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by default, shared with whatever streams the caller's
+        // process has), and a copy on a stream that shares its hardware queue with the search stream starts only when the search
+        // -- a persistent grid that holds its queue for the whole launch -- has ended.  As the fourth and fifth ordinary stream of
+        // the process the copy stream did share the search stream's queue (tools/xfer_overlap.hip, profiles/r04_xfer_overlap.txt:
+        // 128 MB beside a 60 ms kernel: done after 2.4 ms on a queue of its own, after 60 ms on the shared one); the
+        // high-priority class has a pool of its own.
+        int prio_least = 0, prio_greatest = 0;
+        if (r == hipSuccess) r = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        // ... and each of the two gets a class of its own (copy: highest, download: lowest): the download stream WAITS for searches
+        // (a table leaves behind its search), and a wait at the head of a hardware queue holds whatever else shares that queue
+        // -- with both streams in the high-priority class a plan's queue copy sat behind the download stream's wait for the
+        // running search: 110 ms (OSWALD_HIP_DEBUG_SLOW).  No kernel runs on either stream, so the priorities themselves do nothing.
+        if (r == hipSuccess) r = hipStreamCreateWithPriority(&d.stream_copy, hipStreamNonBlocking, prio_greatest);
+        if (r == hipSuccess) r = hipStreamCreateWithPriority(&d.stream_down, hipStreamNonBlocking, prio_least);
+        if (g_debug_slow) fprintf(stderr, "[oswald_hip] stream priorities: least %d, greatest %d\n", prio_least, prio_greatest);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming);
         if (r == hipSuccess) r = hipEventCreateWithFlags(&d.ev_top, hipEventDisableTiming);
@@ -632,6 +694,9 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
             if (c.ev_down) (void)hipEventDestroy(c.ev_down);
             c.ev_down = nullptr;
             if (c.sub_cols) (void)hipHostFree(c.sub_cols);
+            for (int k = 0; k < 2; ++k) { if (c.items_pin[k]) (void)hipHostFree(c.items_pin[k]); c.items_pin[k] = nullptr; c.items_pin_cap[k] = 0; }
+            if (c.ev_items) (void)hipEventDestroy(c.ev_items);
+            c.ev_items = nullptr;
             if (c.blocks_pin) (void)hipHostFree(c.blocks_pin);
             c.ev_up = c.ev_use = c.ev_copy = nullptr;
             c.sub_cols = nullptr;
@@ -642,7 +707,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         }
         if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.items.release(); c.items_q.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); if (c.ev_map) (void)hipEventDestroy(c.ev_map); c.ev_map = nullptr; }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); for (int k = 0; k < 2; ++k) { c.items_buf[k].release(); c.items_q_buf[k].release(); } c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); if (c.ev_map) (void)hipEventDestroy(c.ev_map); c.ev_map = nullptr; }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
                           &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
@@ -781,6 +846,22 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
         off += (uint64_t)nc4 + OSW_TILED_PAD_GROUPS; // + the all-dummy groups the kernels prefetch / drain through
     }
     c.total_col4 = off;
+    // live extents as far as the group lengths tell them (sub_cols_est): lane l of a block holds its sequences 2l, 2l+1
+    c.sub_cols_est.assign((size_t)c.nblocks * 128, 0);
+    for (uint32_t B = 0; B < c.nblocks; ++B) {
+        uint16_t lane_n[64];
+        for (uint32_t l = 0; l < 64; ++l) {
+            const uint32_t g = B * gpb + (2 * l) / W;
+            lane_n[l] = g < ngroups ? n[g] : 0;
+        }
+        uint16_t *e = c.sub_cols_est.data() + (size_t)B * 128;
+        for (uint32_t t = 0; t < 127; ++t) {
+            const uint32_t lg = 31u - (uint32_t)__builtin_clz(t + 1u), sigma = t + 1u - (1u << lg), gl = 64u >> lg;
+            uint16_t mx = 0;
+            for (uint32_t k = 0; k < gl; ++k) mx = std::max(mx, lane_n[sigma * gl + k]);
+            e[t] = mx;
+        }
+    }
     if (int r = ensure_scratch(d, c.max_ncols4 * 4)) return r;
     HIP_TRY(c.tiled.reserve((off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2)));
     HIP_TRY(c.blocks.reserve(c.nblocks * sizeof(OswBlock) + 16));
@@ -911,11 +992,28 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     PhaseTimer pt(ctx->tun.debug_phases);
     if (ctx->topr_r && c.has_index && ctx->topr_queries_version != ctx->queries_version)
         return fail(OSWALD_HIP_ESTATE, "the query set changed since oswald_hip_topr_begin: call it again before searching");
-    if (int r = finish_upload(d, c)) return r; // the planner reads the chunk's live extents; the kernels queued below find the chunk in place
+    // An upload the host has not waited for and that has not landed by itself (its re-tile finds no wave slot while a search
+    // is running): the search is planned on the extents the group lengths give and queued BEHIND the upload on the device --
+    // the host neither waits for the search before this one to drain nor keeps the device waiting for its plan afterwards.
+    // Otherwise the planner reads the live extents the upload brought back.
+    bool landed = true;
+    if (c.upload_pending) {
+        const hipError_t q = hipEventQuery(c.ev_up);
+        if (q == hipErrorNotReady) { landed = false; (void)hipGetLastError(); }
+        else if (q != hipSuccess) return fail(OSWALD_HIP_ERUNTIME, "hipEventQuery(upload): %s", hipGetErrorString(q));
+        else if (int r = finish_upload(d, c)) return r;
+    }
+    if (ctx->tun.plan_waits_for_upload && !landed) { if (int r = finish_upload(d, c)) return r; landed = true; }
+    HoldTimer ht(g_debug_slow);
     if (int r = sync_queries(ctx, d)) return r;
     pt.lap("search: queries + profiles");
-    if (int r = build_items(ctx, d, c)) return r;
+    ht.lap("search: queries + profiles");
+    if (int r = build_items(ctx, d, c, landed && !ctx->tun.plan_on_estimates)) return r;
     pt.lap("search: work-queue plan");
+    ht.lap("search: work-queue plan (incl. the queues' copy)");
+    if (!landed) HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_up, 0)); // everything queued below finds the chunk in place
+    if (c.ev_items) HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_items, 0)); // ... and its work queues (copy stream)
+    ht.lap("search: stream wait for the upload");
     if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return topr_after_search(ctx, d, c); }
     if (!d.bnd.p || d.bnd_stride == 0) return fail(OSWALD_HIP_ESTATE, "device %d has no spill scratch (an earlier allocation failed)", dev);
     if (c.down_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_down, 0)); c.down_pending = false; } // the table of the slot's last search is still on its way out
@@ -925,7 +1023,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.tiled = (const uint16_t *)c.tiled.p;
     a.blocks = (const OswBlock *)c.blocks.p;
     a.sub_cols = c.sub_cols_dev();
-    a.items = (const uint2 *)c.items.p;
+    a.items = (const uint2 *)c.items_dev().p;
     a.nitems = c.nitems;
     a.nitems_wg = c.nitems_wg;
     a.two_ended_waves = ctx->tun.two_ended;
@@ -989,7 +1087,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         // (queue length on the device), and below the int32 re-run of what reached the int16 ceiling
         if (c.nitems_q > 0) {
             OswSearchArgs aq = a;
-            aq.items = (const uint2 *)c.items_q.p;
+            aq.items = (const uint2 *)c.items_q_dev().p;
             aq.nitems = c.nitems_q;
             aq.nitems_wg = c.nitems_q_wg; // 0: wave items only
             aq.prof = (const uint2 *)d.prof_pair8.p;
@@ -1018,7 +1116,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     } else if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
         // query pairs first (the bulk of a multi-query search), on their own queue counters
         OswSearchArgs aq = a;
-        aq.items = (const uint2 *)c.items_q.p;
+        aq.items = (const uint2 *)c.items_q_dev().p;
         aq.nitems = c.nitems_q;
         aq.nitems_wg = c.nitems_q_wg;
         aq.prof = (const uint2 *)d.prof_pair.p;
@@ -1052,7 +1150,9 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     else HIP_TRY(osw_launch_i32r(a, d.grid * (OSW_WG_THREADS / 64), d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
+    ht.lap("search: launches");
     if (int r = topr_after_search(ctx, d, c)) return r;
+    ht.lap("search: top-r launches");
     HIP_TRY(hipEventRecord(c.ev_use, d.stream)); // an upload into this slot waits for it
     c.use_pending = true;
     if (dbg_times) {
@@ -1148,6 +1248,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         }
         HIP_TRY(hipEventRecord(c.ev_down, d.stream_down));
         c.down_pending = true;
+        ht.lap("search: table download queued");
         if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream_down)); pt.lap("search: D2H of the score table"); }
     }
     return 0;

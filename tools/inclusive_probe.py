@@ -11,14 +11,14 @@ plan = synth.DatabasePlan(nseq, queries, synth.SEED_DB, 12)
 shard = multigpu.ShardedDatabase(plan, 16, 134217728, 1, 0, "deal")
 m = np.array(qlens, dtype=np.uint16); a = np.concatenate(queries); nq = len(qlens)
 ad = np.concatenate([[0], np.cumsum(m[:-1], dtype=np.int64)]).astype(np.uint32)
-ctx = capi.Context(1, [0]); ctx.set_scoring(submat.load("blosum62"), 10, 2, 16); ctx.set_queries(a, m, ad)
+ctx = capi.Context(1, [0]); ctx.set_profiling(True); ctx.set_scoring(submat.load("blosum62"), 10, 2, 16); ctx.set_queries(a, m, ad)
 chunks = [shard.chunk(k) for k in range(len(shard.mine))]
 res = [ctx.chunk_upload(c["b"], c["n"], c["disp"], 16) for c in chunks]
 def resident(n):
     for rep in range(n):
         ctx.wait(); t = time.perf_counter()
         for h in res: ctx.chunk_search(h, None)
-        ctx.wait(); print(f"resident pass {1e3*(time.perf_counter()-t):.2f} ms")
+        ctx.wait(); ms, nl, _ = ctx.kernel_stats(reset=True); print(f"resident pass {1e3*(time.perf_counter()-t):.2f} ms, device time of the {nl} searches {ms:.2f} ms")
 resident(3)
 bufs = [[capi.pinned_copy(c[k]) for k in ("b", "n", "disp")] + [capi.HostBuffer((nq, len(c["n"]) * 16), np.int32)] for c in chunks]
 for rep in range(5):
@@ -33,5 +33,7 @@ for rep in range(5):
         if k + 2 < len(bufs):
             hs.append(call(f"upload{k+2}", lambda: ctx.chunk_upload(bufs[k+2][0].a, bufs[k+2][1].a, bufs[k+2][2].a, 16, wait=False)))
     call("wait", lambda: ctx.wait())
+    ms, nl, _ = ctx.kernel_stats(reset=True)
+    print(f"   device time of the {nl} searches (HIP events around each search's launches): {ms:.2f} ms")
     print(f"inclusive pass {rep} ({'with' if rep < 2 or rep == 4 else 'without'} score tables): {1e3*(time.perf_counter()-T0):.2f} ms")
     for name, at, dur in log: print(f"   {name:10s} at {at:8.2f} ms took {dur:8.2f} ms")
