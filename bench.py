@@ -190,6 +190,12 @@ def main():
     shard = multigpu.ShardedDatabase(plan, 16, args.max_chunk, shard_world, shard_rank, args.shard_rule)
     index_base = 0 if strong else rank * nseq_total      # weak mode: global index = shard base + sorted position
 
+    if world > 1 and backend != "nccl":
+        # rehearsal: several PROCESSES on one GPU.  The library's DMA streams sit in priority classes of their own (so that a copy
+        # never queues behind a persistent search grid in a shared hardware queue); with four processes' queues of three classes
+        # on one GPU the scheduler alternates badly between the processes (550 instead of 340 ms per step at four ranks,
+        # tools/ab_gloo4.sh): a configuration that exists for this rehearsal only, so the classes are switched off in it.
+        os.environ.setdefault("OSWALD_HIP_NO_STREAM_CLASSES", "1")
     ctx = capi.Context(1, [gpu])
     gather_note = None
     if gather == "lib":

@@ -63,6 +63,7 @@ struct Tunables {
     int pairs = 1;                     // OSWALD_HIP_PAIRS=0|1|2: never pair / pair when cheaper / pair every neighbour
     bool debug_plan = false;           // OSWALD_HIP_DEBUG=1: print the work-queue plan
     bool debug_phases = false;         // OSWALD_HIP_DEBUG_PHASES=1: wall time of the host-side phases
+    bool no_stream_classes = false;     // OSWALD_HIP_NO_STREAM_CLASSES=1 (A/B hook): the DMA streams are ordinary streams, as before the second session of round 4
     bool plan_on_estimates = false;     // OSWALD_HIP_PLAN_EST=1 (experiment): every search is planned on the group-length extents
     bool plan_waits_for_upload = false; // OSWALD_HIP_PLAN_WAITS=1 (test hook): a search waits for its chunk's upload and plans on the live extents (the behaviour before the second session of round 4)
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
@@ -90,6 +91,7 @@ void Tunables::refresh()
     debug_phases = flag("OSWALD_HIP_DEBUG_PHASES");
     plan_waits_for_upload = flag("OSWALD_HIP_PLAN_WAITS");
     plan_on_estimates = flag("OSWALD_HIP_PLAN_EST");
+    no_stream_classes = flag("OSWALD_HIP_NO_STREAM_CLASSES");
     no_pin = flag("OSWALD_HIP_NO_PIN");
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
@@ -607,6 +609,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         // (a table leaves behind its search), and a wait at the head of a hardware queue holds whatever else shares that queue
         // -- with both streams in the high-priority class a plan's queue copy sat behind the download stream's wait for the
         // running search: 110 ms (OSWALD_HIP_DEBUG_SLOW).  No kernel runs on either stream, so the priorities themselves do nothing.
+        if (ctx->tun.no_stream_classes) prio_least = prio_greatest = 0; // OSWALD_HIP_NO_STREAM_CLASSES=1 (A/B hook): ordinary streams
         if (r == hipSuccess) r = hipStreamCreateWithPriority(&d.stream_copy, hipStreamNonBlocking, prio_greatest);
         if (r == hipSuccess) r = hipStreamCreateWithPriority(&d.stream_down, hipStreamNonBlocking, prio_least);
         if (g_debug_slow) fprintf(stderr, "[oswald_hip] stream priorities: least %d, greatest %d\n", prio_least, prio_greatest);
