@@ -910,7 +910,7 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
         HIP_TRY(hipEventRecord(c.ev_copy, d.stream_copy));
         HIP_TRY(hipStreamWaitEvent(up, c.ev_copy, 0));
         HIP_TRY(hipMemcpyAsync(c.blocks.p, c.blocks_pin, c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemsetAsync(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), up)); // pads = dummy residue
+        HIP_TRY(osw_launch_fill(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), up)); // pads = dummy residue
         HIP_TRY(osw_launch_retile((const uint8_t *)c.st_b.p, (const uint16_t *)c.st_n.p, (const uint32_t *)c.st_disp.p,
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, (uint16_t *)c.sub_cols_buf.p, up));
     }

@@ -151,6 +151,7 @@ hipError_t osw_launch_build_pair_profile8(const uint2 *prof, const uint32_t *pro
 hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          bool intsum, uint4 *prof_pair, hipStream_t s);
+hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s); // a search-shaped fill (see sw_kernels.hip)
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,

@@ -1507,6 +1507,27 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile8(const 
 // Upload-side kernels.
 // ---------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------
+// Upload-side kernels are "search-shaped" (second session of round 4): 256 threads that allocate what a workgroup of the
+// packed-int16 search kernels allocates -- 168 VGPRs per wave, 53 KB of LDS (the launchers add dynamic LDS up to the search
+// kernel's own figure).  A CU holds exactly three search workgroups; their waves and their LDS are placed contiguously and
+// never move (a persistent grid).  Thousands of short workgroups with a small footprint that start TOGETHER with a search
+// land between the search's workgroups while those are being placed, and the holes they leave behind (16 VGPRs here, 256 B
+// of LDS there) are too small for a third search workgroup: such a CU runs two for the whole launch, the search 12 %
+// slower (tools/plan_probe3.py, orders C / D: 123 instead of 110 ms).  Workgroups of the search's own shape leave holes a
+// search workgroup fits exactly.  The re-tile runs a little slower for it (three workgroups per CU).
+// ---------------------------------------------------------------------------
+#define OSW_SEARCH_SHAPED_VGPRS() asm volatile("v_mov_b32 v167, 0" ::: "v167")
+
+// the pad columns of `tiled` (and everything else a chunk's re-tile does not write): dummy residues; instead of the runtime's fill
+// kernel, which is not search-shaped
+extern "C" __global__ __launch_bounds__(256) void osw_fill16(uint4 *__restrict__ p, uint32_t word, size_t n16)
+{
+    OSW_SEARCH_SHAPED_VGPRS();
+    const uint4 v = make_uint4(word, word, word, word);
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) p[k] = v;
+}
+
 // Re-tile the reference's W-lane interleaved groups (a4: b[disp_g + j*W + l],
 // reference host/src/sequences.c:479-498) into 128-sequence wave blocks:
 // tiled[(col4_off*4 + j)*64 + lane] = uint16 {8*residue j of seq 2*lane, 8*residue j of
@@ -1519,6 +1540,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__re
                                                               const uint32_t *__restrict__ disp, uint32_t ngroups, uint32_t W,
                                                               const OswBlock *__restrict__ blocks, uint16_t *__restrict__ tiled)
 {
+    OSW_SEARCH_SHAPED_VGPRS();
     const uint32_t B = blockIdx.x;
     const OswBlock blk = blocks[B];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1553,6 +1575,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile16(const uint8_t *__
                                                                 OswBlock *__restrict__ blocks, uint16_t *__restrict__ tiled, uint16_t *__restrict__ sub_cols)
 {
     __shared__ uint32_t lane_n[64];
+    OSW_SEARCH_SHAPED_VGPRS();
     const uint32_t B = blockIdx.x, t = threadIdx.x;
     const OswBlock blk = blocks[B];
     if (t < 64) lane_n[t] = 0;
@@ -1609,6 +1632,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile16(const uint8_t *__
 extern "C" __global__ __launch_bounds__(128) void osw_block_extent(OswBlock *blocks, const uint16_t *__restrict__ tiled, uint16_t *__restrict__ sub_cols)
 {
     __shared__ uint32_t lane_n[64];
+    OSW_SEARCH_SHAPED_VGPRS();
     const uint32_t B = blockIdx.x;
     const uint32_t t = threadIdx.x;
     const OswBlock blk = blocks[B];
@@ -1882,18 +1906,40 @@ hipError_t osw_launch_i32r(const OswSearchArgs &a, uint32_t regions, hipStream_t
     return hipSuccess;
 }
 
+// dynamic LDS that brings a workgroup of `kern` up to the LDS allocation of a search workgroup (see "search-shaped" above)
+static size_t osw_shape_lds(const void *kern)
+{
+    hipFuncAttributes fs, fk;
+    if (hipFuncGetAttributes(&fs, (const void *)osw_sw_s16q) != hipSuccess || hipFuncGetAttributes(&fk, kern) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const size_t want = fs.sharedSizeBytes, have = fk.sharedSizeBytes;
+    const size_t dyn = want > have ? want - have : 0;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); // (per function and device: cheap, and the device may have changed)
+    return dyn;
+}
+
+hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 15u) || ((uintptr_t)p & 15u)) return hipMemsetAsync(p, byte, bytes, s); // (never: the library's buffers and sizes are multiples of 16)
+    const size_t n16 = bytes / 16;
+    const uint32_t grid = (uint32_t)std::min<size_t>((n16 + 255) / 256, 768u * 4u);
+    hipLaunchKernelGGL(osw_fill16, dim3(grid), dim3(256), osw_shape_lds((const void *)osw_fill16), s, (uint4 *)p, (uint32_t)byte * 0x01010101u, n16);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
     if (W == 16) { // the reference's layout: one kernel re-tiles and finds the live extents
-        hipLaunchKernelGGL(osw_retile16, dim3(nblocks), dim3(256), 0, s, b, n, disp, ngroups, blocks, tiled, sub_cols);
+        hipLaunchKernelGGL(osw_retile16, dim3(nblocks), dim3(256), osw_shape_lds((const void *)osw_retile16), s, b, n, disp, ngroups, blocks, tiled, sub_cols);
         OSW_LAUNCH_CHECK();
         return hipSuccess;
     }
-    hipLaunchKernelGGL(osw_retile, dim3(nblocks), dim3(256), 0, s, b, n, disp, ngroups, W, (const OswBlock *)blocks, tiled);
+    hipLaunchKernelGGL(osw_retile, dim3(nblocks), dim3(256), osw_shape_lds((const void *)osw_retile), s, b, n, disp, ngroups, W, (const OswBlock *)blocks, tiled);
     OSW_LAUNCH_CHECK();
-    hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(128), 0, s, blocks, (const uint16_t *)tiled, sub_cols);
+    hipLaunchKernelGGL(osw_block_extent, dim3(nblocks), dim3(128), osw_shape_lds((const void *)osw_block_extent), s, blocks, (const uint16_t *)tiled, sub_cols);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }
