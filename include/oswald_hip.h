@@ -116,8 +116,9 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
 /* The same, without waiting for the device: returns once the copies and the re-tile kernel are queued on the
  * device's UPLOAD stream -- uploads have a stream of their own, so chunk k+1 comes in while chunk k is being
  * searched: queue search k, then upload k+1 (the reference uploads and searches strictly in turn,
- * FPGAsearch.c:180-223).  b / n / disp must stay valid until the chunk has been searched or released
- * (oswald_hip_chunk_search and _release finish the upload first) or oswald_hip_wait() has returned.  With several
+ * FPGAsearch.c:180-223).  b / n / disp must stay valid until the chunk has been released
+ * (oswald_hip_chunk_release waits for the upload; oswald_hip_chunk_search does NOT -- it queues the search behind the
+ * upload on the device) or oswald_hip_wait() has returned.  With several
  * devices this is also what lets their uploads overlap: queue all of them, then search each (the reference's four clEnqueueWriteBuffer per device
  * are asynchronous too and share one clFinish per device, FPGAsearch.c:180-198). */
 int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
@@ -136,7 +137,9 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
  * max_chunk_size to the device's global memory in init(), utils.c:162-168 (0.8 x memory / 23 score-profile rows). */
 int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_t max_sequence_length, uint64_t *bytes);
 
-/* All queries against a resident chunk, asynchronously on the device's stream.
+/* All queries against a chunk, asynchronously on the device's stream.  The chunk's upload need not have landed: the
+ * search is queued behind it on the device and the call returns at once (its work queues are then planned on the group
+ * lengths n[] instead of the live extents the upload brings back; the scores do not depend on the plan).
  * If scores_out != NULL the int32 scores [nq][ngroups*W] are copied there
  * (valid after oswald_hip_wait).  Replaces the per-query clSetKernelArg +
  * clEnqueueNDRangeKernel loop, clWaitForEvents, clEnqueueReadBuffer and the

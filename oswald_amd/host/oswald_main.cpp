@@ -663,7 +663,7 @@ int do_search(Options &o)
 #pragma omp parallel for num_threads((int)pieces.size()) schedule(static, 1) if (pieces.size() > 1)
             for (unsigned d = 0; d < pieces.size(); ++d) {
                 if (cur[d] < 0) continue;
-                check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search"); // (waits for ITS upload, plans, launches)
+                check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search"); // (plans and queues the search behind the piece's upload; waits for nothing)
                 check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release");        // (the upload has landed; the device re-uses the slot when it is through with it)
             }
             lap("  queue searches of a round");
