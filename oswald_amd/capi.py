@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "liboswald_hip.so")
 # tools/ only: OSWALD_HIP_USE_DIAG_LIB=1 loads the -DOSW_DIAG build (`make -C oswald_amd/csrc diag`), which also reads the
 # planner sweep knobs and the kernel timing diagnostics from the environment; tests and bench.py's records never set it
 if os.environ.get("OSWALD_HIP_USE_DIAG_LIB"):
-    LIB_PATH = os.path.join(_HERE, "liboswald_hip_diag.so")
+    LIB_PATH = os.path.join(_HERE, "liboswald_hip_diag.so" if os.environ["OSWALD_HIP_USE_DIAG_LIB"] == "1" else os.environ["OSWALD_HIP_USE_DIAG_LIB"])  # (or another build's file name, for A/B runs)
 
 # every symbol include/oswald_hip.h declares
 SYMBOLS = (
