@@ -596,19 +596,16 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipStreamCreateWithFlags(&d.stream_up, hipStreamNonBlocking);
-        // The two DMA-only streams are HIGH-PRIORITY streams.  Not for the priority: the runtime maps the streams of a priority
-        // class onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by default, shared with whatever streams the caller's
-        // process has), and a copy on a stream that shares its hardware queue with the search stream starts only when the search
-        // -- a persistent grid that holds its queue for the whole launch -- has ended.  As the fourth and fifth ordinary stream of
-        // the process the copy stream did share the search stream's queue (tools/xfer_overlap.hip, profiles/r04_xfer_overlap.txt:
-        // 128 MB beside a 60 ms kernel: done after 2.4 ms on a queue of its own, after 60 ms on the shared one); the
-        // high-priority class has a pool of its own.
+        // The two DMA-only streams sit in priority classes of their own -- copy: highest, download: lowest.  Not for the priority
+        // (no kernel runs on either): the runtime maps the streams of a class onto a small pool of hardware queues
+        // (GPU_MAX_HW_QUEUES, 4 by default, shared with whatever streams the caller's process has), and a copy on a stream that
+        // shares its hardware queue with the search stream starts only when the search -- a persistent grid that holds its queue for
+        // the whole launch -- has ended.  As the fourth ordinary stream of the process the copy stream did share the search stream's
+        // queue (tools/xfer_overlap.hip, profiles/r04_xfer_overlap.txt: 128 MB beside a 60 ms kernel: done after 2.4 ms on a queue of
+        // its own, after 60 ms on the shared one).  Two classes, not one: the download stream WAITS for searches (a table leaves
+        // behind its search), and a wait at the head of a hardware queue holds whatever else shares that queue.
         int prio_least = 0, prio_greatest = 0;
         if (r == hipSuccess) r = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        // ... and each of the two gets a class of its own (copy: highest, download: lowest): the download stream WAITS for searches
-        // (a table leaves behind its search), and a wait at the head of a hardware queue holds whatever else shares that queue
-        // -- with both streams in the high-priority class a plan's queue copy sat behind the download stream's wait for the
-        // running search: 110 ms (OSWALD_HIP_DEBUG_SLOW).  No kernel runs on either stream, so the priorities themselves do nothing.
         if (ctx->tun.no_stream_classes) prio_least = prio_greatest = 0; // OSWALD_HIP_NO_STREAM_CLASSES=1 (A/B hook): ordinary streams
         if (r == hipSuccess) r = hipStreamCreateWithPriority(&d.stream_copy, hipStreamNonBlocking, prio_greatest);
         if (r == hipSuccess) r = hipStreamCreateWithPriority(&d.stream_down, hipStreamNonBlocking, prio_least);
