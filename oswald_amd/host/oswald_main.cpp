@@ -23,6 +23,8 @@
 #include <ctime>
 #include <stdexcept>
 #include <string>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -285,7 +287,9 @@ GroupRun group_run(const oswald::Chunk &c, uint64_t g0, uint64_t g1)
 // sequences.c:828-1094): both sides search a test portion of the database (the first -p of its groups) to measure
 // their speeds, the rest is divided in that proportion -- the accelerator takes the groups that follow the test
 // portion, the host the longest sequences at the end -- and both work at the same time.
-int do_search_hybrid(Options &o)
+// This is the reference's STATIC division with the whole score table brought to the host, as the reference does it; it
+// serves -r > 1024 (top lists longer than the devices select).  do_search_hybrid below is what -m 1 normally runs.
+int do_search_hybrid_static(Options &o)
 {
     const time_t current_time = time(nullptr);
     printf("\nOSWALD v%s \n\n", oswald::kVersion);
@@ -416,6 +420,267 @@ int do_search_hybrid(Options &o)
     std::vector<std::vector<int32_t>> top_s;
     std::vector<std::vector<uint64_t>> top_i;
     tops_from_table(o, db, scores, nq, top_s, top_i);
+    print_report(o, q, db, top_s, top_i, current_time, work_time, work_time + std::max(test_gpu_time, test_cpu_time));
+    return 0;
+}
+
+// -m 1 as it normally runs (second session of round 4).  The same test portion, the same three report lines, the same
+// roles -- the accelerator works up from the shortest sequences, the host down from the longest, at the same time -- but
+// the boundary between them is not fixed by the test: both sides TAKE work until they meet.  The accelerator takes
+// pieces of up to -k bytes from the front (never more than its rated share of what is left, so that its last pieces get
+// small), the host batches of about ten milliseconds from the back (and none once the accelerator would be through with
+// everything else sooner).  A static split stands and falls with the two ratings: on an MI355X the accelerator is rated
+// on a 20 ms portion at 0.75 - 0.9 of its real speed and the host on a handful of groups, and the side that was given too
+// much keeps the other waiting -- 1 M sequences took 0.38 s with 16 host threads and 0.74 s with 64 where the
+// accelerator alone needs 0.35 s.  The accelerator side is the pipeline of the accelerator-only mode: uploads a piece
+// ahead, top lists selected on the devices (oswald_hip_topr), no score table brought back; the host's scores go to the
+// table and its top candidates are merged with the devices' by the reference's rule (utils.c:3-86).
+int do_search_hybrid(Options &o)
+{
+    if (o.top > 1024) return do_search_hybrid_static(o);
+    const time_t current_time = time(nullptr);
+    printf("\nOSWALD v%s \n\n", oswald::kVersion);
+    printf("Database file:\t\t\t%s\n", o.db);
+    oswald::Queries q = oswald::load_query_sequences(o.queries);
+    oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, 1);
+    const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength, G = db.vect_sequences_count, row = G * W;
+    print_header(o, db);
+    if (db.sequences_count < o.top) o.top = db.sequences_count;
+    const int8_t *sm = oswald::submat_by_name(o.submat);
+    // The host's team leaves a hardware thread to every thread that drives an accelerator (and one to the rest of the process):
+    // with -c = all hardware threads the accelerators' calls -- a pageable upload is staged by the CPU -- waited for a time
+    // slice, and the search ran at half speed.  The report prints the -c that was asked for.
+    int host_threads = std::max(o.cpu_threads, 1);
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int room = hw > 2 * o.num_devices + 2 ? (int)(hw - 2 * o.num_devices - 2) : 1; // (a driving thread and a runtime thread per accelerator, two for the rest)
+        if (hw && host_threads > room) {
+            fprintf(stderr, "oswald: hybrid mode runs the host part on %d threads (-c %d asked for, %u hardware threads, %u of them drive the accelerators)\n", room, host_threads, hw, o.num_devices);
+            host_threads = room;
+        }
+    }
+    const uint64_t host_min_groups = std::max<uint64_t>(1, (2 * (uint64_t)host_threads + nq - 1) / std::max<uint64_t>(nq, 1)); // >= two (group, query) cells per host thread
+    std::vector<int32_t> scores(nq * row, 0); // the host's columns only
+    oswald_hip_ctx *ctx = nullptr;
+    check(bring_up(o, &ctx), "device bring-up");
+    check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space");
+    check(oswald_hip_set_scoring(ctx, sm, o.open_gap, o.extend_gap, 0), "scoring setup");
+    check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
+    check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");
+    // padded residues before every group of the database, and the chunk a group lies in
+    std::vector<uint64_t> pre(G + 1, 0);
+    for (const oswald::Chunk &c : db.chunks)
+        for (uint64_t g = 0; g < c.n.size(); ++g) pre[c.accum + g + 1] = (uint64_t)c.n[g] * W;
+    for (uint64_t g = 0; g < G; ++g) pre[g + 1] += pre[g];
+    auto chunk_of = [&](uint64_t g) -> const oswald::Chunk & {
+        for (const oswald::Chunk &c : db.chunks) if (g >= c.accum && g < c.accum + c.n.size()) return c;
+        return db.chunks.back();
+    };
+    auto cells = [&](uint64_t g0, uint64_t g1) { return (double)(pre[g1] - pre[g0]) * (double)q.Q; };
+    // the accelerator side of a range of groups inside ONE chunk: upload (asynchronous), index, search; the run is kept until the device is through
+    struct Live { GroupRun run; int handle; };
+    auto gpu_upload = [&](int dev, uint64_t g0, uint64_t g1, std::vector<std::unique_ptr<Live>> &keep) {
+        const oswald::Chunk &c = chunk_of(g0);
+        std::unique_ptr<Live> l(new Live{group_run(c, g0 - c.accum, g1 - c.accum), -1});
+        check(oswald_hip_chunk_upload_async(ctx, dev, l->run.b, l->run.bytes, l->run.n, l->run.disp.data(), (uint32_t)l->run.disp.size(), (uint32_t)W, &l->handle), "chunk upload");
+        const uint64_t first = g0 * W, last = std::min<uint64_t>(db.sequences_count, g1 * W);
+        check(oswald_hip_chunk_set_index(ctx, dev, l->handle, (uint32_t)first, (uint32_t)(last > first ? last - first : 0), nullptr), "chunk index");
+        keep.push_back(std::move(l));
+        return keep.back()->handle;
+    };
+    auto gpu_search = [&](int dev, int handle) {
+        check(oswald_hip_chunk_search(ctx, dev, handle, nullptr), "chunk search");
+        check(oswald_hip_chunk_release(ctx, dev, handle), "chunk release");
+    };
+    auto cpu_groups = [&](uint64_t g0, uint64_t g1, int32_t *dst, uint64_t dst_row, uint64_t dst_g0, const std::atomic<bool> *cancel = nullptr,
+                          std::atomic<uint64_t> *done = nullptr) {
+        for (const oswald::Chunk &c : db.chunks) {
+            const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
+            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, host_threads, dst, dst_row, (a0 - dst_g0) * W, o.cpu_vector_length,
+                                                    cancel, done);
+        }
+    };
+    // Test portion: the host on the first -p of the groups, called off when the accelerator's rating is over (as in
+    // do_search_hybrid_static); the accelerator on one portion from the start of the database -- what it computes there is
+    // final: its top candidates are in the devices' running lists
+    uint64_t test_groups = 0;
+    {
+        const double want = o.test_db_percentage * (double)db.vD;
+        while (test_groups < G && (double)pre[test_groups] < want) ++test_groups;
+        test_groups = std::min<uint64_t>(G, std::max<uint64_t>(1, test_groups));
+    }
+    double test_gpu_time = 0, test_cpu_time = 0, gpu_gcups = 0;
+    uint64_t gpu_done = 0, spec_g1 = 0;
+    int spec_handle = -1;
+    {   // (the host's thread team exists before the clock starts: creating 128 threads takes a tenth of a second)
+        int team = 0;
+#pragma omp parallel num_threads(host_threads) reduction(+ : team)
+        team += 1;
+        (void)team;
+    }
+    const double tick_test = dwalltime();
+    std::atomic<bool> call_off{false}, host_done{false};
+    std::atomic<uint64_t> host_test_cells{0};
+    std::vector<std::unique_ptr<Live>> keep0;
+    {
+        // The host's test runs on THIS thread (its thread team exists: see above; a team is per master thread), the
+        // accelerator's on a thread of its own, which calls the host's test off when its rating is over and the host has
+        // finished at least one (group, query).
+        std::vector<int32_t> test_scores(nq * test_groups * W, 0);
+        std::thread gpu_test([&] {
+            // ONE portion: the test portion or the shortest groups that hold 8 MiB of padded residues (a twentieth of a small database), whichever is larger (the
+            // rating only sizes the accelerator's last pieces and the host's batches here -- the boundary between the two sides
+            // is found by the work itself --, so it need not be exact; a launch has a fixed cost of about a millisecond, and
+            // 8 MiB against 20 queries is ~8 ms of work)
+            uint64_t g1 = test_groups;
+            const uint64_t cal_bytes = std::min<uint64_t>(8ull << 20, pre[G] / 20); // (a twentieth of a small database at most)
+            while (g1 < G && pre[g1] < cal_bytes) ++g1;
+            const double t = dwalltime();
+            for (uint64_t g = gpu_done; g < g1;) { // (a portion may span chunks)
+                const oswald::Chunk &c = chunk_of(g);
+                const uint64_t e = std::min<uint64_t>(g1, c.accum + c.n.size());
+                gpu_search(0, gpu_upload(0, g, e, keep0));
+                g = e;
+            }
+            // the accelerator's first piece of the rest comes in beside the test search: what follows the test portion in its
+            // chunk, nine tenths of what is left at most (whatever the ratings turn out to be, that much is the accelerator's) -- all
+            // of it when that is less than 64 MiB
+            if (g1 < G) {
+                const oswald::Chunk &c = chunk_of(g1);
+                uint64_t e = g1 + 1;
+                const double rest = (double)(pre[G] - pre[g1]);
+                const double cap = rest <= 64.0 * 1048576.0 ? rest : std::min((double)o.max_chunk_size, 0.9 * rest); // (a small rest is one piece: a second launch would cost more than the host can give)
+                while (e < c.accum + c.n.size() && (double)(pre[e + 1] - pre[g1]) <= cap) ++e;
+                spec_g1 = e;
+                spec_handle = gpu_upload(0, g1, e, keep0);
+            }
+            check(oswald_hip_wait(ctx, -1), "wait");
+            const double dt = dwalltime() - t;
+            gpu_gcups = cells(gpu_done, g1) / (std::max(dt, 1e-9) * 1e9);
+            test_gpu_time += dt;
+            gpu_done = g1;
+            while (host_test_cells.load() == 0 && !host_done.load()) { // (at least one finished (group, query) to rate the host on)
+                struct timespec ts = {0, 200000};
+                nanosleep(&ts, nullptr);
+                if (dwalltime() - (tick_test + test_gpu_time) > 60.0) break; // (a host that cannot finish one group in a minute is rated 0)
+            }
+            call_off.store(true);
+        });
+        const double t = dwalltime();
+        // (in batches, so that the team sleeps for a moment every millisecond or so: one long parallel region
+        // on every hardware thread keeps the runtime's own threads -- which complete the accelerator's calls -- off the cores)
+        const uint64_t test_batch = 16 * host_min_groups; // (~30 (group, query) cells per thread: the team's wake-up is small against it)
+        for (uint64_t g = 0; g < test_groups && !call_off.load(); g += test_batch)
+            cpu_groups(g, std::min<uint64_t>(test_groups, g + test_batch), test_scores.data(), test_groups * W, 0, &call_off, &host_test_cells);
+        test_cpu_time = dwalltime() - t;
+        host_done.store(true);
+        gpu_test.join();
+    }
+    const double cpu_gcups = (double)host_test_cells.load() / (std::max(test_cpu_time, 1e-9) * 1e9);
+    printf("Test DB percentage:\t\t%.4lf%% \n", o.test_db_percentage);
+    printf("CPU estimated speed:\t\t%.2lf GCUPS\n", cpu_gcups);
+    printf("FPGA estimated speed:\t\t%.2lf GCUPS\n", gpu_gcups);
+
+    // The rest: groups [front, back) are nobody's yet.
+    std::mutex mx;
+    double cpu_live = cpu_gcups; // the host's speed on what it is working on now (the test rated it on the SHORTEST sequences)
+    uint64_t front = spec_handle >= 0 ? spec_g1 : gpu_done, back = G;
+    auto take_gpu = [&](uint64_t &g0, uint64_t &g1) {
+        std::lock_guard<std::mutex> lk(mx);
+        if (front >= back) return false;
+        const double left = (double)(pre[back] - pre[front]);
+        // (what is left of a last few MiB is one piece: the accelerator is through with it in milliseconds, and every launch costs one)
+        const double pow_now = gpu_gcups / std::max(gpu_gcups + cpu_live, 1e-9); // (the host's rating follows what it is doing now)
+        double want = std::min((double)o.max_chunk_size, std::max(1.0, pow_now * left / std::max(1u, o.num_devices)));
+        // no sliver behind the last piece (it would cost a launch of its own): what the accelerator does in ~10 ms goes with it
+        const double sliver = std::max(4.0 * 1048576.0, gpu_gcups * 1e9 * 0.010 / std::max((double)q.Q, 1.0));
+        if (left - want <= sliver && left <= (double)o.max_chunk_size) want = left;
+        const oswald::Chunk &c = chunk_of(front);
+        const uint64_t end = std::min<uint64_t>(back, c.accum + c.n.size());
+        g0 = front;
+        g1 = front + 1;
+        while (g1 < end && (double)(pre[g1 + 1] - pre[g0]) <= want) ++g1;
+        front = g1;
+        return true;
+    };
+    auto take_cpu = [&](uint64_t &g0, uint64_t &g1) {
+        std::lock_guard<std::mutex> lk(mx);
+        if (front >= back || cpu_live <= 0) return false;
+        const double target = cpu_live * 1e9 * 0.010; // cells of ~10 ms of host work
+        g1 = back;
+        g0 = back;
+        while (g0 > front && (g1 - g0 < host_min_groups || cells(g0, g1) < target)) --g0;
+        // ... unless the accelerator would be through with everything else before the host is through with this batch
+        if (gpu_gcups > 0 && cells(front, g0) / gpu_gcups < cells(g0, g1) / cpu_live) return false;
+        back = g0;
+        return true;
+    };
+    const double tick = dwalltime();
+    const bool phases = getenv("OSWALD_DEBUG_PHASES") != nullptr;
+    uint64_t host_first = G; // the host's groups: [host_first, G)
+    std::vector<std::vector<std::unique_ptr<Live>>> keep(o.num_devices);
+    {
+        std::vector<std::thread> devs;
+        for (unsigned d = 0; d < o.num_devices; ++d)
+            devs.emplace_back([&, d] {
+                uint64_t g0, g1;
+                int cur = d == 0 ? spec_handle : -1; // (device 0 holds the piece that came in beside the test search)
+                if (cur < 0) {
+                    if (!take_gpu(g0, g1)) return;
+                    cur = gpu_upload((int)d, g0, g1, keep[d]);
+                }
+                for (;;) { // search the piece in hand, then bring the next one in beside it
+                    const double t0 = dwalltime();
+                    gpu_search((int)d, cur);
+                    const double t1 = dwalltime();
+                    if (!take_gpu(g0, g1)) break;
+                    cur = gpu_upload((int)d, g0, g1, keep[d]);
+                    if (phases) fprintf(stderr, "[oswald] device %u at %.1f ms: search + release calls %.1f ms, next piece %.1f MiB queued in %.1f ms\n", d, (t0 - tick) * 1e3, (t1 - t0) * 1e3,
+                                        (double)(pre[g1] - pre[g0]) / 1048576.0, (dwalltime() - t1) * 1e3);
+                }
+                if (phases) fprintf(stderr, "[oswald] device %u has queued its last piece at %.1f ms\n", d, (dwalltime() - tick) * 1e3);
+            });
+        uint64_t g0, g1;
+        while (take_cpu(g0, g1)) {
+            const double t = dwalltime();
+            cpu_groups(g0, g1, scores.data(), row, 0);
+            host_first = g0;
+            const double rate = cells(g0, g1) / (std::max(dwalltime() - t, 1e-9) * 1e9);
+            std::lock_guard<std::mutex> lk(mx);
+            cpu_live = 0.5 * (cpu_live + rate);
+        }
+        if (phases) fprintf(stderr, "[oswald] host done at %.1f ms: groups %llu .. %llu of %llu, %.2f %% of the padded residues, live rate %.1f GCUPS\n", (dwalltime() - tick) * 1e3,
+                            (unsigned long long)host_first, (unsigned long long)G, (unsigned long long)G, 100.0 * (double)(pre[G] - pre[host_first]) / (double)pre[G], cpu_live);
+        for (std::thread &t : devs) t.join();
+    }
+    // the devices' lists, the host's candidates, merged by the reference's rule
+    std::vector<int32_t> cand_s(nq * 2 * o.top, -1);
+    std::vector<uint32_t> cand_i(nq * 2 * o.top, 0);
+    {
+        std::vector<int32_t> ms(nq * o.top);
+        std::vector<uint32_t> mi(nq * o.top);
+        check(oswald_hip_topr(ctx, (uint32_t)o.top, ms.data(), mi.data()), "top scores");
+        for (uint64_t i = 0; i < nq; ++i)
+            for (uint64_t j = 0; j < o.top; ++j) { cand_s[i * 2 * o.top + j] = ms[i * o.top + j]; cand_i[i * 2 * o.top + j] = mi[i * o.top + j]; }
+        const uint64_t h0 = host_first * W, h1 = db.sequences_count;
+        if (h0 < h1)
+            for (uint64_t i = 0; i < nq; ++i) {
+                std::vector<int32_t> hs;
+                std::vector<uint64_t> hi;
+                oswald::top_scores(scores.data() + i * row + h0, h1 - h0, o.top, hs, hi);
+                for (uint64_t j = 0; j < hs.size(); ++j) { cand_s[i * 2 * o.top + o.top + j] = hs[j]; cand_i[i * 2 * o.top + o.top + j] = (uint32_t)(hi[j] + h0); }
+            }
+    }
+    std::vector<int32_t> fs(nq * o.top);
+    std::vector<uint32_t> fi(nq * o.top);
+    check(oswald_hip_merge_candidates((uint32_t)nq, 2 * o.top, cand_s.data(), cand_i.data(), (uint32_t)o.top, fs.data(), fi.data()), "merge");
+    const double work_time = dwalltime() - tick;
+    if (phases) fprintf(stderr, "[oswald] hybrid: test %.1f ms (accelerator %.1f, host %.1f), rest %.1f ms\n", std::max(test_gpu_time, test_cpu_time) * 1e3, test_gpu_time * 1e3, test_cpu_time * 1e3, work_time * 1e3);
+    oswald_hip_finalize(ctx);
+    std::vector<std::vector<int32_t>> top_s(nq);
+    std::vector<std::vector<uint64_t>> top_i(nq);
+    for (uint64_t i = 0; i < nq; ++i)
+        for (uint64_t j = 0; j < o.top && fs[i * o.top + j] >= 0; ++j) { top_s[i].push_back(fs[i * o.top + j]); top_i[i].push_back(fi[i * o.top + j]); }
     print_report(o, q, db, top_s, top_i, current_time, work_time, work_time + std::max(test_gpu_time, test_cpu_time));
     return 0;
 }
@@ -715,6 +980,10 @@ int do_search(Options &o)
 
 int main(int argc, char *argv[])
 {
+    // the host's worker threads sleep between their parallel regions instead of spinning: with as many of them as the box has
+    // hardware threads (-c 128) the spinning kept the threads that drive the accelerators off the cores (hybrid mode: the
+    // accelerator's 10 ms test took 100)
+    setenv("OMP_WAIT_POLICY", "PASSIVE", 0);
     static struct argp_option options[] = {
         {0, 0, 0, 0, "OSWALD execution", 1},
         {0, 'O', "<string>", 0, "'preprocess' for database preprocessing, 'search' for database search, 'info' for GPU information [REQUIRED]", 1},
@@ -733,7 +1002,7 @@ int main(int argc, char *argv[])
         {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (accepted for compatibility) (default: 256).", 3},
         {"num_fpgas", 'f', "<integer>", 0, "Number of GPUs (the reference's number of FPGAs) (default: 1).", 3},
         {"max_chunk_size", 'k', "<integer>", 0, "Maximum chunk size on the accelerator (bytes, default: 134217728).", 3},
-        {"db_percentage", 'p', "<integer>", 0, "Database percentage for testing computational power (hybrid mode only) (default: 0.01).  An upper bound in this build: the host's test is called off once the GPU's is over, and the host is rated on what it finished.", 3},
+        {"db_percentage", 'p', "<integer>", 0, "Database percentage for testing computational power (hybrid mode only) (default: 0.01).  An upper bound in this build: the host's test is called off once the GPU's is over, and the host is rated on what it finished; the ratings then only size the pieces -- host and GPU take work from the two ends of the database until they meet.", 3},
         {"top", 'r', "<integer>", 0, "Number of scores to show (default: 10).", 3},
         {0}};
     Options o;
