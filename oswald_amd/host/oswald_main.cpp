@@ -438,6 +438,9 @@ int do_search_hybrid_static(Options &o)
 int do_search_hybrid(Options &o)
 {
     if (o.top > 1024) return do_search_hybrid_static(o);
+    // OSWALD_HYBRID_TEST_SPLIT=1 (test hook): a database of any size is shared out -- the accelerator's first piece is half of the
+    // rest, no piece swallows a sliver, and the host takes batches whatever the ratings say (tests/test_gpu_cli.py)
+    const bool force_split = getenv("OSWALD_HYBRID_TEST_SPLIT") != nullptr;
     const time_t current_time = time(nullptr);
     printf("\nOSWALD v%s \n\n", oswald::kVersion);
     printf("Database file:\t\t\t%s\n", o.db);
@@ -549,7 +552,7 @@ int do_search_hybrid(Options &o)
                 const oswald::Chunk &c = chunk_of(g1);
                 uint64_t e = g1 + 1;
                 const double rest = (double)(pre[G] - pre[g1]);
-                const double cap = rest <= 64.0 * 1048576.0 ? rest : std::min((double)o.max_chunk_size, 0.9 * rest); // (a small rest is one piece: a second launch would cost more than the host can give)
+                const double cap = force_split ? 0.5 * rest : rest <= 64.0 * 1048576.0 ? rest : std::min((double)o.max_chunk_size, 0.9 * rest); // (a small rest is one piece: a second launch would cost more than the host can give)
                 while (e < c.accum + c.n.size() && (double)(pre[e + 1] - pre[g1]) <= cap) ++e;
                 spec_g1 = e;
                 spec_handle = gpu_upload(0, g1, e, keep0);
@@ -594,7 +597,8 @@ int do_search_hybrid(Options &o)
         double want = std::min((double)o.max_chunk_size, std::max(1.0, pow_now * left / std::max(1u, o.num_devices)));
         // no sliver behind the last piece (it would cost a launch of its own): what the accelerator does in ~10 ms goes with it
         const double sliver = std::max(4.0 * 1048576.0, gpu_gcups * 1e9 * 0.010 / std::max((double)q.Q, 1.0));
-        if (left - want <= sliver && left <= (double)o.max_chunk_size) want = left;
+        if (force_split) want = std::max(1.0, 0.5 * want);
+        else if (left - want <= sliver && left <= (double)o.max_chunk_size) want = left;
         const oswald::Chunk &c = chunk_of(front);
         const uint64_t end = std::min<uint64_t>(back, c.accum + c.n.size());
         g0 = front;
@@ -606,12 +610,12 @@ int do_search_hybrid(Options &o)
     auto take_cpu = [&](uint64_t &g0, uint64_t &g1) {
         std::lock_guard<std::mutex> lk(mx);
         if (front >= back || cpu_live <= 0) return false;
-        const double target = cpu_live * 1e9 * 0.010; // cells of ~10 ms of host work
+        const double target = force_split ? 0.0 : cpu_live * 1e9 * 0.010; // cells of ~10 ms of host work
         g1 = back;
         g0 = back;
         while (g0 > front && (g1 - g0 < host_min_groups || cells(g0, g1) < target)) --g0;
         // ... unless the accelerator would be through with everything else before the host is through with this batch
-        if (gpu_gcups > 0 && cells(front, g0) / gpu_gcups < cells(g0, g1) / cpu_live) return false;
+        if (!force_split && gpu_gcups > 0 && cells(front, g0) / gpu_gcups < cells(g0, g1) / cpu_live) return false;
         back = g0;
         return true;
     };

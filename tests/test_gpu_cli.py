@@ -119,6 +119,20 @@ def test_cli_hybrid_mode_equals_accelerator_mode(tmp_path, ndev):
     assert re.search(r"Test DB percentage:\t\t0\.0500% \nCPU estimated speed:\t\t\d+\.\d\d GCUPS\nFPGA estimated speed:\t\t\d+\.\d\d GCUPS\n", hyb.stdout)
     host = subprocess.run([hostlib.CLI, "-O", "search", "-m", "2", "-c", "8"] + common, capture_output=True, text=True)
     assert host.returncode == 0 and parse_report(host.stdout) == parse_report(gpu.stdout)
+    # A database this small is one piece for the accelerator after the test.  With the test hook both sides take work from their
+    # ends until they meet (the accelerator in several pieces, the host in batches), the host's candidates are merged with the
+    # devices' top lists -- and the report is the same, ties included.
+    split = subprocess.run([hostlib.CLI, "-O", "search", "-m", "1", "-p", "0.05", "-c", "8", "-f", str(ndev)] + common, capture_output=True, text=True,
+                           env=dict(os.environ, OSWALD_DEVICE_IDS=",".join(["0"] * ndev), OSWALD_HYBRID_TEST_SPLIT="1", OSWALD_DEBUG_PHASES="1"))
+    assert split.returncode == 0, split.stderr
+    assert parse_report(split.stdout) == parse_report(gpu.stdout)
+    m = re.search(r"host done at .*: groups (\d+) \.\. (\d+) of", split.stderr)
+    assert m and int(m.group(1)) < int(m.group(2)), split.stderr[-600:]          # the host did take part of the database
+    # -r beyond what the devices select: the reference's static division with the score table on the host
+    long_gpu = subprocess.run([hostlib.CLI, "-O", "search", "-m", "0", "-r", "1500"] + common[:-4] + ["-k", "300000"], capture_output=True, text=True)
+    long_hyb = subprocess.run([hostlib.CLI, "-O", "search", "-m", "1", "-p", "0.05", "-c", "8", "-r", "1500"] + common[:-4] + ["-k", "300000"], capture_output=True, text=True)
+    assert long_gpu.returncode == 0 and long_hyb.returncode == 0, long_hyb.stderr
+    assert parse_report(long_hyb.stdout) == parse_report(long_gpu.stdout)
 
 
 def _db_and_queries(tmp_path, nseq, qlens, seed):
