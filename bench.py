@@ -58,13 +58,15 @@ N_CU = 256
 SIMD_PER_CU = 4
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
-PK_OPS_PER_ROW = {16: (7.5, 6.5), 32: (24.0, 24.0), 8: (20.0, 20.0)}  # 8: 39 SWAR instructions + 1 v_perm_b32 per row of a 2 x 2 tile = 256 cells (q8_cell.h, CellQ8F)
+PK_OPS_PER_ROW = {16: (6.5, 6.5), 32: (24.0, 24.0), 8: (20.0, 20.0)}  # 8: 39 SWAR instructions + 1 v_perm_b32 per row of a 2 x 2 tile = 256 cells (q8_cell.h, CellQ8F)
 # ... and what such a row costs in core-clock cycles per SIMD at 4 waves per SIMD.  int16: MEASURED on the cell's own
 # instruction mix (tools/oprate2.hip, profiles/r02_oprate2_valu_mix.txt: 3.5 VOP3P + 3 VOP2 = 25.3 cycles for the query-pair
-# row; the sequence-pair row keeps the packed add and has a v_perm_b32: 26.3 + 4.25); int8: MEASURED on the cell's own column
+# row; the sequence-pair row -- since the third session of round 4 one v_pk_mad_i16 pairs the two sequences' scores and adds them, where a
+# v_perm_b32 and a packed add did (7.5 instructions, 30.5 cycles) -- is the same row with a VOP3P instead of the 32-bit add: 27.3 cycles
+# without its loads, tools/oprate8.hip "none", profiles/r04_oprate8_pk_mad.txt); int8: MEASURED on the cell's own column
 # step at the six waves per SIMD osw_sw_q8 runs at (tools/oprate_q8.hip, profiles/r04_oprate_q8.txt: the hand-scheduled cell of
 # round 4 takes 90.9 cycles per row of a 2 x 2 tile = 256 cells; round 3's compiler-scheduled one took 129.5); int32: instructions x 4.25, an estimate.
-ROW_CYCLES = {16: (30.5, 25.3), 32: (102.0, 102.0), 8: (45.45, 45.45)}
+ROW_CYCLES = {16: (27.3, 25.3), 32: (102.0, 102.0), 8: (45.45, 45.45)}
 DTYPE = {16: "int16", 32: "int32", 8: "int8"}
 CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells",
               8: "int8 cells (four 7-bit SWAR cells per register) with int16 re-run of what leaves their range, int32 above"}

@@ -69,7 +69,7 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
-    double pair_margin = 0.95, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5;
+    double pair_margin = 0.95, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5, entries_per_wg = 4.0;
     uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_cols_single = 0, wg_wide_cols_single = 0, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1, grid_per_cu = 0;
     bool no_prio = false, one_stream = false;
     bool debug_times = false, debug_nospill = false; // -DOSW_DIAG only
@@ -100,6 +100,7 @@ void Tunables::refresh()
     col_cost = num("OSWALD_HIP_COL_COST", col_cost);
     target_div = num("OSWALD_HIP_TARGET_DIV", target_div);
     quad_frac = num("OSWALD_HIP_QUAD_FRAC", quad_frac);
+    entries_per_wg = num("OSWALD_HIP_ENTRIES_PER_WG", entries_per_wg);
     wg_min_cols = (uint32_t)num("OSWALD_HIP_WG_MINCOLS", wg_min_cols);
     wg_wide_cols = (uint32_t)num("OSWALD_HIP_WG_WIDECOLS", wg_wide_cols);
     wg_min_cols_single = (uint32_t)num("OSWALD_HIP_WG_MINCOLS_SINGLE", wg_min_cols_single);
@@ -251,7 +252,7 @@ struct Device {
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     uint32_t grid_q8 = 0;            // ... of the 8-bit kernel (more workgroups per CU; at most 2 x grid: it runs alone and may use both halves of the spill scratch)
-    DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters;
+    DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_seq, prof_seq_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters;
     DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
     std::vector<uint32_t> top_pages_host; // source of the asynchronous upload of top_pages
     std::vector<std::shared_ptr<const std::vector<uint32_t>>> retired_maps; // index maps of re-used slots whose upload may still be queued
@@ -357,22 +358,24 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     HIP_TRY(d.prof_off.reserve((nq + 1) * sizeof(uint32_t)));
     HIP_TRY(d.submat.reserve(24 * 32));
     HIP_TRY(d.prof.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
+    HIP_TRY(d.prof_seq.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096));
     if (!ctx->a.empty()) HIP_TRY(hipMemcpyAsync(d.queries.p, ctx->a.data(), ctx->a.size(), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.qlen.p, ctx->m.data(), nq * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.a_disp.p, ctx->a_disp.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.prof_off.p, ctx->prof_off.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.submat.p, ctx->submat, 24 * 32, hipMemcpyHostToDevice, d.stream));
-    // plain integer profile: the plain int16 cell and the exact int32 kernel
+    // plain integer profile: the exact int32 kernel and the pair profiles read `prof`, the plain single-query int16 cell `prof_seq`
     HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                      (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                     0, (uint2 *)d.prof.p, d.stream));
+                                     0, (uint2 *)d.prof.p, (uint4 *)d.prof_seq.p, d.stream));
     // the column-frame int16 cell reads S + ge
     const bool alt = first_pass_is_frame(ctx);
     if (alt) {
         HIP_TRY(d.prof_alt.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
+        HIP_TRY(d.prof_seq_alt.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096));
         HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                          (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                         ctx->extend_gap, (uint2 *)d.prof_alt.p, d.stream));
+                                         ctx->extend_gap, (uint2 *)d.prof_alt.p, (uint4 *)d.prof_seq_alt.p, d.stream));
     }
     // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
     // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern), then the 8-bit cell's page.  Uploaded on the
@@ -708,7 +711,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); for (int k = 0; k < 2; ++k) { c.items_buf[k].release(); c.items_q_buf[k].release(); } c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); if (c.ev_map) (void)hipEventDestroy(c.ev_map); c.ev_map = nullptr; }
-        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
+        for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_seq, &d.prof_seq_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
                           &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
             b->release();
@@ -750,6 +753,13 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     if (!ctx || !submat) return fail(OSWALD_HIP_EINVAL, "null argument");
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
     if (open_gap + extend_gap > 32767) return fail(OSWALD_HIP_EINVAL, "open+extend must fit int16");
+    // The reference's matrices are 24 rows x 32 columns with zeros in column 23 (the dummy residue) and in the padding columns 24..31
+    // (host/src/submat.c), and its preprocessing emits the codes 0..23 only.  The single-query kernels keep 24 entries per profile
+    // row-block and the re-tile kernels store a residue code >= 24 as 23: exact for every matrix whose padding columns equal column 23.
+    for (int i = 0; i < 24; ++i)
+        for (int j = 24; j < 32; ++j)
+            if (submat[i * 32 + j] != submat[i * 32 + 23])
+                return fail(OSWALD_HIP_EINVAL, "substitution matrix: column %d differs from column 23 in row %d (the padding columns 24..31 must repeat the dummy residue's column, as in the reference's matrices)", j, i);
     ctx->tun.refresh();
     if (cell_bits == 0) cell_bits = ctx->tun.cell_bits_default;
     if (cell_bits != 8 && cell_bits != 16 && cell_bits != 32) return fail(OSWALD_HIP_EINVAL, "cell_bits must be 0 (default), 8, 16 or 32");
@@ -1079,8 +1089,9 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     const bool frame = first_pass_is_frame(ctx);
     const auto launch_single = frame ? osw_launch_s16 : osw_launch_pk16;
     const auto launch_pair = frame ? osw_launch_s16q : osw_launch_pk16q;
-    OswSearchArgs as = a; // single queries (`a` itself stays on the plain integer profile for the int32 kernel)
-    if (frame) { as.prof = (const uint2 *)d.prof_alt.p; as.prof_fb = (const uint2 *)d.prof.p; }
+    OswSearchArgs as = a; // single queries on the int16 cells: {S, 1} entries (`a` itself stays on the plain integer profile for the int32 kernel)
+    as.prof = (const uint2 *)d.prof_seq.p;
+    if (frame) { as.prof = (const uint2 *)d.prof_seq_alt.p; as.prof_fb = (const uint2 *)d.prof_seq.p; }
     if (first_pass_is_q8(ctx)) {
         // 8-bit first pass over the query pairs, then -- all on this stream, each kernel reading what the one before
         // queued -- a leftover unpaired query on the plain int16 kernel, the int16 re-run of what left the 7-bit range
@@ -1104,7 +1115,8 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         }
         if (c.nitems + c.nitems_wg > 0) HIP_TRY(osw_launch_pk16(as, grid, d.stream));
         if (c.nitems_q > 0) {
-            OswSearchArgs ar = a; // plain single-query profile, (open+extend, extend)
+            OswSearchArgs ar = a; // plain single-query profile ({S, 1} entries), (open+extend, extend)
+            ar.prof = (const uint2 *)d.prof_seq.p;
             ar.items = (const uint2 *)c.ovf8.p;
             ar.nitems = 0;
             ar.nitems_wg = 0;

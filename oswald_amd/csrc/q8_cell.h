@@ -52,6 +52,7 @@ struct CellQ8 {
     static constexpr bool kShifted = false;
     static constexpr int kRows = OSW_RMAX8;
     static constexpr int kLdsRows = OSW_LDS_ROWS8;
+    static constexpr int kCodes = 32;
     static constexpr int kRowBytes = 64; // 32 codes x 2 queries x 1 byte
     typedef uint2 Entry; // one residue code: 4 rows x (S_A, S_B) bytes, each S + bias
 

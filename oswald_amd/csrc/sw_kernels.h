@@ -10,6 +10,8 @@
 #define OSW_RMAX16 48        // query rows per strip, packed int16 kernels (2 state registers per row; 168 VGPRs = three waves per SIMD)
 #define OSW_RMAX32 16        // query rows per strip, int32 kernel
 #define OSW_LDS_ROWS16 192   // profile rows a wave keeps in LDS per round (12 KB; three workgroups of four waves per CU), packed int16 kernels
+#define OSW_SEQ_CODES 24     // residue codes per row-block of the single-query int16 kernels' profile (16 B each: 96 B per query row)
+#define OSW_LDS_ROWS16_SEQ 128 // ... of which a wave's 12 KB hold 128 rows (the query-pair profile: 32 codes x 16 B, OSW_LDS_ROWS16 / 2 rows)
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
 #define OSW_RMAX8 12         // query rows per strip, SWAR 8-bit kernel (compiler-scheduled; 12 rows keep it within the 80 VGPRs of six waves per SIMD)
 #define OSW_LDS_ROWS8 96     // profile rows a wave keeps in LDS per round, SWAR 8-bit kernel (6 KB: six workgroups per CU)
@@ -113,7 +115,8 @@ struct OswSearchArgs {
     uint32_t two_ended_waves;  // wave items: eat the queue from both ends (see osw_sw_pk16) or heaviest-first only
     uint32_t one_ended_wg;     // phase-1 entries: every workgroup takes the heaviest entry left (else: the first workgroup of a CU the heaviest, the others the lightest)
     uint32_t force_all;        // int32 kernel: run `items` instead of the overflow queue
-    const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16 (column-frame kernels: S + ge)
+    const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16 (column-frame kernels: S + ge); the single-query int16 kernels
+                               // (osw_sw_pk16 / osw_sw_s16): uint4 entries, a 32-bit word {S, 1} per row; query-pair kernels: uint4, 4 x (S_A, S_B)
     const uint2 *prof_fb;      // column-frame kernels: the plain profile of the same queries / pairs (blocks run on the plain cell)
     const uint32_t *prof_off;
     const uint16_t *qlen;
@@ -155,7 +158,9 @@ hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s); 
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
-                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, int add, uint2 *prof, hipStream_t s);
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, int add, uint2 *prof, uint4 *prof_seq, hipStream_t s);
+// (prof_seq, or null: the same entries as the sequence-pair cell reads them: [(prof_off[q] + i/4) * OSW_SEQ_CODES + code], 16 B per code
+// and 4 rows, a 32-bit word {S, 1} per row; codes 0..23 only -- the re-tile kernels store every residue code >= 24 as 23, the dummy)
 uint32_t osw_topr_parts(uint32_t nvalid); // partitions per score row; `cand` holds nq * parts * r tagged keys
 hipError_t osw_launch_topr(const int32_t *scores, uint32_t score_stride, uint32_t nvalid, uint32_t r, uint32_t nq,
                            unsigned long long *cand, int32_t *out_scores, uint32_t *out_index, hipStream_t s);

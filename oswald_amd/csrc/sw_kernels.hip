@@ -102,25 +102,34 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 #define OSW_PA1 "v151"
 #define OSW_PA2 "v152"
 #define OSW_PA3 "v153"
-#define OSW_PA_LO "v[150:151]"
-#define OSW_PA_HI "v[152:153]"
 #define OSW_PA_ALL "v[150:153]"
 #define OSW_PB0 "v154"  // profile buffer B: the next block's (the two alternate)
 #define OSW_PB1 "v155"
 #define OSW_PB2 "v156"
 #define OSW_PB3 "v157"
-#define OSW_PB_LO "v[154:155]"
-#define OSW_PB_HI "v[156:157]"
 #define OSW_PB_ALL "v[154:157]"
-#define OSW_PS0 "v148"  // sequence-pair cell: the (first, second sequence) score pair of a row, made by v_perm_b32 one row ahead
-#define OSW_PS1 "v149"
-#define OSW_INFLIGHT "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
-// ... and the compiler is given v0..v147 only (amdgpu_num_vgpr caps what its register allocator may use; the kernel's
+// sequence-pair cell (round 4, third session): a profile buffer is EIGHT registers -- the 4-row entries of the lane's first and of its
+// second sequence (two ds_read_b128) -- so its even blocks use v150..v157 as {first: v150..v153, second: v154..v157} and its odd
+// blocks a second set, v140..v147; v148 / v149 (the v_perm_b32 pair registers of the old cell) are spare
+#define OSW_SX0 "v150, v154" // even blocks: the (first, second sequence) entries of rows 0..3 as the two sources of the row's v_pk_mad_i16
+#define OSW_SX1 "v151, v155"
+#define OSW_SX2 "v152, v156"
+#define OSW_SX3 "v153, v157"
+#define OSW_SX_A "v[150:153]"
+#define OSW_SX_B "v[154:157]"
+#define OSW_SY0 "v140, v144" // odd blocks
+#define OSW_SY1 "v141, v145"
+#define OSW_SY2 "v142, v146"
+#define OSW_SY3 "v143, v147"
+#define OSW_SY_A "v[140:143]"
+#define OSW_SY_B "v[144:147]"
+#define OSW_INFLIGHT "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+// ... and the compiler is given v0..v139 only (amdgpu_num_vgpr caps what its register allocator may use; the kernel's
 // register count still comes out as 168 -- three waves per SIMD -- because the asm statements clobber the fixed ones): the
 // fixed registers are out of its reach by construction, not by the luck of an allocation order (round 2 had them at
 // v120..v127 inside the compiler's range; with a larger budget the allocator did park temporaries there between asm
-// statements).  tools/isa_check.py verifies it on the ISA.
-#define OSW_COMPILER_VGPRS __attribute__((amdgpu_num_vgpr(148)))
+// statements).  tools/isa_check.py verifies it on the ISA.  (The compiler uses 125 - 139 of the 140.)
+#define OSW_COMPILER_VGPRS __attribute__((amdgpu_num_vgpr(140)))
 
 // ---------------------------------------------------------------------------
 // The cell, hand-scheduled.  State per row r: E[r] and D[r] = H(i0+r-1, j-1),
@@ -193,6 +202,12 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // ---------------------------------------------------------------------------
 #define OSW_TADD_PK(XN, DN, SN) "v_pk_add_i16 " XN ", " DN ", " SN " clamp\n\t"
 #define OSW_TADD_32(XN, DN, SN) "v_add_u32 " XN ", " DN ", " SN "\n\t"
+// sequence-pair cell: SN = "Ea, Eb", the 32-bit profile entries {low half: S, high half: 1} of the row for the lane's first and second
+// sequence; x.lo = Ea.lo * Eb.hi + D.lo = S(a) + D.lo, x.hi = Ea.hi * Eb.lo + D.hi = S(b) + D.hi: the half selects of v_pk_mad_i16 pair
+// the two scores up AND add them to the diagonal in one instruction (tools/oprate8.hip checks the instruction and prices the row:
+// 29.1 cycles against 33.1 with v_perm_b32 + packed add, profiles/r04_oprate8_pk_mad.txt).  An entry beyond the query is all zero
+// (fill_profile_slice): 0 * 0 + D = D, a zero score.
+#define OSW_TADD_MAD(XN, DN, SN) "v_pk_mad_i16 " XN ", " SN ", " DN " op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
 #define OSW_SCMAX(SC, SCI, DP, DN) "v_pk_maximum3_f16 " SC ", " SCI ", " DP ", " DN "\n\t"
 // plain biased cell (go_ slot: open + extend; fl_: the bias, a constant)
 #define OSW_B_ROW(ADD, XN, DN, SN, X, E, HOOK, SCMAX)                              \
@@ -254,23 +269,20 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 #define OSW_QP_LD(BUF) "ds_read_b128 " BUF ", %[a0_] offset:%[off_]\n\ts_waitcnt lgkmcnt(1)\n\t"
 #define OSW_WAIT0 "s_waitcnt lgkmcnt(0)\n\t"
 
-// Four rows of a SEQUENCE-PAIR cell.  A buffer holds {lo.x, lo.y, hi.x, hi.y}: rows (0,1) and (2,3) of the lane's
-// first and of its second sequence; v_perm_b32 pairs them up, one row ahead of their use, in OSW_PS0 / OSW_PS1 in
-// turn.  On entry OSW_PS0 holds the pair of the block's row 1; on exit that of the next block's row 1.
-#define OSW_PERM_A(PS, HI, LO) "v_perm_b32 " PS ", " HI ", " LO ", %[sela_]\n\t" /* rows 0 / 2 of a buffer half */
-#define OSW_PERM_B(PS, HI, LO) "v_perm_b32 " PS ", " HI ", " LO ", %[selb_]\n\t" /* rows 1 / 3 */
-#define OSW_SP_ROWS2(ROW, ADD, CLOY, CHIY, SC1, MID)                               \
-    ROW(ADD, "%[xb_]", "%[D1_]", OSW_PS0, "%[x_]", "%[E0_]", OSW_PERM_A(OSW_PS1, CHIY, CLOY), "") \
-    ROW(ADD, "%[x_]", "%[D2_]", OSW_PS1, "%[xb_]", "%[E1_]", OSW_PERM_B(OSW_PS0, CHIY, CLOY) MID, SC1("%[D1_]", "%[D2_]"))
-#define OSW_SP_MID(ROW, ADD, CLOY, CHIY, NLOX, NHIX, SC1, MID)                     \
-    OSW_SP_ROWS2(ROW, ADD, CLOY, CHIY, SC1, MID)                                   \
-    ROW(ADD, "%[xb_]", "%[D3_]", OSW_PS0, "%[x_]", "%[E2_]", OSW_PERM_A(OSW_PS1, NHIX, NLOX), "") \
-    ROW(ADD, "%[x_]", "%[D4_]", OSW_PS1, "%[xb_]", "%[E3_]", OSW_PERM_B(OSW_PS0, NHIX, NLOX), OSW_SC_RUN("%[D3_]", "%[D4_]"))
-#define OSW_SP_LAST(ROW, ROWL, ADD, CLOY, CHIY, SC1)                               \
-    OSW_SP_ROWS2(ROW, ADD, CLOY, CHIY, SC1, "")                                    \
-    ROW(ADD, "%[xb_]", "%[D3_]", OSW_PS0, "%[x_]", "%[E2_]", "", "")               \
+// Four rows of a SEQUENCE-PAIR cell: C1..C3 = the entry pairs ("Ea, Eb") of the block's rows 1..3, N0 = row 0 of the next block (the
+// other buffer set); MID = the loads of the block after next into this block's set (all of it has been read by then) and the wait for
+// the next block's, in front of the last row -- the query-pair cell's schedule with two ds_read_b128 per block.
+#define OSW_SP_ROWS3(ROW, C1, C2, C3, SC1)                                         \
+    ROW(OSW_TADD_MAD, "%[xb_]", "%[D1_]", C1, "%[x_]", "%[E0_]", "", "")           \
+    ROW(OSW_TADD_MAD, "%[x_]", "%[D2_]", C2, "%[xb_]", "%[E1_]", "", SC1("%[D1_]", "%[D2_]")) \
+    ROW(OSW_TADD_MAD, "%[xb_]", "%[D3_]", C3, "%[x_]", "%[E2_]", "", "")
+#define OSW_SP_MID(ROW, C1, C2, C3, N0, SC1, MID)                                  \
+    OSW_SP_ROWS3(ROW, C1, C2, C3, SC1) MID                                         \
+    ROW(OSW_TADD_MAD, "%[x_]", "%[D4_]", N0, "%[xb_]", "%[E3_]", "", OSW_SC_RUN("%[D3_]", "%[D4_]"))
+#define OSW_SP_LAST(ROW, ROWL, C1, C2, C3, SC1)                                    \
+    OSW_SP_ROWS3(ROW, C1, C2, C3, SC1)                                             \
     ROWL("%[hl_]", "%[xb_]", "%[E3_]", OSW_SC_RUN("%[D3_]", "%[hl_]"))
-#define OSW_SP_LD(LO, HI) "ds_read_b64 " LO ", %[a0_] offset:%[off_]\n\tds_read_b64 " HI ", %[a1_] offset:%[off_]\n\ts_waitcnt lgkmcnt(2)\n\t"
+#define OSW_SP_LD(BA, BB) "ds_read_b128 " BA ", %[a0_] offset:%[off_]\n\tds_read_b128 " BB ", %[a1_] offset:%[off_]\n\ts_waitcnt lgkmcnt(2)\n\t"
 
 // the statement around a block's text: rows RB*4 .. RB*4+3 of the strip
 #define OSW_BLOCK_STMT_MID(TXT, SCC, FLC)                                                                                        \
@@ -278,35 +290,34 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
                  : [x_] "+v"(x), [xb_] "=&v"(xb), [E0_] "+v"(E[RB * 4]), [E1_] "+v"(E[RB * 4 + 1]), [E2_] "+v"(E[RB * 4 + 2]),   \
                    [E3_] "+v"(E[RB * 4 + 3]), [D1_] "+v"(D[RB * 4 + 1]), [D2_] "+v"(D[RB * 4 + 2]), [D3_] "+v"(D[RB * 4 + 3]),   \
                    [D4_] "+v"(D[RB * 4 + 4]), [sc_] SCC(sc)                                                                      \
-                 : [a0_] "v"(a0), [a1_] "v"(a1), [off_] "i"((RB + 2) * BLOCK_BYTES), [ge_] "s"(ge), [go_] "s"(go), [fl_] FLC(fl),  \
-                   [sela_] "s"(0x05040100u), [selb_] "s"(0x07060302u)                                                            \
+                 : [a0_] "v"(a0), [a1_] "v"(a1), [off_] "i"((RB + 2) * BLOCK_BYTES), [ge_] "s"(ge), [go_] "s"(go), [fl_] FLC(fl)   \
                  : "memory", OSW_INFLIGHT)
 #define OSW_BLOCK_STMT_LAST(TXT, SCC, FLC)                                                                                       \
     asm volatile(TXT                                                                                                             \
                  : [x_] "+v"(x), [xb_] "=&v"(xb), [E0_] "+v"(E[RB * 4]), [E1_] "+v"(E[RB * 4 + 1]), [E2_] "+v"(E[RB * 4 + 2]),   \
                    [E3_] "+v"(E[RB * 4 + 3]), [D1_] "+v"(D[RB * 4 + 1]), [D2_] "+v"(D[RB * 4 + 2]), [D3_] "+v"(D[RB * 4 + 3]),   \
                    [hl_] "=&v"(hl), [sc_] SCC(sc)                                                                                \
-                 : [ge_] "s"(ge), [go_] "s"(go), [fl_] FLC(fl), [sela_] "s"(0x05040100u), [selb_] "s"(0x07060302u)               \
+                 : [ge_] "s"(ge), [go_] "s"(go), [fl_] FLC(fl)                                                                   \
                  : "memory", OSW_INFLIGHT)
 
 // One block of either cell kind with buffers CUR* (this block's) and NXT* (the next one's); SC1 = how the block's
 // first odd row folds into the maximum (OSW_SC_RUN, or OSW_SC_START in block 0 of the column-frame cell)
-#define OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, C0, C1, C2, C3, CLO, CHI, CALL, N0, N1, N2, N3)                           \
+#define OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, C1, C2, C3, CALL, N0, S1, S2, S3, SA, SB, SN0)                              \
     do {                                                                                                                         \
         if constexpr (!SEQ) {                                                                                                    \
             if constexpr (LAST) OSW_BLOCK_STMT_LAST(OSW_QP_LAST(ROW, ROWL, ADD, C1, C2, C3, SC1), SCC1, FLC);                    \
             else if constexpr (LD) OSW_BLOCK_STMT_MID(OSW_QP_MID(ROW, ADD, C1, C2, C3, N0, SC1, OSW_QP_LD(CALL)), SCC1, FLC);    \
             else OSW_BLOCK_STMT_MID(OSW_QP_MID(ROW, ADD, C1, C2, C3, N0, SC1, OSW_WAIT0), SCC1, FLC);                            \
         } else {                                                                                                                 \
-            if constexpr (LAST) OSW_BLOCK_STMT_LAST(OSW_SP_LAST(ROW, ROWL, ADD, C1, C3, SC1), SCC1, FLC);                        \
-            else if constexpr (LD) OSW_BLOCK_STMT_MID(OSW_SP_MID(ROW, ADD, C1, C3, N0, N2, SC1, OSW_SP_LD(CLO, CHI)), SCC1, FLC); \
-            else OSW_BLOCK_STMT_MID(OSW_SP_MID(ROW, ADD, C1, C3, N0, N2, SC1, OSW_WAIT0), SCC1, FLC);                            \
+            if constexpr (LAST) OSW_BLOCK_STMT_LAST(OSW_SP_LAST(ROW, ROWL, S1, S2, S3, SC1), SCC1, FLC);                         \
+            else if constexpr (LD) OSW_BLOCK_STMT_MID(OSW_SP_MID(ROW, S1, S2, S3, SN0, SC1, OSW_SP_LD(SA, SB)), SCC1, FLC);      \
+            else OSW_BLOCK_STMT_MID(OSW_SP_MID(ROW, S1, S2, S3, SN0, SC1, OSW_WAIT0), SCC1, FLC);                                \
         }                                                                                                                        \
     } while (0)
 #define OSW_BLOCK_EVEN(ROW, ROWL, ADD, SC1, SCC1, FLC) \
-    OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, OSW_PA0, OSW_PA1, OSW_PA2, OSW_PA3, OSW_PA_LO, OSW_PA_HI, OSW_PA_ALL, OSW_PB0, OSW_PB1, OSW_PB2, OSW_PB3)
+    OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, OSW_PA1, OSW_PA2, OSW_PA3, OSW_PA_ALL, OSW_PB0, OSW_SX1, OSW_SX2, OSW_SX3, OSW_SX_A, OSW_SX_B, OSW_SY0)
 #define OSW_BLOCK_ODD(ROW, ROWL, ADD, SC1, SCC1, FLC) \
-    OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, OSW_PB0, OSW_PB1, OSW_PB2, OSW_PB3, OSW_PB_LO, OSW_PB_HI, OSW_PB_ALL, OSW_PA0, OSW_PA1, OSW_PA2, OSW_PA3)
+    OSW_BLOCK_BODY(ROW, ROWL, ADD, SC1, SCC1, FLC, OSW_PB1, OSW_PB2, OSW_PB3, OSW_PB_ALL, OSW_PA0, OSW_SY1, OSW_SY2, OSW_SY3, OSW_SY_A, OSW_SY_B, OSW_SX0)
 
 // The head of a column: LDS addresses of the lane's residue(s), the loads of blocks 0 and 1, the first diagonal sum
 // (and, for the sequence-pair cell, the score pairs of rows 0 and 1).  VC = the residue register of the step.
@@ -317,21 +328,20 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
     LD1                                                                            \
     ADD("%[x_]", "%[tp_]", OSW_PA0)
 #define OSW_QP_HEAD_LD1 "ds_read_b128 " OSW_PB_ALL ", %[a0_] offset:%[off_]\n\ts_waitcnt lgkmcnt(1)\n\t"
-#define OSW_SP_HEAD(ADD, VC, LD1)                                                  \
-    "v_add_u32_sdwa %[a0_], %[base_], " VC " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
-    "v_add_u32_sdwa %[a1_], %[base_], " VC " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
-    "ds_read_b64 " OSW_PA_LO ", %[a0_]\n\t"                                        \
-    "ds_read_b64 " OSW_PA_HI ", %[a1_]\n\t"                                        \
+#define OSW_SP_HEAD(VC, LD1)                                                       \
+    "v_and_b32 %[a0_], 0xff, " VC "\n\t"                                           \
+    "v_lshrrev_b32 %[a1_], 8, " VC "\n\t"                                          \
+    "v_lshl_add_u32 %[a0_], %[a0_], 1, %[base_]\n\t"                               \
+    "v_lshl_add_u32 %[a1_], %[a1_], 1, %[base_]\n\t"                               \
+    "ds_read_b128 " OSW_SX_A ", %[a0_]\n\t"                                        \
+    "ds_read_b128 " OSW_SX_B ", %[a1_]\n\t"                                        \
     LD1                                                                            \
-    OSW_PERM_A(OSW_PS1, OSW_PA2, OSW_PA0)                                          \
-    OSW_PERM_B(OSW_PS0, OSW_PA2, OSW_PA0)                                          \
-    ADD("%[x_]", "%[tp_]", OSW_PS1)
-#define OSW_SP_HEAD_LD1 "ds_read_b64 " OSW_PB_LO ", %[a0_] offset:%[off_]\n\tds_read_b64 " OSW_PB_HI ", %[a1_] offset:%[off_]\n\ts_waitcnt lgkmcnt(2)\n\t"
+    OSW_TADD_MAD("%[x_]", "%[tp_]", OSW_SX0)
+#define OSW_SP_HEAD_LD1 "ds_read_b128 " OSW_SY_A ", %[a0_] offset:%[off_]\n\tds_read_b128 " OSW_SY_B ", %[a1_] offset:%[off_]\n\ts_waitcnt lgkmcnt(2)\n\t"
 #define OSW_HEAD_STMT(TXT)                                                                                                       \
     asm volatile(TXT                                                                                                             \
                  : [a0_] "=&v"(a0), [a1_] "=&v"(a1), [x_] "=&v"(x)                                                               \
-                 : [base_] "v"(base), [tp_] "v"(top_prev), [sh_] "s"(sh), [off_] "i"(BLOCK_BYTES), [sela_] "s"(0x05040100u),     \
-                   [selb_] "s"(0x07060302u)                                                                                      \
+                 : [base_] "v"(base), [tp_] "v"(top_prev), [sh_] "s"(sh), [off_] "i"(BLOCK_BYTES)                                \
                  : "memory", OSW_INFLIGHT)
 #define OSW_HEAD_BODY(ADD)                                                                                                       \
     do {                                                                                                                         \
@@ -341,10 +351,10 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
             else if constexpr (NB > 1) OSW_HEAD_STMT(OSW_QP_HEAD(ADD, OSW_VC1, OSW_QP_HEAD_LD1));                                \
             else OSW_HEAD_STMT(OSW_QP_HEAD(ADD, OSW_VC1, OSW_WAIT0));                                                            \
         } else {                                                                                                                 \
-            if constexpr (P == 0 && NB > 1) OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC0, OSW_SP_HEAD_LD1));                           \
-            else if constexpr (P == 0) OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC0, OSW_WAIT0));                                      \
-            else if constexpr (NB > 1) OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC1, OSW_SP_HEAD_LD1));                                \
-            else OSW_HEAD_STMT(OSW_SP_HEAD(ADD, OSW_VC1, OSW_WAIT0));                                                            \
+            if constexpr (P == 0 && NB > 1) OSW_HEAD_STMT(OSW_SP_HEAD(OSW_VC0, OSW_SP_HEAD_LD1));                           \
+            else if constexpr (P == 0) OSW_HEAD_STMT(OSW_SP_HEAD(OSW_VC0, OSW_WAIT0));                                      \
+            else if constexpr (NB > 1) OSW_HEAD_STMT(OSW_SP_HEAD(OSW_VC1, OSW_SP_HEAD_LD1));                                \
+            else OSW_HEAD_STMT(OSW_SP_HEAD(OSW_VC1, OSW_WAIT0));                                                            \
         }                                                                                                                        \
     } while (0)
 
@@ -358,14 +368,14 @@ struct ArithI16B {
     template <int P, int NB, bool SEQ>
     static __device__ __forceinline__ void head(uint32_t base, uint32_t sh, v2s top_prev, uint32_t &a0, uint32_t &a1, v2s &x)
     {
-        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        constexpr int BLOCK_BYTES = SEQ ? 16 * OSW_SEQ_CODES : 512; // 16 B per code: 4 rows x a {S, 1} entry (24 codes), or x the int16 scores of two queries (32)
         OSW_HEAD_BODY(OSW_TADD_PK);
     }
     template <int RB, int NB, bool SEQ>
     static __device__ __forceinline__ void block(uint32_t a0, uint32_t a1, v2s (&D)[NB * 4], v2s (&E)[NB * 4], v2s &x, v2s &hl, v2s &sc, uint32_t ge,
                                                  uint32_t go, v2s /*aux*/)
     {
-        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        constexpr int BLOCK_BYTES = SEQ ? 16 * OSW_SEQ_CODES : 512; // 16 B per code: 4 rows x a {S, 1} entry (24 codes), or x the int16 scores of two queries (32)
         constexpr bool LAST = RB == NB - 1, LD = RB + 2 < NB;
         const uint32_t fl = OSW_I16B_BIAS;
         v2s xb;
@@ -389,7 +399,7 @@ struct ArithI16S {
     template <int P, int NB, bool SEQ>
     static __device__ __forceinline__ void head(uint32_t base, uint32_t sh, v2s top_prev, uint32_t &a0, uint32_t &a1, v2s &x)
     {
-        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        constexpr int BLOCK_BYTES = SEQ ? 16 * OSW_SEQ_CODES : 512; // 16 B per code: 4 rows x a {S, 1} entry (24 codes), or x the int16 scores of two queries (32)
         if constexpr (INTSUM) OSW_HEAD_BODY(OSW_TADD_32);
         else OSW_HEAD_BODY(OSW_TADD_PK);
     }
@@ -397,7 +407,7 @@ struct ArithI16S {
     static __device__ __forceinline__ void block(uint32_t a0, uint32_t a1, v2s (&D)[NB * 4], v2s (&E)[NB * 4], v2s &x, v2s &hl, v2s &sc, uint32_t ge,
                                                  uint32_t go, v2s fl)
     {
-        constexpr int BLOCK_BYTES = SEQ ? 256 : 512;
+        constexpr int BLOCK_BYTES = SEQ ? 16 * OSW_SEQ_CODES : 512; // 16 B per code: 4 rows x a {S, 1} entry (24 codes), or x the int16 scores of two queries (32)
         constexpr bool LAST = RB == NB - 1, LD = RB + 2 < NB;
         v2s xb;
         if constexpr (INTSUM) {
@@ -423,9 +433,10 @@ struct CellSeqPair {
     static constexpr uint32_t kFloorBits = A::kFloor;
     static constexpr bool kShifted = A::kShifted;
     static constexpr int kRows = OSW_RMAX16;
-    static constexpr int kLdsRows = OSW_LDS_ROWS16;
-    static constexpr int kRowBytes = 64; // profile bytes per query row: 32 codes x int16
-    typedef uint2 Entry;                 // one code, 4 rows
+    static constexpr int kLdsRows = OSW_LDS_ROWS16_SEQ;
+    static constexpr int kCodes = OSW_SEQ_CODES; // entries per row-block: the 24 residue codes the re-tiled database can hold
+    static constexpr int kRowBytes = 4 * OSW_SEQ_CODES; // profile bytes per query row: 24 codes x a 32-bit entry {low half: S, high half: 1}
+    typedef uint4 Entry;                  // one code, 4 rows (osw_build_profile's prof_seq)
     static __device__ __forceinline__ T zero() { return as_v2s(A::kFloor); } // the value that stands for 0
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
@@ -436,11 +447,11 @@ struct CellSeqPair {
     //   the set's C register (8*code = byte offset of the code's profile entry), F(i0, j) in its
     //   F register (out: F(i0+R, j)).  base = LDS byte address of the lane's profile slice;
     //   top_prev = H(i0-1, j-1); hl = H(i0+R-1, j).
-    // Four rows of substitution scores for both sequences of the lane are two ds_read_b64 (one per
-    // sequence; single ones: a ds_read2_b64's 32-bank addressing makes residue codes c and c+16
-    // collide, measured 2.5 conflict cycles per LDS instruction, while ds_read_b64 sees 64 banks and
-    // the 32 codes x 8 B of a row-block are conflict-free) + four v_perm_b32 that pair up (lo, hi);
-    // the loads run two blocks ahead, inside the blocks' statements (ArithI16*::block).
+    // Four rows of profile entries for both sequences of the lane are two ds_read_b128 (one per sequence; 16 B per
+    // residue code: address = base + 2 * (8*code)); the row's v_pk_mad_i16 pairs the two scores up and adds them to the
+    // diagonal (OSW_TADD_MAD: 6.5 instructions per row; until the third session of round 4 a v_perm_b32 per row paired
+    // 16-bit scores from 8-byte entries and a packed add followed: 7.5); the loads run two blocks ahead, inside the
+    // blocks' statements (ArithI16*::block).
     template <int R, int RB>
     struct Blocks {
         static __device__ __forceinline__ void run(uint32_t a0, uint32_t a1, T (&D)[R], T (&E)[R], T &x, T &hl, GapT goe, GapT ge, T &score, T aux)
@@ -479,6 +490,7 @@ struct CellQueryPair {
     static constexpr bool kShifted = A::kShifted;
     static constexpr int kRows = OSW_RMAX16;
     static constexpr int kLdsRows = OSW_LDS_ROWS16 / 2;
+    static constexpr int kCodes = 32;
     static constexpr int kRowBytes = 128; // 32 codes x 2 queries x int16
     typedef uint4 Entry;                  // one code, 4 rows x 2 queries
     static __device__ __forceinline__ T zero() { return as_v2s(A::kFloor); } // the value that stands for 0
@@ -522,6 +534,7 @@ struct CellI32 {
     static constexpr bool kShifted = false;
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
+    static constexpr int kCodes = 32;
     static constexpr int kRowBytes = 64;
     typedef uint2 Entry;
     static __device__ __forceinline__ T zero() { return 0; }
@@ -928,15 +941,15 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
 // the same code -- all lanes past the end of their sequence read the dummy code -- would otherwise hit the same
 // LDS banks at different addresses (a G-way conflict); shifted by one entry per group they hit neighbouring
 // banks.  E = uint2 / uint4 (the entry); tid / nthr: the threads that copy (a wave, or the whole workgroup).
-template <class E>
+template <class E, uint32_t NC = 32u> // NC = entries (residue codes) per row-block
 static __device__ __forceinline__ void fill_profile_slice(const E *prof_q, uint32_t rb0, uint32_t rbg, uint32_t G, uint32_t rb_end, E *dst,
                                                           uint32_t tid, uint32_t nthr)
 {
-    const uint32_t per_group = rbg * 32u; // entries
+    const uint32_t per_group = rbg * NC; // entries
     for (uint32_t g = 0; g < G; ++g) {
         const uint32_t rbs = rb0 + g * rbg; // first row-block of the group
-        const uint32_t valid = rb_end > rbs ? ((rb_end - rbs) < rbg ? (rb_end - rbs) : rbg) * 32u : 0u;
-        const E *src = prof_q + (size_t)rbs * 32u;
+        const uint32_t valid = rb_end > rbs ? ((rb_end - rbs) < rbg ? (rb_end - rbs) : rbg) * NC : 0u;
+        const E *src = prof_q + (size_t)rbs * NC;
         E *d = dst + (size_t)g * (per_group + 1u);
         for (uint32_t e = tid; e < per_group; e += nthr) d[e] = e < valid ? src[e] : E{};
     }
@@ -979,7 +992,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     uint2 *bnd = (uint2 *)osw_uniform64((uint64_t)bnd_wave);
     const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
     typedef typename C::Entry Entry; // the profile scores of one residue code for 4 rows
-    const Entry *prof_q = (const Entry *)prof + (size_t)p.prof_off[q] * 32u;
+    const Entry *prof_q = (const Entry *)prof + (size_t)p.prof_off[q] * (uint32_t)C::kCodes;
     if (plan.rounds > 1) {
         // the scratch columns the prefetch and the drain steps read past the block's last one are the
         // row above of dummy columns: "zero" in the cell's representation (other items have written here)
@@ -1005,7 +1018,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             __syncthreads(); // every wave is done with the previous slice
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
-            fill_profile_slice<Entry>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
+            fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
             __syncthreads();
 #ifdef OSW_DIAG
             if (p.wg_times && lane == 0) atomicAdd(&p.counters_ovf[4], (uint32_t)((__builtin_readcyclecounter() - tb) >> 10));
@@ -1014,7 +1027,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             // only this wave touches its region; LDS operations of one wave execute in order, the wave barriers
             // only pin the compiler's order
             __builtin_amdgcn_wave_barrier();
-            fill_profile_slice<Entry>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
+            fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -1536,6 +1549,14 @@ extern "C" __global__ __launch_bounds__(256) void osw_fill16(uint4 *__restrict__
 // pre-filled with the dummy residue: OSW_TILED_PAD_GROUPS all-dummy groups lie
 // in front of the first block and behind every block (the columns the lane
 // groups of the search kernels warm up, prefetch and drain through).
+// four residue codes in the bytes of a word, each masked to five bits and 24..31 replaced by 23
+static __device__ __forceinline__ uint32_t osw_clamp_codes4(uint32_t v)
+{
+    v &= 0x1f1f1f1fu;
+    const uint32_t m = ((v >> 3) & (v >> 4) & 0x01010101u) * 0x1fu; // 0x1f in the bytes that hold 24..31
+    return (v & ~m) | (m & 0x17171717u);
+}
+
 extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
                                                               const uint32_t *__restrict__ disp, uint32_t ngroups, uint32_t W,
                                                               const OswBlock *__restrict__ blocks, uint16_t *__restrict__ tiled)
@@ -1557,8 +1578,10 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__re
             r0 = src[(size_t)j * W];
             r1 = src[(size_t)j * W + 1];
         }
-        // codes >= 32 cannot come from the reference's preprocessing (0..23); keep the offset inside the entry row
-        tiled[((size_t)blk.col4_off * 4 + j) * 64 + lane] = (uint16_t)(((r0 & 31u) * 8u) | (((r1 & 31u) * 8u) << 8));
+        // codes >= 24 cannot come from the reference's preprocessing (0..23) and score like the dummy, 23, in every matrix
+        // oswald_hip_set_scoring accepts: they are stored as 23 (the single-query kernels' profile holds 24 entries per row-block)
+        r0 &= 31u; r1 &= 31u;
+        tiled[((size_t)blk.col4_off * 4 + j) * 64 + lane] = (uint16_t)(((r0 < 24u ? r0 : 23u) * 8u) | (((r1 < 24u ? r1 : 23u) * 8u) << 8));
     }
 }
 
@@ -1607,8 +1630,8 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile16(const uint8_t *__
             if ((w[k] & 0xffffu) != 0x1717u) last[2 * k] = j + 1;
             if ((w[k] >> 16) != 0x1717u) last[2 * k + 1] = j + 1;
         }
-        // codes >= 32 cannot come from the reference's preprocessing (0..23); keep the offset inside the entry row
-        dst[(size_t)j * 8] = make_uint4((v.x & 0x1f1f1f1fu) << 3, (v.y & 0x1f1f1f1fu) << 3, (v.z & 0x1f1f1f1fu) << 3, (v.w & 0x1f1f1f1fu) << 3);
+        // codes >= 24 (bits 4 and 3 both set) cannot come from the reference's preprocessing (0..23); they are stored as 23, see osw_retile
+        dst[(size_t)j * 8] = make_uint4(osw_clamp_codes4(v.x) << 3, osw_clamp_codes4(v.y) << 3, osw_clamp_codes4(v.z) << 3, osw_clamp_codes4(v.w) << 3);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -1660,7 +1683,7 @@ extern "C" __global__ __launch_bounds__(128) void osw_block_extent(OswBlock *blo
 extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_t *__restrict__ a, const uint32_t *__restrict__ a_disp,
                                                                      const uint16_t *__restrict__ qlen, const uint32_t *__restrict__ prof_off,
                                                                      const int8_t *__restrict__ submat, uint32_t nq, int add,
-                                                                     uint2 *__restrict__ prof)
+                                                                     uint2 *__restrict__ prof, uint4 *__restrict__ prof_seq)
 {
     const uint32_t q = blockIdx.y;
     if (q >= nq) return;
@@ -1684,6 +1707,15 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_profile(const uint8_
         o.x = (uint32_t)(uint16_t)s[0] | ((uint32_t)(uint16_t)s[1] << 16);
         o.y = (uint32_t)(uint16_t)s[2] | ((uint32_t)(uint16_t)s[3] << 16);
         prof[(size_t)(prof_off[q] + rb) * 32 + code] = o;
+        // the sequence-pair cell's form of the same entry: a 32-bit word per row, {low half: S, high half: 1} (OSW_TADD_MAD)
+        if (prof_seq && code < OSW_SEQ_CODES) {
+            uint4 w;
+            w.x = (uint32_t)(uint16_t)s[0] | 0x10000u;
+            w.y = (uint32_t)(uint16_t)s[1] | 0x10000u;
+            w.z = (uint32_t)(uint16_t)s[2] | 0x10000u;
+            w.w = (uint32_t)(uint16_t)s[3] | 0x10000u;
+            prof_seq[(size_t)(prof_off[q] + rb) * OSW_SEQ_CODES + code] = w;
+        }
     }
 }
 
@@ -1945,12 +1977,12 @@ hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t
 }
 
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
-                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, int add, uint2 *prof, hipStream_t s)
+                                    const int8_t *submat, uint32_t nq, uint32_t max_rowblocks, int add, uint2 *prof, uint4 *prof_seq, hipStream_t s)
 {
     if (nq == 0) return hipSuccess;
     uint32_t gx = (max_rowblocks * 32 + 255) / 256;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, add, prof);
+    hipLaunchKernelGGL(osw_build_profile, dim3(gx, nq), dim3(256), 0, s, a, a_disp, qlen, prof_off, submat, nq, add, prof, prof_seq);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -43,5 +43,6 @@ timeout -k 10 200 ./tools/oprate4 > $OUT/oprate4.txt 2>&1
 timeout -k 10 100 ./tools/oprate5 > $OUT/oprate5.txt 2>&1
 timeout -k 10 100 ./tools/oprate6 > $OUT/oprate6.txt 2>&1
 timeout -k 10 100 ./tools/oprate7 > $OUT/oprate7.txt 2>&1
+timeout -k 10 100 ./tools/oprate8 > $OUT/oprate8.txt 2>&1
 python tools/cli_e2e.py 1000000 > $OUT/cli_1m.txt 2>&1; echo "cli e2e rc=$?"; tail -5 $OUT/cli_1m.txt
 tools/startup_probe.sh > $OUT/startup.txt 2>&1
