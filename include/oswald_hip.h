@@ -95,7 +95,13 @@ int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen);
  * cells in int32, on the device (the reference escalates int8 -> int16 ->
  * int32 on the host, HybridSearch.c:1670-1680,:1774-1784).  With cell_bits 8
  * a matrix whose entries span more than 127, or a gap penalty above 127,
- * makes the search run on the int16 cells alone. */
+ * makes the search run on the int16 cells alone.
+ * Column 23 of the table is the dummy residue's and columns 24..31 are
+ * padding; in the reference's matrices all nine hold zeros, and its
+ * preprocessing emits the residue codes 0..23 only (sequences.c:60-116).  The
+ * library treats a database residue code of 24..31 as code 23, and refuses
+ * (OSWALD_HIP_EINVAL) a table whose columns 24..31 do not repeat column 23 --
+ * the one case in which that would change a score. */
 int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_gap, int extend_gap, int cell_bits);
 
 /* Query set: residues of all queries back to back (codes 0..23), lengths m[],

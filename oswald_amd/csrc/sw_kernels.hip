@@ -228,21 +228,22 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
     "v_pk_maximum3_f16 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                       \
     "v_pk_maximum3_f16 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]"
 // column-frame cell (go_ slot: gap open; fl_: the floor of the next column's frame, a register)
-#define OSW_S_ROW_T(ADD, PAUSE, XN, DN, SN, X, E, HOOK, SCMAX)                      \
+#define OSW_S_ROW_T(ADD, PAUSE1, PAUSE2, XN, DN, SN, X, E, HOOK, SCMAX)             \
     ADD(XN, DN, SN) HOOK                                                           \
     "v_pk_maximum3_f16 " DN ", " X ", " E ", " OSW_VF "\n\t"                       \
-    "v_subrev_u32 " OSW_VT ", %[go_], " DN "\n\t" PAUSE                            \
+    "v_subrev_u32 " OSW_VT ", %[go_], " DN "\n\t" PAUSE1                           \
     SCMAX                                                                          \
     "v_pk_maximum3_f16 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                       \
     "v_pk_maximum3_f16 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]\n\t"             \
-    "v_subrev_u32 " OSW_VF ", %[ge_], " OSW_VF "\n\t" PAUSE
-#define OSW_S_ROW(ADD, XN, DN, SN, X, E, HOOK, SCMAX) OSW_S_ROW_T(ADD, "", XN, DN, SN, X, E, HOOK, SCMAX)
-// ... with a one-cycle pause behind each of the two subtracts: the query-pair kernel's row.  The rate at which three
-// waves get these rows through a SIMD depends on where a wave steps aside (tools/oprate5.hip: 25.5 - 27.5 cycles per
-// row over the placements of an s_nop 0, 26.2 with none; behind a 32-bit VOP2 it helps, behind a VOP3P it hurts); in
-// the kernel (profiles/r04_nop_sweep.txt) no pause costs the pair kernel 3.5 %, this placement is the best of the 14
-// tried, and the sequence-pair kernel (a v_perm_b32 per row on top) is best with none.
-#define OSW_S_ROWP(ADD, XN, DN, SN, X, E, HOOK, SCMAX) OSW_S_ROW_T(ADD, "s_nop 0\n\t", XN, DN, SN, X, E, HOOK, SCMAX)
+    "v_subrev_u32 " OSW_VF ", %[ge_], " OSW_VF "\n\t" PAUSE2
+// The rate at which three waves get these rows through a SIMD depends on where a wave steps aside (tools/oprate5.hip: 25.5 - 27.5
+// cycles per row over the placements of an s_nop 0, 26.2 with none; behind a 32-bit VOP2 it helps, behind a VOP3P it hurts).
+// Query-pair kernel (profiles/r04_nop_sweep.txt): a one-cycle pause behind each of the two subtracts -- none costs it 3.5 %, this
+// placement is the best of the 14 tried.  Sequence-pair kernel (its diagonal add is the VOP3P v_pk_mad_i16; tools/ab_seq_pause.sh,
+// two runs each on Q1 / C5 at 1 M sequences): behind the first subtract only +0.8 / +0.9 %, behind the second only +0.7 / +0.7 %,
+// behind both -1.2 / -0.8 %.
+#define OSW_S_ROW(ADD, XN, DN, SN, X, E, HOOK, SCMAX) OSW_S_ROW_T(ADD, "s_nop 0\n\t", "", XN, DN, SN, X, E, HOOK, SCMAX)
+#define OSW_S_ROWP(ADD, XN, DN, SN, X, E, HOOK, SCMAX) OSW_S_ROW_T(ADD, "s_nop 0\n\t", "s_nop 0\n\t", XN, DN, SN, X, E, HOOK, SCMAX)
 #define OSW_S_ROW_LAST(HL, X, E, SCMAX)                                            \
     "v_pk_maximum3_f16 " HL ", " X ", " E ", " OSW_VF "\n\t"                       \
     "v_subrev_u32 " OSW_VT ", %[go_], " HL "\n\t"                                  \

@@ -830,3 +830,38 @@ def test_api_misuse_of_the_round3_entry_points(hip_ctx):
     hip_ctx.chunk_release(h)
     s2, i2 = capi.merge_candidates(np.array([[5, -1, 5, 7]], np.int32), np.array([[3, 0, 9, 1]], np.uint32), 3)
     assert s2.tolist() == [[7, 5, 5]] and i2.tolist() == [[1, 9, 3]]
+
+
+@pytest.mark.parametrize("W", [16, 64])
+@pytest.mark.parametrize("bits", [16, 8, 32])
+def test_residue_codes_beyond_the_alphabet_score_like_the_dummy(hip_ctx, oracle, W, bits):
+    """The reference's preprocessing emits the codes 0..23 and its matrices hold zeros in column 23 (the dummy) and in the
+    padding columns 24..31 (host/src/submat.c).  The re-tile kernels store a code >= 24 as 23 -- the single-query kernels'
+    profile has 24 entries per row-block -- which is exact for such matrices: one query, a pair and an odd one out against
+    sequences sprinkled with the codes 24..31, on every cell mode and both re-tile kernels (W = 16 has its own)."""
+    rng = np.random.default_rng(2404)
+    for qlens in ([120], [60, 61], [33, 90, 91]):
+        qs = synth.make_queries(qlens, seed=3)
+        seqs = [rng.integers(0, 24, int(l)).astype(np.uint8) for l in rng.integers(1, 300, 150)]
+        for s in seqs[::3]:
+            s[rng.integers(0, len(s), max(1, len(s) // 5))] = rng.integers(24, 32, max(1, len(s) // 5))
+        seqs.append(np.concatenate([qs[-1], rng.integers(24, 32, 7).astype(np.uint8), qs[-1]]))
+        L, R, O = db_from_sequences(seqs)
+        b, n, disp, _, _ = layout(L, R, O, W)
+        assert (b >= 24).any()
+        sm = submat.load("blosum62")
+        got = run_gpu(hip_ctx, qs, b, n, disp, W, sm, 10, 2, cell_bits=bits)
+        want = expect(oracle, qs, b, n, disp, W, sm, 10, 2)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_matrix_padding_columns_must_repeat_the_dummy_column(hip_ctx):
+    """... and a matrix for which that would not be exact is refused by oswald_hip_set_scoring, with the reason."""
+    from oswald_amd import capi
+    sm = submat.load("blosum62").copy()
+    sm[5, 27] = 3
+    with pytest.raises(capi.OswaldHipError, match="column 27"):
+        hip_ctx.set_scoring(sm, 10, 2, 0)
+    sm = submat.load("blosum62").copy()
+    sm[:, 23:] = -2   # any value, as long as the padding repeats column 23
+    hip_ctx.set_scoring(sm, 10, 2, 0)
