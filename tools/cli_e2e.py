@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/cli_e2e.py -- end-to-end wall time of the `oswald` CLI on a synthetic C2-size database."""
+"""tools/cli_e2e.py [nseq [tmpdir [query lengths, comma separated]]] -- end-to-end wall time of the `oswald` CLI on a synthetic database
+(default: the 20 queries of C2; "375" = Q1, "5000" = C5)."""
 import os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oswald_amd import synth
@@ -7,7 +8,7 @@ nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 tmp = sys.argv[2] if len(sys.argv) > 2 else "/tmp/osw_e2e"
 os.makedirs(tmp, exist_ok=True)
 cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oswald_amd", "oswald")
-qs = synth.make_queries(synth.default_query_lengths())
+qs = synth.make_queries([int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else synth.default_query_lengths())
 L, R, O = synth.make_database(nseq, qs)
 t = time.time(); synth.write_fasta(f"{tmp}/db.fasta", [R[O[i]:O[i+1]] for i in range(nseq)]); synth.write_fasta(f"{tmp}/q.fasta", qs); print("fasta written", round(time.time()-t,1), "s")
 t = time.time(); subprocess.run([cli, "-O", "preprocess", "-i", f"{tmp}/db.fasta", "-o", f"{tmp}/db"], check=True, stdout=subprocess.DEVNULL); print("preprocess", round(time.time()-t,2), "s")
