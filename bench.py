@@ -133,6 +133,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # this pool's host driver supports dmabuf IPC only: without it RCCL's exchange of buffers between the ranks' processes fails
+    # (hipIpcGetMemHandle: invalid argument).  The image exports it; a launcher that built its own environment may not have.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world == 1 and args.gpus > 1:
         # started without a launcher: start the ranks ourselves (before anything touches the GPU) and leave with their code
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
