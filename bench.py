@@ -57,7 +57,7 @@ CLOCK_HZ = 2.4e9                 # max clock (MI355X_MICROARCH.md)
 N_CU = 256
 SIMD_PER_CU = 4
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
-# lane: two sequences per lane, incl. the v_perm_b32 that pairs their scores; query pairs)}
+# lane: two sequences per lane, their scores paired and added by one v_pk_mad_i16; query pairs)}
 PK_OPS_PER_ROW = {16: (6.5, 6.5), 32: (24.0, 24.0), 8: (20.0, 20.0)}  # 8: 39 SWAR instructions + 1 v_perm_b32 per row of a 2 x 2 tile = 256 cells (q8_cell.h, CellQ8F)
 # ... and what such a row costs in core-clock cycles per SIMD at 4 waves per SIMD.  int16: MEASURED on the cell's own
 # instruction mix (tools/oprate2.hip, profiles/r02_oprate2_valu_mix.txt: 3.5 VOP3P + 3 VOP2 = 25.3 cycles for the query-pair

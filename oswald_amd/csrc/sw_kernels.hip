@@ -12,8 +12,10 @@
 //     cell is kept as short as the ISA allows and hand-scheduled:
 //       - packed int16 values carrying a bias of 1024, on which gfx950's
 //         v_pk_maximum3_f16 is an integer max3, stored relative to a per-column
-//         frame that makes the horizontal gap decay free: 6.5 VOP3P
-//         instructions per row (+1 v_perm_b32 when a lane holds two sequences),
+//         frame that makes the horizontal gap decay free: 6.5
+//         instructions per row -- also when a lane holds two sequences of ONE
+//         query: a v_pk_mad_i16 with half selects pairs their two scores up and
+//         adds them to the diagonal (OSW_TADD_MAD) --,
 //         exact below 22256 (plain biased cell for blocks whose frame would not
 //         fit: 7.5 per row, exact below 30576);
 //       - sequences that reach the ceiling are queued for the int32 kernel
@@ -25,8 +27,8 @@
 //     four waves and 8 KB, which cost a third more round boundaries and gained
 //     nothing: a gfx950 SIMD issues these instruction streams at the same rate
 //     from three waves as from four); database columns stream through.  The strip's slice of the query profile lives in a wave-private
-//     LDS region and is read with conflict-free ds_read_b64 (4 rows per read,
-//     address = 8*residue + imm; `tiled` stores 8*residue).
+//     LDS region and is read with ds_read_b128 (the 16-byte entry of a residue
+//     code: 4 rows; address = 2 * (8*residue) + imm; `tiled` stores 8*residue).
 //   * "wave geometry" G (1,2,4,...,64): the 64 lanes form G groups of 64/G
 //     lanes.  Group g runs strip (round*G + g) of the SAME 128/G sequences, one
 //     column behind group g-1, and receives that group's bottom row (H, F)
@@ -183,7 +185,7 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // every H, E, F pattern is >= 1024 >= go, ge (the kernel checks go <= 1024; ge <= 64 anyway).  The diagonal add is a
 // v_add_u32 too when the profile stores its (S_lo, S_hi) pairs as the 32-bit INTEGER S_lo + 65536 * S_hi (query-pair
 // profile, osw_build_pair_profile), so that the sum is right in both halves although S_lo may be negative; the
-// sequence-pair cell assembles its score pairs with v_perm_b32 and keeps the packed add.
+// sequence-pair cell's diagonal add is the v_pk_mad_i16 that also pairs the lane's two scores up (OSW_TADD_MAD).
 // ---------------------------------------------------------------------------
 #define OSW_I16S_FRAME_MAX 8192u
 
@@ -194,11 +196,11 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
 // of any instruction or statement that touches a register the statement before it defines -- outputs and clobbers alike,
 // other asm statements in between counting for nothing.  With a statement per row, per load and per wait that was 73-75
 // s_nop in a 48-row column, ~0.9 cycles each at three waves per SIMD (tools/oprate4.hip, probe fs_nop; the statements
-// all end in full 32-bit writes: none has the hazard).  With the loads, the waits and the v_perm_b32 inside the block
+// all end in full 32-bit writes: none has the hazard).  With the loads and the waits inside the block
 // statement -- the profile buffers and the temporaries are fixed registers for that -- 15 are left.
 //   register / operand names are strings: XN = diagonal sum of the next row (out), DN = D[r+1] (in: H(r, j-1), out:
 //   H(r, j)), SN = score pair of the next row, X = this row's diagonal sum, E = E[r]; HOOK = text issued behind the
-//   add (v_perm_b32, loads, waits), SCMAX = the half instruction of the running / column maximum or ""
+//   add (loads, waits), SCMAX = the half instruction of the running / column maximum or ""
 // ---------------------------------------------------------------------------
 #define OSW_TADD_PK(XN, DN, SN) "v_pk_add_i16 " XN ", " DN ", " SN " clamp\n\t"
 #define OSW_TADD_32(XN, DN, SN) "v_add_u32 " XN ", " DN ", " SN "\n\t"
