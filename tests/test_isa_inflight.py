@@ -37,6 +37,12 @@ def test_no_compiler_vmem_between_asm_loads_and_their_waits(isa):
     assert not bad, "compiler-issued vector memory inside an asm load window: %r" % bad[:8]
 
 
+def test_cell_shape(isa):
+    """The single-query kernels pair a lane's two scores with v_pk_mad_i16 (no v_perm_b32 left); b128 profile reads."""
+    bad = isa_check.check_cell_shape(isa)
+    assert not bad, "; ".join(bad)
+
+
 def test_stamp_ties_the_built_library_to_the_checked_sources(isa):
     """The stamp next to liboswald_hip.so names the library built from the sources that have just passed."""
     info = isa_check.stamp()

@@ -144,9 +144,42 @@ def check_vmem_windows(isa, group=GROUPS[0]):
     return bad
 
 
+def check_cell_shape(isa):
+    """The rows of the int16 cells as they are priced: the single-query kernels pair the scores of a lane's two
+    sequences with one v_pk_mad_i16 per row and have no v_perm_b32 left; every int16 kernel reads its profile with
+    ds_read_b128 only and keeps v_pk_maximum3_f16 as its maximum.  -> list of complaints"""
+    counts, fn = {}, None
+    for line in isa:
+        m = re.match(r'^(osw_\w+):', line)
+        if m:
+            fn = m.group(1)
+        if fn not in GROUPS[0]["kernels"] or not line.startswith("\t"):
+            continue
+        op = line.split(";")[0].strip().split(" ")[0]
+        counts.setdefault(fn, {}).setdefault(op, 0)
+        counts[fn][op] += 1
+    bad = []
+    for k in GROUPS[0]["kernels"]:
+        c = counts.get(k, {})
+        single = not k.endswith("q")
+        if c.get("v_perm_b32", 0):
+            bad.append("%s has %d v_perm_b32" % (k, c["v_perm_b32"]))
+        if single and c.get("v_pk_mad_i16", 0) < 300:
+            bad.append("%s has %d v_pk_mad_i16 (one per row of every unrolled strip height expected)" % (k, c.get("v_pk_mad_i16", 0)))
+        if not single and c.get("v_pk_mad_i16", 0):
+            bad.append("%s has %d v_pk_mad_i16 (the query-pair row adds with a 32-bit add)" % (k, c["v_pk_mad_i16"]))
+        if c.get("ds_read_b64", 0) or c.get("ds_read2_b64", 0) or c.get("ds_read_b128", 0) < 100:
+            bad.append("%s reads its profile with %d ds_read_b128, %d ds_read_b64" % (k, c.get("ds_read_b128", 0), c.get("ds_read_b64", 0)))
+        if c.get("v_pk_maximum3_f16", 0) < 1000:
+            bad.append("%s has %d v_pk_maximum3_f16" % (k, c.get("v_pk_maximum3_f16", 0)))
+    return bad
+
+
 def check(isa=None):
-    """All three checks; raises AssertionError with the findings."""
+    """All checks; raises AssertionError with the findings."""
     isa = isa or compile_to_asm()
+    shape = check_cell_shape(isa)
+    assert not shape, "; ".join(shape)
     for group in GROUPS:
         seen, bad = check_inflight_registers(isa, group)
         assert seen > group["min_asm_uses"], "%s: the asm blocks that use the fixed registers were not found" % (group["kernels"],)
@@ -183,7 +216,8 @@ def stamp():
     info = {"library_sha256": sha256_file(LIB), "source_digest": source_digest(), "hipcc": ver[0] if ver else "", "kernels": list(KERNELS),
             "checks": ["in-flight registers untouched by compiler-scheduled code",
                        "; ".join("%s: <= %d VGPRs, <= %d B of scratch outside the column loops" % ("/".join(g["kernels"]), g["budget"], g["scratch"]) for g in GROUPS),
-                       "no compiler-issued vector memory (spill traffic included) inside the asm load windows"]}
+                       "no compiler-issued vector memory (spill traffic included) inside the asm load windows",
+                       "single-query int16 kernels: one v_pk_mad_i16 per row, no v_perm_b32; profile reads are ds_read_b128"]}
     with open(STAMP, "w") as f:
         json.dump(info, f, indent=1)
     return info
