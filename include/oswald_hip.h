@@ -49,7 +49,7 @@ extern "C" {
 #define OSWALD_HIP_ESTATE (-5)   /* call sequence violated (e.g. search before set_queries) */
 #define OSWALD_HIP_ECOMM (-6)    /* an RCCL call failed (multi-GPU top-r gather) */
 
-#define OSWALD_HIP_ABI_VERSION 3
+#define OSWALD_HIP_ABI_VERSION 4
 
 typedef struct oswald_hip_ctx oswald_hip_ctx;
 
@@ -68,6 +68,18 @@ int oswald_hip_device_count(int *count);
  * posix_memalign(AOCL_ALIGNMENT, ...), host/src/sequences.h:15, host/src/FPGAsearch.c:69-74.  Needs a GPU. */
 int oswald_hip_host_alloc(size_t bytes, void **ptr);
 int oswald_hip_host_free(void *ptr);
+
+/* The same for memory the caller already has: page-locks [ptr, ptr + bytes) in place (hipHostRegister), so that uploads
+ * from it are plain asynchronous DMA at the link's rate instead of copies the runtime stages through its own buffers on the
+ * caller's thread (measured on MI355X / PCIe Gen5: ~18 GB/s staged, ~50 GB/s direct).  Meant for a database the caller has
+ * read or mapped as a whole -- the CLI registers its group cache chunk by chunk on a helper thread while the devices are
+ * brought up -- where the reference allocates every chunk buffer 64-byte aligned "for DMA" before its timed region starts
+ * (posix_memalign(AOCL_ALIGNMENT, ...), host/src/sequences.c:470-476, :540-560).  A range is registered once and
+ * unregistered (by its start address) before it is freed or unmapped; both calls need a GPU and may be made from any
+ * thread, also while searches are running.  Read-only mappings cannot be registered on every kernel: on failure the
+ * memory simply stays pageable (uploads from it still work) and the call says why. */
+int oswald_hip_host_register(void *ptr, size_t bytes);
+int oswald_hip_host_unregister(void *ptr);
 
 /* Bring-up: one stream and one buffer set per device; device_ids == NULL means
  * devices 0..ndev-1.  Replaces init(), utils.c:99-173 (platform, context,
@@ -122,11 +134,15 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
 /* The same, without waiting for the device: returns once the copies and the re-tile kernel are queued on the
  * device's UPLOAD stream -- uploads have a stream of their own, so chunk k+1 comes in while chunk k is being
  * searched: queue search k, then upload k+1 (the reference uploads and searches strictly in turn,
- * FPGAsearch.c:180-223).  b / n / disp must stay valid until the chunk has been released
+ * FPGAsearch.c:180-223).  b must stay valid until the chunk has been released (n and disp are copied before the call returns)
  * (oswald_hip_chunk_release waits for the upload; oswald_hip_chunk_search does NOT -- it queues the search behind the
  * upload on the device) or oswald_hip_wait() has returned.  With several
  * devices this is also what lets their uploads overlap: queue all of them, then search each (the reference's four clEnqueueWriteBuffer per device
- * are asynchronous too and share one clFinish per device, FPGAsearch.c:180-198). */
+ * are asynchronous too and share one clFinish per device, FPGAsearch.c:180-198).
+ * A large chunk that arrives while its device has nothing to do -- the first chunk of a search -- is cut by the library into
+ * a HEAD of whole 128-sequence blocks and the REST (two copies, two re-tiles, and later two searches behind one another):
+ * the device starts on the head while the rest is still on the link, instead of waiting for all of it (2.3 ms per 128 MiB).
+ * Nothing of this shows at the boundary: one handle, one score table, one index. */
 int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                                   const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int *chunk);
 
@@ -135,6 +151,15 @@ int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b
  * upload allocates what its chunk needs.  Stands where the reference sizes its device buffers for the largest
  * chunk before the timed region starts (FPGAsearch.c:85-96). */
 int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length);
+
+/* Optional, in the same place: the device buffers of `slots` chunk slots (staging copy, re-tiled residues, block tables,
+ * and -- with nq > 0 -- score table, re-run queue and work queues for a set of nq queries) for chunks of up to chunk_bytes
+ * bytes in ngroups groups of lane_width sequences, on device dev (dev < 0: all), allocated NOW instead of by the first
+ * uploads and searches: mapping device memory costs ~20 ms per GB, which a short search would otherwise pay inside its
+ * timed region.  A hint only: a chunk that needs more grows its slot as before.  The reference creates its six device
+ * buffers, sized for the largest chunk, once per search and re-uses them for every chunk (FPGAsearch.c:85-96). */
+int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t lane_width,
+                              uint32_t nq, uint32_t slots);
 
 /* The largest chunk -- in bytes of b, i.e. padded residues, the unit of the command line's -k -- device dev can hold for
  * a set of nq queries and sequences of up to max_sequence_length residues: 0.8 of its free memory (less the work
@@ -156,8 +181,12 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
  * search of the chunk may still be running -- the next upload into the slot waits for it on the device. */
 int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk);
 
-/* Convenience: upload + search + release in one asynchronous call, the exact
- * per-chunk step of FPGAsearch.c:132-238. */
+/* Convenience: upload + search + release in one ASYNCHRONOUS call, the exact per-chunk step of FPGAsearch.c:132-238:
+ * the copies go out on the device's copy stream, the search is queued behind them on the device, and the call returns
+ * without waiting for either (the reference's four clEnqueueWriteBuffer per device are non-blocking too and share one
+ * clFinish, FPGAsearch.c:180-198) -- with several devices, call it for each of them in turn and their uploads overlap.
+ * b / n / disp and scores_out must stay valid until oswald_hip_wait() has returned for the device; the chunk's slot is
+ * given back then. */
 int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                                   const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int32_t *scores_out);
 
@@ -220,6 +249,10 @@ int oswald_hip_merge_candidates(uint32_t nq, uint64_t ncand, const int32_t *cand
 int oswald_hip_comm_unique_id(void *id, size_t id_bytes);
 int oswald_hip_comm_init_rank(oswald_hip_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank);
 int oswald_hip_comm_info(oswald_hip_ctx *ctx, int *out4);
+/* Gives the process-level communicator up again (ncclCommAbort: no rank waits for another): oswald_hip_topr is a local
+ * call afterwards.  For a job whose ranks could not ALL join -- the ranks that did must not stay in a communicator the
+ * others are not in; every rank calls it (no-op without a communicator) before the job takes another way. */
+int oswald_hip_comm_destroy(oswald_hip_ctx *ctx);
 
 /* Device time spent in the DP kernels since the last reset, measured with HIP
  * events on the device's stream (enabled by oswald_hip_set_profiling). */

@@ -28,6 +28,7 @@ SYMBOLS = (
     "oswald_hip_topr_begin", "oswald_hip_chunk_set_index", "oswald_hip_topr", "oswald_hip_merge_candidates",
     "oswald_hip_comm_unique_id", "oswald_hip_comm_init_rank", "oswald_hip_comm_info", "oswald_hip_max_chunk_size",
     "oswald_hip_host_alloc", "oswald_hip_host_free", "oswald_hip_rerun_stats",
+    "oswald_hip_host_register", "oswald_hip_host_unregister", "oswald_hip_comm_destroy", "oswald_hip_reserve_chunks",
 )
 COMM_ID_BYTES = 128   # OSWALD_HIP_COMM_ID_BYTES
 
@@ -60,6 +61,7 @@ def load():
     lib.oswald_hip_chunk_upload.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, C.POINTER(i32)]
     lib.oswald_hip_chunk_upload_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, C.POINTER(i32)]
     lib.oswald_hip_reserve.argtypes = [vp, i32, u32]
+    lib.oswald_hip_reserve_chunks.argtypes = [vp, i32, u64, u32, u32, u32, u32]
     lib.oswald_hip_rerun_counts.argtypes = [vp, i32, C.POINTER(u64)]
     lib.oswald_hip_chunk_search.argtypes = [vp, i32, i32, vp]
     lib.oswald_hip_chunk_release.argtypes = [vp, i32, i32]
@@ -73,6 +75,9 @@ def load():
     lib.oswald_hip_rerun_stats.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.oswald_hip_host_alloc.argtypes = [sz, C.POINTER(vp)]
     lib.oswald_hip_host_free.argtypes = [vp]
+    lib.oswald_hip_host_register.argtypes = [vp, sz]
+    lib.oswald_hip_host_unregister.argtypes = [vp]
+    lib.oswald_hip_comm_destroy.argtypes = [vp]
     lib.oswald_hip_max_chunk_size.argtypes = [vp, i32, u32, u32, C.POINTER(u64)]
     lib.oswald_hip_comm_unique_id.argtypes = [vp, sz]
     lib.oswald_hip_comm_init_rank.argtypes = [vp, vp, sz, i32, i32]
@@ -136,6 +141,28 @@ def pinned_copy(x: np.ndarray) -> HostBuffer:
     hb = HostBuffer(x.shape, x.dtype)
     hb.a[...] = x
     return hb
+
+
+class Registered:
+    """A numpy array page-locked in place (oswald_hip_host_register) for as long as this object lives: uploads from it are
+    asynchronous DMA.  The array must not be resized or freed meanwhile (a reference is kept)."""
+
+    def __init__(self, a: np.ndarray):
+        assert a.flags.c_contiguous
+        self.a = a
+        self.p = C.c_void_p(a.ctypes.data)
+        _chk(load().oswald_hip_host_register(self.p, a.nbytes))
+
+    def close(self):
+        if self.p:
+            load().oswald_hip_host_unregister(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def comm_unique_id() -> bytes:
@@ -210,6 +237,9 @@ class Context:
     def reserve(self, max_sequence_length: int, dev: int = -1):
         _chk(self.lib.oswald_hip_reserve(self.h, dev, max_sequence_length))
 
+    def reserve_chunks(self, chunk_bytes: int, ngroups: int, lane_width: int = 16, nq: int = 0, slots: int = 3, dev: int = -1):
+        _chk(self.lib.oswald_hip_reserve_chunks(self.h, dev, chunk_bytes, ngroups, lane_width, nq, slots))
+
     def chunk_search(self, chunk: int, out: np.ndarray | None = None, dev: int = 0):
         """Asynchronous; `out` (int32 [nq][ngroups*W]) is valid after wait()."""
         if out is not None:
@@ -263,6 +293,10 @@ class Context:
         assert len(comm_id) >= COMM_ID_BYTES
         buf = C.create_string_buffer(bytes(comm_id), len(comm_id))
         _chk(self.lib.oswald_hip_comm_init_rank(self.h, buf, len(comm_id), nranks, rank))
+
+    def comm_destroy(self):
+        """Gives the process-level communicator up again (every rank, before the job takes another way)."""
+        _chk(self.lib.oswald_hip_comm_destroy(self.h))
 
     def comm_info(self):
         out = (C.c_int * 4)()

@@ -68,6 +68,7 @@ struct Tunables {
     bool plan_waits_for_upload = false; // OSWALD_HIP_PLAN_WAITS=1 (test hook): a search waits for its chunk's upload and plans on the live extents (the behaviour before the second session of round 4)
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
+    size_t split_bytes = 32u << 20;    // OSWALD_HIP_SPLIT_BYTES=bytes: from this size on an asynchronous upload that finds its device idle is cut into head + rest (0: never; a small value: test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 0.95, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5, entries_per_wg = 4.0;
     uint32_t wg_min_cols = 2048, wg_wide_cols = 2048, wg_min_cols_single = 0, wg_wide_cols_single = 0, wg_min_rounds = 0, wg_min_cols_long = 0, two_ended = 0, one_ended_wg = 1, grid_per_cu = 0;
@@ -94,6 +95,7 @@ void Tunables::refresh()
     no_stream_classes = flag("OSWALD_HIP_NO_STREAM_CLASSES");
     no_pin = flag("OSWALD_HIP_NO_PIN");
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
+    split_bytes = (size_t)num("OSWALD_HIP_SPLIT_BYTES", (double)(32u << 20));
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
 #ifdef OSW_DIAG
     pair_margin = num("OSWALD_HIP_PAIR_MARGIN", pair_margin);
@@ -141,7 +143,7 @@ struct HoldTimer {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
         const double ms = std::chrono::duration<double, std::milli>(n - t).count();
-        if (ms > 3.0) fprintf(stderr, "[oswald_hip] the host was held %.1f ms in: %s\n", ms, what);
+        if (ms > 1.0) fprintf(stderr, "[oswald_hip] the host was held %.1f ms in: %s\n", ms, what);
         t = n;
     }
 };
@@ -165,7 +167,42 @@ struct DevBuf {
         cap = want;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
+    // a buffer that is a slice of an Arena (below): owned by the arena, re-assigned with every query set
+    bool view = false;
+    void assign(void *ptr, size_t bytes) { release(); p = ptr; cap = bytes; view = true; }
+};
+
+// Page-locked host memory that only ever grows: the library's own staging of everything small it sends to a device.  Round 5:
+// a small hipMemcpyAsync from PAGEABLE memory (a std::vector, or the caller's n[] / disp[] / index map) issued while a chunk is on
+// the link held the caller for ~9 ms -- the runtime stages such a copy on the caller's thread and waits for it -- so nothing
+// pageable is handed to a copy any more: small inputs are copied (memcpy) into one of these first.
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipHostFree(p); if (e != hipSuccess) { (void)hipGetLastError(); return e; } p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable);
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// One allocation for the many small per-query-set buffers of a device (queries, lengths, offsets, matrix, profiles in every
+// form, constant pages): a slab made at bring-up and cut anew for every query set, so that the first search of a query set
+// -- inside the caller's timed region, like the reference's query upload (FPGAsearch.c:85) -- makes no allocation at all
+// (a hipMalloc maps device memory through the kernel driver, beside whatever upload is in flight; slices of a slab that
+// exists cost nothing).  A set that needs more than the slab holds gets a larger one (one hipMalloc).
+struct Arena {
+    DevBuf slab;
+    size_t used = 0;
+    static size_t up(size_t n) { return (n + 255) & ~(size_t)255; }
+    void *take(size_t bytes) { void *r = (char *)slab.p + used; used += up(bytes); return r; }
 };
 
 struct Chunk {
@@ -175,21 +212,27 @@ struct Chunk {
     uint32_t max_ncols4 = 0;     // largest stored extent of a block
     uint64_t total_col4 = 0;     // stored 4-column groups incl. the pad group per block
     DevBuf tiled, blocks, sub_cols_buf, scores, ovf, ovf8;
-    // The work queues, two sets in turn: a plan goes to the device on the copy stream AT ONCE, and since a search is planned
-    // while its chunk's upload is still on its way, the search of the slot's previous chunk may still be running -- and reading
-    // the set the plan before this one was copied into.  (The set before that is free: a slot is re-used only after
-    // oswald_hip_chunk_release, which returns when the released chunk's upload has landed, i.e. after the search of the chunk
-    // before it.)
-    DevBuf items_buf[2], items_q_buf[2];
-    int items_cur = 0;
-    // ... and their page-locked sources, so that the copy is asynchronous and the host never waits for the copy stream (whatever
-    // holds it: with a slot re-used beside a running search the plan's copy has been seen to wait for that search, 110 ms);
-    // the launches of the search wait for ev_items on the device instead
+    // The work queues, two sets in turn, in PAGE-LOCKED HOST memory that the kernels read in place (a wave fetches one 8-byte
+    // entry per work item over the link: microseconds against items of 0.1 - 10 ms).  Round 4 copied every plan to the device on
+    // the copy stream; there the few hundred KB queued BEHIND the bulk copies of the chunks coming in, and the first search of a
+    // pass -- the head of a chunk cut in two, whose rest is on the link -- waited 1.4 ms for its queues (round 5,
+    // profiles/r05_inclusive_probe_q1.txt).  Two sets: a search is planned while its chunk's upload is still on its way, and the
+    // search of the slot's previous chunk may still be running -- and pulling from the set the plan before this one was written to.
+    // (The set before that is free: a slot is re-used only after oswald_hip_chunk_release, which returns when the released chunk's
+    // upload has landed, i.e. after the search of the chunk before it.)
     uint2 *items_pin[2] = {nullptr, nullptr};
     size_t items_pin_cap[2] = {0, 0};   // entries (both queues, one behind the other)
-    hipEvent_t ev_items = nullptr;
-    DevBuf &items_dev() { return items_buf[items_cur]; }
-    DevBuf &items_q_dev() { return items_q_buf[items_cur]; }
+    size_t items_q_off[2] = {0, 0};     // where the query-pair kernel's queue starts in the set
+    int items_cur = 0;
+    // ... and who read a set last: recorded on the search stream behind the launches that pull from it.  A plan that is about to
+    // overwrite a set waits for its last reader on the host (with one plan per residency that reader is long gone, but
+    // a resident chunk searched twice in a row and re-planned in between came back to a set a running search was still pulling
+    // from); build_items also keeps an estimate plan while a search of the chunk is pending, so the wait is never met on the
+    // pipelined path.
+    hipEvent_t ev_set_read[2] = {nullptr, nullptr};
+    bool set_read_pending[2] = {false, false};
+    const uint2 *items_ptr() const { return items_pin[items_cur]; }
+    const uint2 *items_q_ptr() const { return items_pin[items_cur] + items_q_off[items_cur]; }
     const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     // host copy of the live extents (see osw_retile16 / osw_block_extent), for the planner: PAGE-LOCKED, so that the copy
@@ -207,8 +250,9 @@ struct Chunk {
     std::vector<OswBlock> blocks_host;  // the block table as planned on the host ...
     OswBlock *blocks_pin = nullptr;     // ... and its page-locked copy, the source of the asynchronous upload
     size_t blocks_pin_cap = 0;
-    DevBuf st_b, st_n, st_disp;         // the caller's arrays as they arrive on the device (the re-tile kernel's input): per slot,
+    DevBuf st_b;                        // the caller's residues as they arrive on the device (the re-tile kernel's input): per slot,
                                         // so that the copies of the next upload never wait for a re-tile that has not found room yet
+    PinBuf nd_pin;                      // the caller's n[] and disp[], copied at the upload call; the re-tile kernel reads them in place
     hipEvent_t ev_copy = nullptr;       // recorded on the copy stream behind them
     hipEvent_t ev_down = nullptr;       // recorded on the download stream behind the copy of the chunk's score table to the caller ...
     bool down_pending = false;          // ... which the next search that writes the slot's table must wait for
@@ -228,15 +272,25 @@ struct Chunk {
     // index_map[k] if a map was given, else first_index + k; nvalid real sequences
     bool has_index = false;
     uint32_t first_index = 0, nvalid = 0;
-    std::shared_ptr<const std::vector<uint32_t>> index_map; // host copy: source of the (asynchronous) upload below
+    bool index_map = false;             // the chunk has a map
     // the index map on the device: two buffers in turn (a slot re-used while its last search -- which reads the old map --
-    // is still running gets the other one), copied on the DMA-only copy stream (a copy queued on the search stream would
-    // hold the caller until the running search is over: the host copy is pageable); ev_map: the copy has landed
+    // is still running gets the other one), copied on the DMA-only copy stream from a page-locked copy of the caller's map
+    // (map_pin, two in turn like their targets); ev_map[k]: the copy of buffer k has landed
     DevBuf index_map_dev[2];
+    PinBuf map_pin[2];
     int map_cur = 0;
     bool map_pending = false;
-    hipEvent_t ev_map = nullptr;
+    hipEvent_t ev_map[2] = {nullptr, nullptr};
+    // A chunk the library cut in two at its upload (oswald_hip_chunk_upload_async on an idle device): the caller's handle is
+    // the HEAD's slot, `next` the slot of the REST (groups head_groups .. of the caller's arrays), which no handle names.
+    // Every per-chunk entry point walks the chain.
+    int next = -1;
+    bool is_cont = false;               // this slot is the rest of another slot's chunk
 };
+
+// Slots a device keeps at most before an upload GROWS the largest free one instead of opening another: three resident chunks
+// (one searched, two coming in) and the two pieces of a first chunk cut at its upload.
+#define OSW_MAX_SLOTS 5
 
 struct EventPair { hipEvent_t a, b, c, d; bool c_used; }; // a..b: all DP launches of a chunk search; c..d: the int16 re-run of the 8-bit pass (c_used); d..b: the int32 re-run
 
@@ -249,13 +303,16 @@ struct Device {
     hipStream_t stream_down = nullptr; // score tables on their way to the caller, beside the next chunk's search
     uint64_t up_seq = 0;             // uploads queued so far
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_mark = nullptr;    // OSWALD_HIP_DEBUG_SLOW: "the first upload of a pass was issued" (reference point of the device's time line)
+    bool mark_set = false;
     hipDeviceProp_t prop;
     uint32_t grid = 0;               // persistent workgroups per launch
     uint32_t grid_q8 = 0;            // ... of the 8-bit kernel (more workgroups per CU; at most 2 x grid: it runs alone and may use both halves of the spill scratch)
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_seq, prof_seq_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters;
     DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
-    std::vector<uint32_t> top_pages_host; // source of the asynchronous upload of top_pages
-    std::vector<std::shared_ptr<const std::vector<uint32_t>>> retired_maps; // index maps of re-used slots whose upload may still be queued
+    Arena qset;                           // what the buffers of the current query set (queries ... top_pages, prof_pair8) are slices of
+    uint8_t *qstage = nullptr;            // page-locked: the small inputs of the query set as the arena holds them, read in place by the copy kernel
+    size_t qstage_cap = 0;
     std::vector<void *> registered;  // caller score tables pinned for an in-flight download (released at the next wait)
     uint64_t bnd_stride = 0;         // spill columns x lanes ({H,F} entries) per wave slot, behind the slot's zero and trash pages
     uint64_t queries_version = ~0ull; // what is currently uploaded
@@ -350,20 +407,70 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     if (!ctx->have_scoring) return fail(OSWALD_HIP_ESTATE, "oswald_hip_set_scoring has not been called");
     if (!ctx->have_queries) return fail(OSWALD_HIP_ESTATE, "oswald_hip_set_queries has not been called");
     if (d.queries_version == ctx->queries_version && d.scoring_version == ctx->scoring_version) return 0;
-    HIP_TRY(hipStreamSynchronize(d.stream)); // a call that failed half-way may have left copies from the host arrays queued
+    HoldTimer ht(g_debug_slow);
+    // the searches of the query set before this one are through (they read the arena and, before it, the staging buffer)
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    ht.lap("queries: wait for the stream");
     const uint32_t nq = ctx->nq;
-    HIP_TRY(d.queries.reserve(ctx->a.size() + 16));
-    HIP_TRY(d.qlen.reserve(nq * sizeof(uint16_t) + 16));
-    HIP_TRY(d.a_disp.reserve((nq + 1) * sizeof(uint32_t)));
-    HIP_TRY(d.prof_off.reserve((nq + 1) * sizeof(uint32_t)));
-    HIP_TRY(d.submat.reserve(24 * 32));
-    HIP_TRY(d.prof.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
-    HIP_TRY(d.prof_seq.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096));
-    if (!ctx->a.empty()) HIP_TRY(hipMemcpyAsync(d.queries.p, ctx->a.data(), ctx->a.size(), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(hipMemcpyAsync(d.qlen.p, ctx->m.data(), nq * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(hipMemcpyAsync(d.a_disp.p, ctx->a_disp.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(hipMemcpyAsync(d.prof_off.p, ctx->prof_off.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(hipMemcpyAsync(d.submat.p, ctx->submat, 24 * 32, hipMemcpyHostToDevice, d.stream));
+    // Every buffer of the query set is a slice of the device's arena (see Arena): sizes first, one slab, then the slices.  The
+    // small INPUTS come first, in one run: they are put together in a page-locked staging buffer with the same offsets and
+    // brought over by ONE kernel that reads the staging buffer in place -- no copy engine, nothing pageable: round 5 found the
+    // six little hipMemcpyAsync from the context's std::vectors holding the caller for 8.6 ms of a 25-ms search (the runtime
+    // stages a pageable copy on the caller's thread, and the copy engine was busy with the chunk coming in).
+    const bool alt_ = first_pass_is_frame(ctx), q8_ = first_pass_is_q8(ctx);
+    const uint32_t np_ = (uint32_t)ctx->pair_len.size();
+    const size_t prof8 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096, prof16 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096;
+    const size_t pair16 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096, pair8 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint2) + 4096;
+    const size_t pages_bytes = (size_t)(128 + OSW_I16S_TABLE + 64) * 2 * sizeof(uint32_t);
+    struct Slice { DevBuf *buf; size_t bytes; const void *src; size_t src_bytes; };
+    const Slice slices[] = {// inputs (src: what the staging buffer holds at the slice's offset; top_pages is generated in place below)
+                            {&d.queries, ctx->a.size() + 16, ctx->a.data(), ctx->a.size()},
+                            {&d.qlen, nq * sizeof(uint16_t) + 16, ctx->m.data(), nq * sizeof(uint16_t)},
+                            {&d.a_disp, (nq + 1) * sizeof(uint32_t), ctx->a_disp.data(), nq * sizeof(uint32_t)},
+                            {&d.prof_off, (nq + 1) * sizeof(uint32_t), ctx->prof_off.data(), nq * sizeof(uint32_t)},
+                            {&d.submat, 24 * 32, ctx->submat, 24 * 32},
+                            {&d.pair_q, np_ ? 2 * np_ * sizeof(uint32_t) : 0, ctx->pair_q.data(), 2 * np_ * sizeof(uint32_t)},
+                            {&d.pair_off, np_ ? np_ * sizeof(uint32_t) : 0, ctx->pair_off.data(), np_ * sizeof(uint32_t)},
+                            {&d.pair_len, np_ ? np_ * sizeof(uint16_t) + 16 : 0, ctx->pair_len.data(), np_ * sizeof(uint16_t)},
+                            {&d.top_pages, pages_bytes, nullptr, 0},
+                            // built on the device
+                            {&d.prof, prof8, nullptr, 0}, {&d.prof_seq, prof16, nullptr, 0}, {&d.prof_alt, alt_ ? prof8 : 0, nullptr, 0}, {&d.prof_seq_alt, alt_ ? prof16 : 0, nullptr, 0},
+                            {&d.prof_pair, np_ ? pair16 : 0, nullptr, 0}, {&d.prof_pair8, np_ && q8_ ? pair8 : 0, nullptr, 0}, {&d.prof_pair_i16, np_ && alt_ ? pair16 : 0, nullptr, 0}};
+    constexpr size_t kInputs = 9;
+    size_t total = 0, inputs_bytes = 0;
+    for (size_t i = 0; i < sizeof slices / sizeof slices[0]; ++i) { total += Arena::up(slices[i].bytes); if (i + 1 == kInputs) inputs_bytes = total; }
+    if (total > d.qset.slab.cap) {
+        for (const Slice &sl : slices) sl.buf->release(); // (views into the old slab)
+        HIP_TRY(d.qset.slab.reserve(total + total / 2));
+    }
+    if (inputs_bytes > d.qstage_cap) {
+        if (d.qstage) HIP_TRY(hipHostFree(d.qstage));
+        d.qstage = nullptr;
+        d.qstage_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&d.qstage, inputs_bytes + inputs_bytes / 2, hipHostMallocPortable));
+        d.qstage_cap = inputs_bytes + inputs_bytes / 2;
+    }
+    d.qset.used = 0;
+    memset(d.qstage, 0, inputs_bytes);
+    uint32_t *pages = nullptr;
+    for (const Slice &sl : slices) {
+        const size_t off = d.qset.used;
+        if (sl.bytes) sl.buf->assign(d.qset.take(sl.bytes), sl.bytes); else sl.buf->release();
+        if (sl.src && sl.src_bytes) memcpy(d.qstage + off, sl.src, sl.src_bytes);
+        if (sl.buf == &d.top_pages) pages = (uint32_t *)(d.qstage + off);
+    }
+    // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
+    // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern), then 64 entries of the 8-bit
+    // cell's "zero": its offset c in every byte (q8_cell.h)
+    for (size_t i = 64; i < 128; ++i) pages[2 * i] = pages[2 * i + 1] = 0x04000400u;
+    if (q8_)
+        for (size_t i = 128 + OSW_I16S_TABLE; i < 128 + OSW_I16S_TABLE + 64; ++i) pages[2 * i] = pages[2 * i + 1] = (uint32_t)offset8_of(ctx) * 0x01010101u;
+    for (size_t k = 0; k < OSW_I16S_TABLE; ++k) {
+        const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
+        pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);
+    }
+    ht.lap("queries: buffers and staging");
+    HIP_TRY(osw_launch_copy16(d.qstage, d.qset.slab.p, inputs_bytes, d.stream));
     // plain integer profile: the exact int32 kernel and the pair profiles read `prof`, the plain single-query int16 cell `prof_seq`
     HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                      (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
@@ -371,53 +478,29 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     // the column-frame int16 cell reads S + ge
     const bool alt = first_pass_is_frame(ctx);
     if (alt) {
-        HIP_TRY(d.prof_alt.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096));
-        HIP_TRY(d.prof_seq_alt.reserve((size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096));
         HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                          (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
                                          ctx->extend_gap, (uint2 *)d.prof_alt.p, (uint4 *)d.prof_seq_alt.p, d.stream));
     }
-    // constant "row above a first round": 64 {H,F} entries of zeros, 64 of the biased-int16 floor (1024), then the
-    // column-frame cell's floor table, entry k = 1024 + k * ge (capped below the fp16 inf pattern), then the 8-bit cell's page.  Uploaded on the
-    // device's stream like everything else here (ordered behind a search still in flight).
-    std::vector<uint32_t> &pages = d.top_pages_host; // a member: an early return must not free the source of a queued copy
-    pages.assign((128 + OSW_I16S_TABLE + 64) * 2, 0u);
-    for (size_t i = 64; i < 128; ++i) pages[2 * i] = pages[2 * i + 1] = 0x04000400u;
-    // ... and behind the table 64 entries of the 8-bit cell's "zero": its offset c in every byte (q8_cell.h)
-    if (first_pass_is_q8(ctx))
-        for (size_t i = 128 + OSW_I16S_TABLE; i < 128 + OSW_I16S_TABLE + 64; ++i) pages[2 * i] = pages[2 * i + 1] = (uint32_t)offset8_of(ctx) * 0x01010101u;
-    for (size_t k = 0; k < OSW_I16S_TABLE; ++k) {
-        const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
-        pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);
-    }
-    HIP_TRY(d.top_pages.reserve(pages.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpyAsync(d.top_pages.p, pages.data(), pages.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     const uint32_t np = (uint32_t)ctx->pair_len.size();
     if (np > 0) {
-        HIP_TRY(d.pair_q.reserve(2 * np * sizeof(uint32_t)));
-        HIP_TRY(d.pair_off.reserve(np * sizeof(uint32_t)));
-        HIP_TRY(d.pair_len.reserve(np * sizeof(uint16_t) + 16));
-        HIP_TRY(d.prof_pair.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096));
-        HIP_TRY(hipMemcpyAsync(d.pair_q.p, ctx->pair_q.data(), 2 * np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(d.pair_off.p, ctx->pair_off.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(d.pair_len.p, ctx->pair_len.data(), np * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(osw_launch_build_pair_profile((const uint2 *)(alt ? d.prof_alt.p : d.prof.p), (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                               (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
                                               ctx->pair_max_rowblocks, alt /* column-frame pair cell: 32-bit integer sums */, (uint4 *)d.prof_pair.p, d.stream));
         if (first_pass_is_q8(ctx)) {
-            HIP_TRY(d.prof_pair8.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint2) + 4096));
             HIP_TRY(osw_launch_build_pair_profile8((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                                    (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
                                                    ctx->pair_max_rowblocks, bias8_of(ctx), (uint2 *)d.prof_pair8.p, d.stream));
         }
         if (alt) { // plain int16 pair profile for the items the first-pass cell hands to the plain cell
-            HIP_TRY(d.prof_pair_i16.reserve((size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096));
             HIP_TRY(osw_launch_build_pair_profile((const uint2 *)d.prof.p, (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
                                                   (const uint32_t *)d.pair_q.p, (const uint32_t *)d.pair_off.p, (const uint16_t *)d.pair_len.p, np,
                                                   ctx->pair_max_rowblocks, false, (uint4 *)d.prof_pair_i16.p, d.stream));
         }
     }
-    HIP_TRY(hipStreamSynchronize(d.stream)); // host vectors may change after return
+    // (nothing here waits for the device: the kernels read the staging buffer, which is this device's own and is written again
+    // only behind the stream synchronisation at the top; the context's vectors may change as soon as this returns)
+    ht.lap("queries: staging copy and profile kernels queued");
     d.queries_version = ctx->queries_version;
     d.scoring_version = ctx->scoring_version;
     return 0;
@@ -431,7 +514,6 @@ void release_registered(Device &d)
 {
     for (void *p : d.registered) (void)hipHostUnregister(p);
     d.registered.clear();
-    d.retired_maps.clear();
 }
 
 // Strip-boundary spill scratch: one region per resident wave and launch (two launches run side by side), every region
@@ -476,12 +558,16 @@ void drain_events(Device &d)
 {
     if (g_debug_slow && d.ev_used.size() > 1) { // (OSWALD_HIP_DEBUG_SLOW: how the searches of a pass lie on the device's time line)
         for (size_t k = 0; k < d.ev_used.size(); ++k) {
-            float dur = 0, gap = 0;
+            float dur = 0, gap = 0, since = 0;
+            if (k == 0 && d.mark_set && hipEventElapsedTime(&since, d.ev_mark, d.ev_used[0].a) == hipSuccess)
+                fprintf(stderr, "[oswald_hip] search 0 started on the device %.3f ms after the pass's first upload was issued\n", since);
+            (void)hipGetLastError();
             (void)hipEventElapsedTime(&dur, d.ev_used[k].a, d.ev_used[k].b);
             if (k + 1 < d.ev_used.size()) (void)hipEventElapsedTime(&gap, d.ev_used[k].b, d.ev_used[k + 1].a);
             fprintf(stderr, "[oswald_hip] search %zu: %.3f ms on the device, %.3f ms to the next search's start\n", k, dur, gap);
         }
     }
+    d.mark_set = false;
     for (auto &e : d.ev_used) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { d.dp_ms += ms; d.dp_launches++; }
@@ -515,7 +601,7 @@ int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     if (c.nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "chunk index: nvalid %u exceeds the chunk's %u lanes", c.nvalid, c.ngroups * c.W);
     if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0 || c.nvalid == 0) return 0; // nothing was searched: nothing to add
     if (!d.top_run[0].p || !d.top_run[1].p) return fail(OSWALD_HIP_ESTATE, "oswald_hip_topr_begin has not prepared device %d", d.id);
-    if (c.map_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_map, 0)); c.map_pending = false; } // the chunk's index map has landed
+    if (c.map_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_map[c.map_cur], 0)); c.map_pending = false; } // the chunk's index map has landed
     HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * osw_topr_parts(c.nvalid) * r * sizeof(unsigned long long)));
     HIP_TRY(osw_launch_topr_fold_chunk((const int32_t *)c.scores.p, c.score_stride, c.nvalid, r, ctx->nq,
                                        c.index_map ? (const uint32_t *)c.index_map_dev[c.map_cur].p : nullptr, c.first_index, (unsigned long long *)d.topr_cand.p,
@@ -567,6 +653,27 @@ int oswald_hip_host_free(void *ptr)
     return 0;
 }
 
+// Page-locks memory the caller already has (a mapped or loaded database): uploads from it are asynchronous DMA.
+int oswald_hip_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0) return fail(OSWALD_HIP_EINVAL, "nothing to register");
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? OSWALD_HIP_ENOMEM : OSWALD_HIP_ERUNTIME, "hipHostRegister(%p, %zu bytes): %s (the memory stays pageable; uploads from it still work)", ptr, bytes,
+                    hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int oswald_hip_host_unregister(void *ptr)
+{
+    if (!ptr) return 0;
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(OSWALD_HIP_ERUNTIME, "hipHostUnregister(%p): %s", ptr, hipGetErrorString(e)); }
+    return 0;
+}
+
 int oswald_hip_device_count(int *count)
 {
     if (!count) return fail(OSWALD_HIP_EINVAL, "count is null");
@@ -589,6 +696,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
     oswald_hip_ctx *ctx = new (std::nothrow) oswald_hip_ctx;
     if (!ctx) return fail(OSWALD_HIP_ENOMEM, "out of host memory");
     ctx->tun.refresh();
+    ctx->profiling = g_debug_slow; // (OSWALD_HIP_DEBUG_SLOW: the device's time line of every pass, see drain_events)
     ctx->dev.resize(ndev);
     for (int i = 0; i < ndev; ++i) {
         Device &d = ctx->dev[i];
@@ -624,7 +732,8 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
         int per_cu8 = 0;
         if (osw_occupancy_q8(&per_cu8) != (int)hipSuccess || per_cu8 < 1) per_cu8 = per_cu;
         d.grid_q8 = std::min<uint32_t>(2 * d.grid, (uint32_t)d.prop.multiProcessorCount * (uint32_t)per_cu8);
-        r = d.counters.reserve((OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
+        r = d.qset.slab.reserve(16u << 20); // the query sets' arena: the BASELINE set needs 8 MB
+        if (r == hipSuccess) r = d.counters.reserve((OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
         // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
@@ -652,6 +761,8 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             if (r == hipSuccess) r = osw_launch_i32(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_i32r(a, 8, d.stream);
             if (r == hipSuccess) r = osw_launch_q8(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_warm_aux_kernels(d.stream);
+            if (r == hipSuccess) r = osw_launch_copy16(nullptr, nullptr, 0, d.stream_up);
             if (r == hipSuccess) r = hipStreamSynchronize(d.stream);
             scratch.release();
             if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ERUNTIME, "warm-up of device %d failed: %s", d.id, hipGetErrorString(r)); }
@@ -698,24 +809,27 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
             c.ev_down = nullptr;
             if (c.sub_cols) (void)hipHostFree(c.sub_cols);
             for (int k = 0; k < 2; ++k) { if (c.items_pin[k]) (void)hipHostFree(c.items_pin[k]); c.items_pin[k] = nullptr; c.items_pin_cap[k] = 0; }
-            if (c.ev_items) (void)hipEventDestroy(c.ev_items);
-            c.ev_items = nullptr;
+            for (int k = 0; k < 2; ++k) { if (c.ev_set_read[k]) (void)hipEventDestroy(c.ev_set_read[k]); c.ev_set_read[k] = nullptr; c.set_read_pending[k] = false; }
             if (c.blocks_pin) (void)hipHostFree(c.blocks_pin);
             c.ev_up = c.ev_use = c.ev_copy = nullptr;
             c.sub_cols = nullptr;
             c.sub_cols_cap = 0;
             c.blocks_pin = nullptr;
             c.blocks_pin_cap = 0;
-            c.st_b.release(); c.st_n.release(); c.st_disp.release();
+            c.st_b.release(); c.nd_pin.release(); c.map_pin[0].release(); c.map_pin[1].release();
         }
         if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); for (int k = 0; k < 2; ++k) { c.items_buf[k].release(); c.items_q_buf[k].release(); } c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); if (c.ev_map) (void)hipEventDestroy(c.ev_map); c.ev_map = nullptr; }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; } }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_seq, &d.prof_seq_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
                           &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
             b->release();
+        d.qset.slab.release();
+        if (d.qstage) (void)hipHostFree(d.qstage);
+        d.qstage = nullptr;
         if (d.ev_top) (void)hipEventDestroy(d.ev_top);
+        if (d.ev_mark) (void)hipEventDestroy(d.ev_mark);
         drain_events(d);
         for (auto &e : d.ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); (void)hipEventDestroy(e.c); (void)hipEventDestroy(e.d); }
         if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
@@ -733,8 +847,11 @@ int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen)
     if (int r = check_dev(ctx, dev)) return r;
     if (!buf || buflen == 0) return fail(OSWALD_HIP_EINVAL, "buffer is null");
     const Device &d = ctx->dev[dev];
+    char bus[32] = "unknown";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, d.id) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "unknown"); }
     snprintf(buf, buflen,
              "Device %d: %s (%s)\n"
+             "  PCI bus id:               %s\n"
              "  compute units:            %d\n"
              "  max clock:                %d MHz\n"
              "  global memory:            %zu MiB\n"
@@ -742,7 +859,7 @@ int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen)
              "  wavefront size:           %d\n"
              "  L2 cache:                 %d KiB\n"
              "  persistent workgroups:    %u x %d threads\n",
-             d.id, d.prop.name, d.prop.gcnArchName, d.prop.multiProcessorCount, d.prop.clockRate / 1000,
+             d.id, d.prop.name, d.prop.gcnArchName, bus, d.prop.multiProcessorCount, d.prop.clockRate / 1000,
              d.prop.totalGlobalMem >> 20, d.prop.sharedMemPerBlock >> 10, d.prop.warpSize, d.prop.l2CacheSize >> 10, d.grid,
              OSW_WG_THREADS);
     return 0;
@@ -805,30 +922,35 @@ int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, co
     return 0;
 }
 
-static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
-                             uint32_t ngroups, uint32_t W, int *chunk, bool async)
+// One slot's worth of an upload: groups [0, ngroups) of the arrays given, whose displacements are `disp_bias` too large (the
+// rest of a chunk the library cut in two keeps the caller's displacement table: its bytes start at b, its table at the entry
+// of its first group, and the device-side base pointer is moved back by the bias instead of the table being rebased).
+// -> the slot's index in *slot_out.
+static int upload_slot(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp, uint32_t disp_bias,
+                       uint32_t ngroups, uint32_t W, int *slot_out)
 {
-    if (int r = check_dev(ctx, dev)) return r;
-    if (!chunk) return fail(OSWALD_HIP_EINVAL, "chunk out-pointer is null");
-    if (W != 16 && W != 32 && W != 64 && W != 128) return fail(OSWALD_HIP_EINVAL, "lane_width must be 16, 32, 64 or 128");
-    if (ngroups > 0 && (!b || !n || !disp)) return fail(OSWALD_HIP_EINVAL, "null chunk arrays");
     for (uint32_t g = 0; g < ngroups; ++g)
-        if ((uint64_t)disp[g] + (uint64_t)n[g] * W > vD)
-            return fail(OSWALD_HIP_EINVAL, "group %u runs past the chunk (disp %u + %u*%u > %llu)", g, disp[g], n[g], W, (unsigned long long)vD);
+        if (disp[g] < disp_bias || (uint64_t)(disp[g] - disp_bias) + (uint64_t)n[g] * W > vD)
+            return fail(OSWALD_HIP_EINVAL, "group %u runs past the chunk (disp %u + %u*%u > %llu)", g, disp[g] - disp_bias, n[g], W, (unsigned long long)vD);
     Device &d = ctx->dev[dev];
-    HIP_TRY(hipSetDevice(d.id));
-    // A free slot whose buffers are large enough already (the smallest such), else a new one: growing a buffer frees the
-    // old one, and hipFree waits for the device -- i.e. for whatever search is running beside this upload.
-    int slot = -1;
+    // A free slot whose buffers are large enough already (the smallest such), else -- before a new one is opened -- the
+    // LARGEST free slot, which then grows: oswald_hip_max_chunk_size reckons with three resident chunks per device (four slots
+    // with a first chunk cut in two), and slots are never given back before finalize.  Growing a buffer frees the
+    // old one, and hipFree waits for the device -- i.e. for whatever search is running beside this upload: a device gets there
+    // only when its caller sends chunks of growing size.
+    const size_t need_scores = (size_t)ctx->nq * ((ngroups + OSW_BLOCK_SEQS / W - 1) / (OSW_BLOCK_SEQS / W)) * OSW_BLOCK_SEQS * sizeof(int32_t);
+    int slot = -1, largest_free = -1;
     for (size_t i = 0; i < d.chunks.size(); ++i) {
         const Chunk &k = d.chunks[i];
-        if (k.live || k.upload_pending || k.st_b.cap < vD + 64) continue;
-        const size_t need_scores = (size_t)ctx->nq * ((ngroups + OSW_BLOCK_SEQS / W - 1) / (OSW_BLOCK_SEQS / W)) * OSW_BLOCK_SEQS * sizeof(int32_t);
+        if (k.live || k.upload_pending) continue;
+        if (k.st_b.p && (largest_free < 0 || k.st_b.cap > d.chunks[largest_free].st_b.cap)) largest_free = (int)i;
+        if (k.st_b.cap < vD + 64) continue;
         if (k.scores.cap && k.scores.cap < need_scores + 16) continue; // (its score table and re-run queues would have to grow too)
         if (slot < 0 || k.st_b.cap < d.chunks[slot].st_b.cap) slot = (int)i;
     }
     if (slot < 0)
         for (size_t i = 0; i < d.chunks.size(); ++i) if (!d.chunks[i].live && !d.chunks[i].upload_pending && !d.chunks[i].st_b.p) { slot = (int)i; break; } // (never used)
+    if (slot < 0 && largest_free >= 0 && d.chunks.size() >= OSW_MAX_SLOTS) slot = largest_free; // grows below
     if (slot < 0) { d.chunks.emplace_back(); slot = (int)d.chunks.size() - 1; }
     Chunk &c = d.chunks[slot];
     PhaseTimer pt(ctx->tun.debug_phases);
@@ -838,6 +960,8 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     c.nblocks = (ngroups + gpb - 1) / gpb;
     c.score_stride = c.nblocks * OSW_BLOCK_SEQS;
     c.ncols4_alloc.assign(c.nblocks, 0);
+    c.next = -1;
+    c.is_cont = false;
     std::vector<OswBlock> &blocks = c.blocks_host; // (a member: oswald_hip_chunk_upload_async returns before the copy has run)
     blocks.assign(c.nblocks, OswBlock{});
     uint64_t off = OSW_TILED_PAD_GROUPS; // all-dummy columns in front of the first block
@@ -864,13 +988,11 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
             const uint32_t g = B * gpb + (2 * l) / W;
             lane_n[l] = g < ngroups ? n[g] : 0;
         }
+        // entry (G - 1) + sigma = the longest lane of sub-block sigma at geometry G: a binary heap over the 64 lanes, filled
+        // from the leaves (G = 64: entries 63 .. 126) up -- entry t covers the entries 2t + 1 and 2t + 2
         uint16_t *e = c.sub_cols_est.data() + (size_t)B * 128;
-        for (uint32_t t = 0; t < 127; ++t) {
-            const uint32_t lg = 31u - (uint32_t)__builtin_clz(t + 1u), sigma = t + 1u - (1u << lg), gl = 64u >> lg;
-            uint16_t mx = 0;
-            for (uint32_t k = 0; k < gl; ++k) mx = std::max(mx, lane_n[sigma * gl + k]);
-            e[t] = mx;
-        }
+        for (uint32_t l = 0; l < 64; ++l) e[63 + l] = lane_n[l];
+        for (int t = 62; t >= 0; --t) e[t] = std::max(e[2 * t + 1], e[2 * t + 2]);
     }
     if (int r = ensure_scratch(d, c.max_ncols4 * 4)) return r;
     HIP_TRY(c.tiled.reserve((off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2)));
@@ -885,8 +1007,9 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
         c.sub_cols_cap = want;
     }
     HIP_TRY(c.st_b.reserve(vD + 64));
-    HIP_TRY(c.st_n.reserve(ngroups * sizeof(uint16_t) + 16));
-    HIP_TRY(c.st_disp.reserve(ngroups * sizeof(uint32_t) + 16));
+    const size_t disp_off = ((size_t)ngroups * sizeof(uint16_t) + 63) & ~(size_t)63;
+    HIP_TRY(c.nd_pin.reserve(disp_off + (size_t)ngroups * sizeof(uint32_t) + 64));
+    if (ngroups) { memcpy(c.nd_pin.p, n, (size_t)ngroups * sizeof(uint16_t)); memcpy((char *)c.nd_pin.p + disp_off, disp, (size_t)ngroups * sizeof(uint32_t)); }
     if (c.nblocks > c.blocks_pin_cap) {
         if (c.blocks_pin) HIP_TRY(hipHostFree(c.blocks_pin));
         c.blocks_pin = nullptr;
@@ -910,33 +1033,115 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     // (oswald_hip_search_chunk_async, or a release right behind a search): the upload stream waits for that search.
     hipStream_t up = d.stream_up;
     if (c.use_pending) { HIP_TRY(hipStreamWaitEvent(up, c.ev_use, 0)); c.use_pending = false; }
+    if (g_debug_slow && !d.mark_set) {
+        if (!d.ev_mark) HIP_TRY(hipEventCreate(&d.ev_mark));
+        HIP_TRY(hipEventRecord(d.ev_mark, d.stream_copy));
+        d.mark_set = true;
+    }
+    HoldTimer ht(g_debug_slow);
     if (ngroups > 0) {
         HIP_TRY(hipMemcpyAsync(c.st_b.p, b, vD, hipMemcpyHostToDevice, d.stream_copy));
-        HIP_TRY(hipMemcpyAsync(c.st_n.p, n, ngroups * sizeof(uint16_t), hipMemcpyHostToDevice, d.stream_copy));
-        HIP_TRY(hipMemcpyAsync(c.st_disp.p, disp, ngroups * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream_copy));
+        ht.lap("upload: copy of the residues queued");
         HIP_TRY(hipEventRecord(c.ev_copy, d.stream_copy));
+        ht.lap("upload: event behind the copy recorded");
         HIP_TRY(hipStreamWaitEvent(up, c.ev_copy, 0));
-        HIP_TRY(hipMemcpyAsync(c.blocks.p, c.blocks_pin, c.nblocks * sizeof(OswBlock), hipMemcpyHostToDevice, up));
+        ht.lap("upload: upload stream made to wait for the copy");
+        // (the block table comes over by a kernel that reads its page-locked source in place, and the live extents go back the same
+        // way: the upload stream carries kernels only.  Round 5: a small hipMemcpyAsync on this stream -- behind a re-tile that is
+        // waiting for a wave slot -- held the caller for 7 - 9 ms in a process's first pass)
+        HIP_TRY(osw_launch_copy16(c.blocks_pin, c.blocks.p, c.nblocks * sizeof(OswBlock), up));
+        ht.lap("upload: block table queued");
         HIP_TRY(osw_launch_fill(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), up)); // pads = dummy residue
-        HIP_TRY(osw_launch_retile((const uint8_t *)c.st_b.p, (const uint16_t *)c.st_n.p, (const uint32_t *)c.st_disp.p,
+        ht.lap("upload: fill queued");
+        // (the base pointer moved back by the bias: base + disp[g] is the group's place in the staging copy)
+        // (n[] and disp[] are read where they are: the slot's page-locked copy)
+        HIP_TRY(osw_launch_retile((const uint8_t *)c.st_b.p - disp_bias, (const uint16_t *)c.nd_pin.p, (const uint32_t *)((const char *)c.nd_pin.p + disp_off),
                                   ngroups, W, (OswBlock *)c.blocks.p, c.nblocks, (uint16_t *)c.tiled.p, (uint16_t *)c.sub_cols_buf.p, up));
     }
+    ht.lap("upload: re-tile queued");
     if (pt.on) { HIP_TRY(hipStreamSynchronize(up)); pt.lap("upload: H2D + re-tile"); }
-    if (c.nblocks) HIP_TRY(hipMemcpyAsync(c.sub_cols, c.sub_cols_dev(), (size_t)c.nblocks * 128 * sizeof(uint16_t), hipMemcpyDeviceToHost, up));
+    if (c.nblocks) HIP_TRY(osw_launch_copy16(c.sub_cols_dev(), c.sub_cols, (size_t)c.nblocks * 128 * sizeof(uint16_t), up)); // device -> the page-locked host copy, written by the kernel
     HIP_TRY(hipEventRecord(c.ev_up, up));
+    ht.lap("upload: live extents' way back queued");
     c.up_seq = ++d.up_seq;
     c.items_version = ~0ull;
     c.searched = false;
     c.has_index = false;
-    if (c.index_map) d.retired_maps.push_back(std::move(c.index_map)); // (its copy to the device may still be queued: freed at the next synchronisation)
-    c.index_map.reset();
+    c.index_map = false;
     c.live = true;
     c.upload_pending = true;
-    *chunk = slot;
-    if (!async) {
-        if (int r = finish_upload(d, c)) return r; // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
-        pt.lap("upload: sync");
+    *slot_out = slot;
+    return 0;
+}
+
+// No search and no upload of this device is still on its way: a chunk that arrives now is what the device will wait for.
+// (Asked of the chunks' own events, not of the streams: a few microseconds of housekeeping queued on a stream -- the memset of
+// oswald_hip_topr_begin -- must not count.)
+static bool device_is_idle(Device &d)
+{
+    for (Chunk &c : d.chunks) {
+        if (c.use_pending && c.ev_use) {
+            if (hipEventQuery(c.ev_use) != hipSuccess) { (void)hipGetLastError(); return false; }
+            c.use_pending = false;
+        }
+        if (c.upload_pending && c.ev_up && hipEventQuery(c.ev_up) != hipSuccess) { (void)hipGetLastError(); return false; }
     }
+    return true;
+}
+
+static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
+                             uint32_t ngroups, uint32_t W, int *chunk, bool async)
+{
+    if (int r = check_dev(ctx, dev)) return r;
+    if (!chunk) return fail(OSWALD_HIP_EINVAL, "chunk out-pointer is null");
+    if (W != 16 && W != 32 && W != 64 && W != 128) return fail(OSWALD_HIP_EINVAL, "lane_width must be 16, 32, 64 or 128");
+    if (ngroups > 0 && (!b || !n || !disp)) return fail(OSWALD_HIP_EINVAL, "null chunk arrays");
+    Device &d = ctx->dev[dev];
+    HIP_TRY(hipSetDevice(d.id));
+    // The first chunk of a search is what nothing can hide: its copy (2.3 ms per 128 MiB over PCIe Gen5), its re-tile and the
+    // plan of its search all happen before the device has anything to do.  An asynchronous upload of some size that finds its
+    // device idle is therefore cut into a HEAD of whole 128-sequence blocks and the REST: the head is in the device after a
+    // fraction of the copy, and the rest comes in, is re-tiled and planned while the head is being searched.  How much the
+    // head must hold for its search to cover the rest's copy depends on the query set: a search reads the database at
+    // ~(sum of the query lengths / 200) times the rate of the link (one 375-residue query: 28 GB/s of residues against
+    // 57 GB/s of copy; twenty queries of 100 .. 1000: 1 GB/s) -- head = 1 / (1 + that ratio) of the bytes, at least a twelfth
+    // (the rest's re-tile and plan, ~2 ms, want hiding too), at most half.  (Round 4 had this in the CLI; every caller of
+    // the C ABI gets it now.)  The reference uploads and searches in turn (FPGAsearch.c:180-223).
+    const uint32_t gpb = OSW_BLOCK_SEQS / W;
+    uint32_t head_groups = 0;
+    if (async && ctx->tun.split_bytes && vD >= ctx->tun.split_bytes && ngroups >= 3 * gpb && disp[0] == 0 && device_is_idle(d)) {
+        double sum_m = 0;
+        if (ctx->have_queries) for (uint16_t m : ctx->m) sum_m += m;
+        const double frac = std::min(0.5, std::max(1.0 / 12.0, sum_m > 0 ? 1.0 / (1.0 + sum_m / 200.0) : 1.0 / 12.0));
+        uint32_t g = gpb;
+        while (g + gpb < ngroups && (double)disp[g + gpb] <= frac * (double)vD) g += gpb;
+        // (the reference's layout: the groups back to back in order -- anything else is uploaded in one piece)
+        bool in_order = true;
+        for (uint32_t k = 0; k + 1 < ngroups && in_order; ++k) in_order = (uint64_t)disp[k] + (uint64_t)n[k] * W <= disp[k + 1];
+        if (in_order && g + gpb <= ngroups && disp[g] > 0 && disp[g] < vD) head_groups = g;
+    }
+    if (head_groups == 0) {
+        int slot = -1;
+        if (int r = upload_slot(ctx, dev, b, vD, n, disp, 0, ngroups, W, &slot)) return r;
+        *chunk = slot;
+        if (!async) {
+            if (int r = finish_upload(d, d.chunks[slot])) return r; // caller's buffers are free again (reference: clFinish, FPGAsearch.c:197)
+        }
+        return 0;
+    }
+    int head = -1, rest = -1;
+    const uint32_t cut = disp[head_groups];
+    if (int r = upload_slot(ctx, dev, b, cut, n, disp, 0, head_groups, W, &head)) return r;
+    if (int r = upload_slot(ctx, dev, b + cut, vD - cut, n + head_groups, disp + head_groups, cut, ngroups - head_groups, W, &rest)) {
+        d.chunks[head].live = false; // (its upload is queued and harmless; the slot is free again once it has landed)
+        return r;
+    }
+    d.chunks[head].next = rest;
+    d.chunks[rest].is_cont = true;
+    *chunk = head;
+    if (ctx->tun.debug_phases || g_debug_slow)
+        fprintf(stderr, "[oswald_hip] upload cut in two: head %u groups / %u bytes (slot %d), rest %u groups / %llu bytes (slot %d)\n", head_groups, cut, head, ngroups - head_groups,
+                (unsigned long long)(vD - cut), rest);
     return 0;
 }
 
@@ -966,8 +1171,77 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
     return 0;
 }
 
+// The buffers of `slots` chunk slots for chunks of up to chunk_bytes bytes in ngroups groups, allocated now -- before the
+// caller's clock starts -- instead of by the first uploads and searches: mapping a few hundred MB of device memory takes
+// milliseconds (20 ms per GB on the round-5 box: 9 ms of a 27-ms one-query search at 1 M sequences went into the first
+// upload's allocations).  A hint: a chunk that needs more grows its slot as before.
+int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
+{
+    if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
+    if (dev >= (int)ctx->dev.size()) return fail(OSWALD_HIP_ENODEV, "device index %d out of range", dev);
+    if (W != 16 && W != 32 && W != 64 && W != 128) return fail(OSWALD_HIP_EINVAL, "lane_width must be 16, 32, 64 or 128");
+    if (chunk_bytes > 0xfff00000ull) return fail(OSWALD_HIP_EINVAL, "a chunk holds at most %llu bytes", 0xfff00000ull);
+    slots = std::min<uint32_t>(slots, OSW_MAX_SLOTS);
+    const uint32_t gpb = OSW_BLOCK_SEQS / W, nblocks = (ngroups + gpb - 1) / gpb;
+    for (int i = 0; i < (int)ctx->dev.size(); ++i) {
+        if (dev >= 0 && i != dev) continue;
+        Device &d = ctx->dev[i];
+        HIP_TRY(hipSetDevice(d.id));
+        while (d.chunks.size() < slots) d.chunks.emplace_back();
+        for (uint32_t k = 0; k < slots; ++k) {
+            Chunk &c = d.chunks[k];
+            if (c.live || c.upload_pending) continue;
+            // re-tiled residues: a byte per residue of every block padded to its longest group (sorted databases: ~1.02 x the chunk)
+            // + the all-dummy column groups around every block
+            const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
+            HIP_TRY(c.tiled.reserve(col4 * 64 * sizeof(uint2)));
+            HIP_TRY(c.blocks.reserve(nblocks * sizeof(OswBlock) + 16));
+            HIP_TRY(c.sub_cols_buf.reserve((size_t)nblocks * 128 * sizeof(uint16_t) + 16));
+            HIP_TRY(c.st_b.reserve(chunk_bytes + 64));
+            HIP_TRY(c.nd_pin.reserve((size_t)ngroups * 6 + 192));
+            if ((size_t)nblocks * 128 > c.sub_cols_cap) {
+                if (c.sub_cols) HIP_TRY(hipHostFree(c.sub_cols));
+                c.sub_cols = nullptr;
+                c.sub_cols_cap = 0;
+                const size_t want = (size_t)nblocks * 128 + (size_t)nblocks * 16 + 128;
+                HIP_TRY(hipHostMalloc((void **)&c.sub_cols, want * sizeof(uint16_t), hipHostMallocPortable));
+                c.sub_cols_cap = want;
+            }
+            if (nblocks > c.blocks_pin_cap) {
+                if (c.blocks_pin) HIP_TRY(hipHostFree(c.blocks_pin));
+                c.blocks_pin = nullptr;
+                c.blocks_pin_cap = 0;
+                const size_t want = (size_t)nblocks + nblocks / 8 + 16;
+                HIP_TRY(hipHostMalloc((void **)&c.blocks_pin, want * sizeof(OswBlock), hipHostMallocPortable));
+                c.blocks_pin_cap = want;
+            }
+            if (nq > 0) {
+                HIP_TRY(c.scores.reserve((size_t)nq * nblocks * OSW_BLOCK_SEQS * sizeof(int32_t) + 16));
+                HIP_TRY(c.ovf.reserve((size_t)nq * nblocks * 128 * sizeof(uint2) + 16));
+                // work queues (page-locked host memory): an entry of 8 B per (entity, sub-block) -- a few per block and query
+                const size_t entries = (size_t)nblocks * (nq + 1) * 16 + 4096;
+                for (int set = 0; set < 2; ++set) {
+                    if (entries > c.items_pin_cap[set]) {
+                        if (c.items_pin[set]) HIP_TRY(hipHostFree(c.items_pin[set]));
+                        c.items_pin[set] = nullptr;
+                        c.items_pin_cap[set] = 0;
+                        HIP_TRY(hipHostMalloc((void **)&c.items_pin[set], entries * sizeof(uint2), hipHostMallocPortable));
+                        c.items_pin_cap[set] = entries;
+                    }
+                }
+            }
+            if (!c.ev_up) HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
+            if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
+            if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
+            if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
+        }
+    }
+    return 0;
+}
+
 // Device memory one byte of chunk (one padded residue of the interleaved groups) takes, worst case, for each of the
-// three chunks a device holds while one is searched and the next two come in: the staging copy of the upload (1), the
+// chunks' worth of slots a device keeps (three resident chunks -- one searched while the next two come in -- and the pieces of a first
+// chunk the library cut in two, OSW_MAX_SLOTS): the staging copy of the upload (1), the
 // re-tiled residues (a 128-sequence block is padded to its longest group: <= 1.25), the all-dummy columns behind every
 // block (18 x 512 B per block of >= 128 x 28 B: 2.6), and per sequence -- at most one per 28 bytes, the shortest
 // padded group length -- 4 B of score, 8 B of int32 re-run queue and 8 B of int16 re-run queue per query.
@@ -986,22 +1260,20 @@ int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_
     const uint64_t scratch = 2ull * d.grid * (OSW_WG_THREADS / 64) * (stride + OSW_SCRATCH_DATA) * sizeof(uint2);
     uint64_t usable = (uint64_t)(0.8 * (double)free_b);
     if (stride > d.bnd_stride || !d.bnd.p) usable = usable > scratch ? usable - scratch : 0;
-    const double per_byte = 3.0 * (1.0 + 1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
+    // (four chunks' worth: slots are kept, and after a first chunk cut in two -- head and rest fit no full chunk -- three more are opened)
+    const double per_byte = 4.1 * (1.0 + 1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
     const uint64_t fit = (uint64_t)((double)usable / per_byte);
     *bytes = std::min<uint64_t>(fit, 0xfff00000ull); // (column offsets inside a chunk are 32-bit)
     return 0;
 }
 
-int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out)
+// ---------------------------------------------------------------------------------------------------------------
+// A chunk search in three steps, all of them queueing only: PLAN (queries / profiles in place, work queues planned and on
+// their way, the search stream ordered behind the chunk's upload and its queues), LAUNCH (the DP kernels of the first-pass
+// arithmetic, the re-run tiers, the chunk's top list), DOWNLOAD (the score table to the caller, on the download stream).
+// ---------------------------------------------------------------------------------------------------------------
+static int search_plan(oswald_hip_ctx *ctx, Device &d, Chunk &c, PhaseTimer &pt, HoldTimer &ht)
 {
-    if (int r = check_dev(ctx, dev)) return r;
-    Device &d = ctx->dev[dev];
-    if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
-    Chunk &c = d.chunks[chunk];
-    HIP_TRY(hipSetDevice(d.id));
-    PhaseTimer pt(ctx->tun.debug_phases);
-    if (ctx->topr_r && c.has_index && ctx->topr_queries_version != ctx->queries_version)
-        return fail(OSWALD_HIP_ESTATE, "the query set changed since oswald_hip_topr_begin: call it again before searching");
     // An upload the host has not waited for and that has not landed by itself (its re-tile finds no wave slot while a search
     // is running): the search is planned on the extents the group lengths give and queued BEHIND the upload on the device --
     // the host neither waits for the search before this one to drain nor keeps the device waiting for its plan afterwards.
@@ -1014,7 +1286,6 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         else if (int r = finish_upload(d, c)) return r;
     }
     if (ctx->tun.plan_waits_for_upload && !landed) { if (int r = finish_upload(d, c)) return r; landed = true; }
-    HoldTimer ht(g_debug_slow);
     if (int r = sync_queries(ctx, d)) return r;
     pt.lap("search: queries + profiles");
     ht.lap("search: queries + profiles");
@@ -1022,10 +1293,14 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     pt.lap("search: work-queue plan");
     ht.lap("search: work-queue plan (incl. the queues' copy)");
     if (!landed) HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_up, 0)); // everything queued below finds the chunk in place
-    if (c.ev_items) HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_items, 0)); // ... and its work queues (copy stream)
     ht.lap("search: stream wait for the upload");
+    return 0;
+}
+
+static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht)
+{
     if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return topr_after_search(ctx, d, c); }
-    if (!d.bnd.p || d.bnd_stride == 0) return fail(OSWALD_HIP_ESTATE, "device %d has no spill scratch (an earlier allocation failed)", dev);
+    if (!d.bnd.p || d.bnd_stride == 0) return fail(OSWALD_HIP_ESTATE, "device %d has no spill scratch (an earlier allocation failed)", d.id);
     if (c.down_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_down, 0)); c.down_pending = false; } // the table of the slot's last search is still on its way out
 
     OswSearchArgs a;
@@ -1033,7 +1308,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.tiled = (const uint16_t *)c.tiled.p;
     a.blocks = (const OswBlock *)c.blocks.p;
     a.sub_cols = c.sub_cols_dev();
-    a.items = (const uint2 *)c.items_dev().p;
+    a.items = c.items_ptr();
     a.nitems = c.nitems;
     a.nitems_wg = c.nitems_wg;
     a.two_ended_waves = ctx->tun.two_ended;
@@ -1066,12 +1341,14 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     a.goe = (int32_t)goe;
     a.ge = (int32_t)ge;
 
-    const bool dbg_times = ctx->tun.debug_times; // -DOSW_DIAG builds only
+#ifdef OSW_DIAG
+    const bool dbg_times = ctx->tun.debug_times;
     if (dbg_times) {
         HIP_TRY(d.wg_times.reserve((size_t)d.grid * 5 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(d.wg_times.p, 0, (size_t)d.grid * 5 * sizeof(unsigned long long), d.stream));
         a.wg_times = (unsigned long long *)d.wg_times.p;
     }
+#endif
     EventPair ev{};
     if (ctx->profiling) {
         if (d.ev_pool.empty()) {
@@ -1098,7 +1375,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
         // (queue length on the device), and below the int32 re-run of what reached the int16 ceiling
         if (c.nitems_q > 0) {
             OswSearchArgs aq = a;
-            aq.items = (const uint2 *)c.items_q_dev().p;
+            aq.items = c.items_q_ptr();
             aq.nitems = c.nitems_q;
             aq.nitems_wg = c.nitems_q_wg; // 0: wave items only
             aq.prof = (const uint2 *)d.prof_pair8.p;
@@ -1128,7 +1405,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     } else if (ctx->cell_bits != 32 && c.nitems_q + c.nitems_q_wg > 0) {
         // query pairs first (the bulk of a multi-query search), on their own queue counters
         OswSearchArgs aq = a;
-        aq.items = (const uint2 *)c.items_q_dev().p;
+        aq.items = c.items_q_ptr();
         aq.nitems = c.nitems_q;
         aq.nitems_wg = c.nitems_q_wg;
         aq.prof = (const uint2 *)d.prof_pair.p;
@@ -1162,78 +1439,90 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     else HIP_TRY(osw_launch_i32r(a, d.grid * (OSW_WG_THREADS / 64), d.stream));
     if (ctx->profiling) { HIP_TRY(hipEventRecord(ev.b, d.stream)); d.ev_used.push_back(ev); }
     c.searched = true;
+    // the set of work queues these launches pull from is busy until here (build_items)
+    {
+        const int k = c.items_cur;
+        if (!c.ev_set_read[k]) HIP_TRY(hipEventCreateWithFlags(&c.ev_set_read[k], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c.ev_set_read[k], d.stream));
+        c.set_read_pending[k] = true;
+    }
     ht.lap("search: launches");
     if (int r = topr_after_search(ctx, d, c)) return r;
     ht.lap("search: top-r launches");
     HIP_TRY(hipEventRecord(c.ev_use, d.stream)); // an upload into this slot waits for it
     c.use_pending = true;
+#ifdef OSW_DIAG
     if (dbg_times) {
-        // diagnostics only: when did the workgroups of the DP launch start / leave phase 1 / finish
+        // diagnostics only (liboswald_hip_diag.so): when did the workgroups of the DP launch start / leave phase 1 / finish
         HIP_TRY(hipStreamSynchronize(d.stream));
         std::vector<unsigned long long> t((size_t)grid * 5);
         HIP_TRY(hipMemcpy(t.data(), d.wg_times.p, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (uint32_t g = 0; g < grid; ++g) { if (t[g * 4]) t0 = std::min(t0, t[g * 4]); t1 = std::max(t1, std::max(t[g * 4 + 2], t[g * 4 + 3])); }
-        const double span = (double)(t1 - t0) / 100.0; // us
-        uint32_t hist_p1[10] = {0}, hist_end[10] = {0};
-        double sum_end = 0;
-        for (uint32_t g = 0; g < grid; ++g) {
-            const double p1 = (double)(t[g * 4 + 1] - t0) / 100.0, e = (double)(std::max(t[g * 4 + 2], t[g * 4 + 3]) - t0) / 100.0;
-            hist_p1[std::min(9, (int)(p1 / span * 10))]++;
-            hist_end[std::min(9, (int)(e / span * 10))]++;
-            sum_end += e;
-        }
-        fprintf(stderr, "[oswald_hip] DP launch span %.1f us over %u workgroups; mean finish at %.0f%% of span\n", span, grid, 100.0 * sum_end / grid / span);
-        {
-            uint32_t ctr[8] = {0};
-            HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
-            // waves x span in core-clock cycles (2.4 GHz nominal) against the cycles spent in the slice reloads of workgroup items
-            const double wave_cycles = (double)grid * 4.0 * span * 2400.0;
-            fprintf(stderr, "[oswald_hip]   workgroup items: slice reload + barrier waits %.3g cycles = %.1f%% of all wave time\n",
-                    (double)ctr[4] * 1024.0, 100.0 * (double)ctr[4] * 1024.0 / wave_cycles);
-        }
-        fprintf(stderr, "[oswald_hip]   phase-1 exits by decile:");
-        for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_p1[k]);
-        fprintf(stderr, "\n[oswald_hip]   finishes by decile:    ");
-        for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_end[k]);
-        fprintf(stderr, "\n");
-        {
-            // per CU: when its LAST workgroup finished, and the time-integral of its resident workgroups (4 = full)
-            std::vector<std::pair<unsigned long long, std::vector<double>>> cus; // (cu id, finish times of its workgroups)
-            for (uint32_t g = 0; g < grid; ++g) {
-                const unsigned long long cu = t[(size_t)grid * 4 + g];
-                const double e = (double)(std::max(t[g * 4 + 2], t[g * 4 + 3]) - t0) / 100.0;
-                auto it = std::find_if(cus.begin(), cus.end(), [&](const auto &x) { return x.first == cu; });
-                if (it == cus.end()) { cus.push_back({cu, {}}); it = cus.end() - 1; }
-                it->second.push_back(e);
-            }
-            uint32_t hist_last[10] = {0}, hist_n[8] = {0};
-            double sum_last = 0, occ = 0;
-            for (auto &c2 : cus) {
-                const double last = *std::max_element(c2.second.begin(), c2.second.end());
-                hist_last[std::min(9, (int)(last / span * 10))]++;
-                hist_n[std::min<size_t>(7, c2.second.size())]++;
-                sum_last += last;
-                for (double e : c2.second) occ += e;
-            }
-            fprintf(stderr, "[oswald_hip]   %zu CUs; last finish per CU by decile:", cus.size());
-            for (int k = 0; k < 10; ++k) fprintf(stderr, " %u", hist_last[k]);
-            fprintf(stderr, "; mean last finish %.0f%% of span; workgroups per CU histogram:", 100.0 * sum_last / cus.size() / span);
-            for (int k = 0; k < 8; ++k) fprintf(stderr, " %u", hist_n[k]);
-            fprintf(stderr, "; mean resident workgroups per CU over the span %.2f\n", occ / cus.size() / span);
-        }
+        uint32_t ctr[8] = {0};
+        HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
+        osw_diag_report_times(t.data(), grid, ctr[4]);
     }
-    if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: kernels"); }
-    if (scores_out) {
-        // The caller's table is [nq][ngroups*W]; ours is pitched to whole wave blocks.  It leaves on the download stream,
-        // behind the search (ev_use) and beside whatever the search stream runs next: row by row when the rows are few (plain
-        // DMA, nothing that needs a wave slot), packed on the device first when they are many (a pitched copy into
-        // pageable memory runs at a fraction of a GB/s).
-        const uint32_t row = c.ngroups * c.W;
+#endif
+    return 0;
+}
+
+// The chunk's (this slot's) table to the caller: columns [col0, col0 + ngroups * W) of rows of out_stride scores.
+static int search_download(oswald_hip_ctx *ctx, Device &d, Chunk &c, int32_t *scores_out, size_t out_stride, size_t col0, PhaseTimer &pt, HoldTimer &ht)
+{
+    // The caller's table is [nq][out_stride]; ours is pitched to whole wave blocks.  It leaves on the download stream,
+    // behind the search (ev_use) and beside whatever the search stream runs next: row by row when the rows are few (plain
+    // DMA, nothing that needs a wave slot), packed on the device first when they are many (a pitched copy into
+    // pageable memory runs at a fraction of a GB/s).
+    const uint32_t row = c.ngroups * c.W;
+    if (row == 0 || ctx->nq == 0) return 0;
+    int32_t *dst = scores_out + col0;
+    HIP_TRY(hipStreamWaitEvent(d.stream_down, c.ev_use, 0));
+    if (out_stride == row && (row == c.score_stride || ctx->nq == 1)) {
+        HIP_TRY(hipMemcpyAsync(dst, c.scores.p, (size_t)ctx->nq * row * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream_down));
+    } else if (ctx->nq <= 64) {
+        for (uint32_t q = 0; q < ctx->nq; ++q)
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)q * out_stride, (const int32_t *)c.scores.p + (size_t)q * c.score_stride, (size_t)row * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, d.stream_down));
+    } else {
         const size_t bytes = (size_t)ctx->nq * row * sizeof(int32_t);
-        // pin the caller's table for the copy unless it is page-locked already (oswald_hip_host_alloc): the DMA engine then
-        // writes it directly (a copy into a pageable buffer it has not seen before runs at ~1 GB/s: 8.9 ms for the 8 MB of
+        HIP_TRY(d.scores_packed.reserve(bytes));
+        HIP_TRY(hipMemcpy2DAsync(d.scores_packed.p, (size_t)row * sizeof(int32_t), c.scores.p, (size_t)c.score_stride * sizeof(int32_t),
+                                 (size_t)row * sizeof(int32_t), ctx->nq, hipMemcpyDeviceToDevice, d.stream_down));
+        if (out_stride == row) HIP_TRY(hipMemcpyAsync(dst, d.scores_packed.p, bytes, hipMemcpyDeviceToHost, d.stream_down));
+        else HIP_TRY(hipMemcpy2DAsync(dst, out_stride * sizeof(int32_t), d.scores_packed.p, (size_t)row * sizeof(int32_t), (size_t)row * sizeof(int32_t), ctx->nq,
+                                      hipMemcpyDeviceToHost, d.stream_down));
+    }
+    HIP_TRY(hipEventRecord(c.ev_down, d.stream_down));
+    c.down_pending = true;
+    ht.lap("search: table download queued");
+    if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream_down)); pt.lap("search: D2H of the score table"); }
+    return 0;
+}
+
+// a caller's handle: the slot of a live chunk that is not the rest of another one
+static int check_chunk(oswald_hip_ctx *ctx, int dev, int chunk)
+{
+    if (int r = check_dev(ctx, dev)) return r;
+    const Device &d = ctx->dev[dev];
+    if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live || d.chunks[chunk].is_cont) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
+    return 0;
+}
+
+int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out)
+{
+    if (int r = check_chunk(ctx, dev, chunk)) return r;
+    Device &d = ctx->dev[dev];
+    HIP_TRY(hipSetDevice(d.id));
+    PhaseTimer pt(ctx->tun.debug_phases);
+    if (ctx->topr_r && d.chunks[chunk].has_index && ctx->topr_queries_version != ctx->queries_version)
+        return fail(OSWALD_HIP_ESTATE, "the query set changed since oswald_hip_topr_begin: call it again before searching");
+    HoldTimer ht(g_debug_slow);
+    size_t out_stride = 0;
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) out_stride += (size_t)d.chunks[k].ngroups * d.chunks[k].W;
+    if (scores_out && out_stride && ctx->have_queries) {
+        // pin the caller's table for the copy unless it is page-locked already (oswald_hip_host_alloc / _register): the DMA engine
+        // then writes it directly (a copy into a pageable buffer it has not seen before runs at ~1 GB/s: 8.9 ms for the 8 MB of
         // C2; this way 0.5 ms)
+        const size_t bytes = (size_t)ctx->nq * out_stride * sizeof(int32_t);
         hipPointerAttribute_t attr;
         const bool pinned_already = hipPointerGetAttributes(&attr, scores_out) == hipSuccess && attr.type == hipMemoryTypeHost;
         (void)hipGetLastError(); // (an unknown -- pageable -- pointer is reported as an error by some runtimes)
@@ -1245,48 +1534,57 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             else (void)hipGetLastError(); // e.g. already pinned by the caller: the plain copy below is still correct
             pt.lap("search: pin caller's table");
         }
-        HIP_TRY(hipStreamWaitEvent(d.stream_down, c.ev_use, 0));
-        if (row == c.score_stride || ctx->nq == 1) {
-            HIP_TRY(hipMemcpyAsync(scores_out, c.scores.p, bytes, hipMemcpyDeviceToHost, d.stream_down));
-        } else if (ctx->nq <= 64) {
-            for (uint32_t q = 0; q < ctx->nq; ++q)
-                HIP_TRY(hipMemcpyAsync(scores_out + (size_t)q * row, (const int32_t *)c.scores.p + (size_t)q * c.score_stride, (size_t)row * sizeof(int32_t),
-                                       hipMemcpyDeviceToHost, d.stream_down));
-        } else {
-            HIP_TRY(d.scores_packed.reserve(bytes));
-            HIP_TRY(hipMemcpy2DAsync(d.scores_packed.p, (size_t)row * sizeof(int32_t), c.scores.p, (size_t)c.score_stride * sizeof(int32_t),
-                                     (size_t)row * sizeof(int32_t), ctx->nq, hipMemcpyDeviceToDevice, d.stream_down));
-            HIP_TRY(hipMemcpyAsync(scores_out, d.scores_packed.p, bytes, hipMemcpyDeviceToHost, d.stream_down));
-        }
-        HIP_TRY(hipEventRecord(c.ev_down, d.stream_down));
-        c.down_pending = true;
-        ht.lap("search: table download queued");
-        if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream_down)); pt.lap("search: D2H of the score table"); }
+    }
+    // a chunk the library cut in two at its upload: head, then rest, behind one another on the device
+    size_t col0 = 0;
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) {
+        Chunk &c = d.chunks[k];
+        if (int r = search_plan(ctx, d, c, pt, ht)) return r;
+        if (int r = search_launch(ctx, d, c, ht)) return r;
+        if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: kernels"); }
+        if (scores_out) if (int r = search_download(ctx, d, c, scores_out, out_stride, col0, pt, ht)) return r;
+        col0 += (size_t)c.ngroups * c.W;
     }
     return 0;
 }
 
 int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
 {
-    if (int r = check_dev(ctx, dev)) return r;
+    if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
-    if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
     HIP_TRY(hipSetDevice(d.id));
     // the caller's b / n / disp are free once the upload has landed; a search of the chunk may still be running -- the
     // next upload into the slot waits for it on the device (ev_use), the host does not
-    if (int r = finish_upload(d, d.chunks[chunk])) return r;
-    d.chunks[chunk].live = false; // buffers are kept for the next upload into this slot
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) if (int r = finish_upload(d, d.chunks[k])) return r;
+    for (int k = chunk; k >= 0;) {
+        Chunk &c = d.chunks[k];
+        k = c.next;
+        c.live = false; // buffers are kept for the next upload into this slot
+        c.next = -1;
+        c.is_cont = false;
+    }
     return 0;
 }
 
+// Upload, search and release in one call, and asynchronous throughout: the copies are queued on the copy stream, the search
+// behind them on the device, and the slot goes back to the pool when the host next learns that the upload has landed
+// (oswald_hip_wait, or a later upload's completion on the same in-order stream) -- a following upload into it waits for this
+// search on the device.  With several devices the calls for device d+1 are made while device d's chunk is still on the link:
+// the reference's four clEnqueueWriteBuffer per device are non-blocking too (FPGAsearch.c:180-198).
 int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                                   const uint32_t *disp, uint32_t ngroups, uint32_t W, int32_t *scores_out)
 {
     int h = -1;
-    if (int r = oswald_hip_chunk_upload(ctx, dev, b, vD, n, disp, ngroups, W, &h)) return r;
-    int r = oswald_hip_chunk_search(ctx, dev, h, scores_out);
-    // the slot is recycled by the next upload; the stream keeps the work ordered
-    ctx->dev[dev].chunks[h].live = false;
+    if (int r = oswald_hip_chunk_upload_async(ctx, dev, b, vD, n, disp, ngroups, W, &h)) return r;
+    const int r = oswald_hip_chunk_search(ctx, dev, h, scores_out);
+    Device &d = ctx->dev[dev];
+    for (int k = h; k >= 0;) { // (upload_pending stays set: the slots are not re-used before the upload has landed)
+        Chunk &c = d.chunks[k];
+        k = c.next;
+        c.live = false;
+        c.next = -1;
+        c.is_cont = false;
+    }
     return r;
 }
 
@@ -1301,7 +1599,7 @@ int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_up));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_down));
-        for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; c.down_pending = false; }
+        for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; c.down_pending = false; c.set_read_pending[0] = c.set_read_pending[1] = false; }
         release_registered(ctx->dev[i]);
     }
     return 0;
@@ -1311,50 +1609,102 @@ int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nval
 {
     if (int rc = check_dev(ctx, dev)) return rc;
     Device &d = ctx->dev[dev];
-    if (chunk < 0 || chunk >= (int)d.chunks.size()) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
-    Chunk &c = d.chunks[chunk];
-    if (!c.searched) return fail(OSWALD_HIP_ESTATE, "chunk %d has not been searched", chunk);
+    if (chunk < 0 || chunk >= (int)d.chunks.size() || d.chunks[chunk].is_cont) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
+    uint32_t lanes = 0;
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) {
+        if (!d.chunks[k].searched) return fail(OSWALD_HIP_ESTATE, "chunk %d has not been searched", chunk);
+        lanes += d.chunks[k].ngroups * d.chunks[k].W;
+    }
     if (!scores || !index) return fail(OSWALD_HIP_EINVAL, "null output");
-    if (nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "nvalid %u exceeds the chunk's %u lanes", nvalid, c.ngroups * c.W);
+    if (nvalid > lanes) return fail(OSWALD_HIP_EINVAL, "nvalid %u exceeds the chunk's %u lanes", nvalid, lanes);
     if (r == 0 || ctx->nq == 0) return 0;
     HIP_TRY(hipSetDevice(d.id));
     const size_t cnt = (size_t)ctx->nq * r;
     if (r > 1024) return fail(OSWALD_HIP_EINVAL, "top-r on the device supports r <= 1024 (asked for %u)", r);
-    if (int rc = queue_topr(ctx, d, c, nvalid, r)) return rc;
-    HIP_TRY(hipMemcpyAsync(scores, d.topr_scores.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
-    HIP_TRY(hipMemcpyAsync(index, d.topr_index.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    HIP_TRY(hipStreamSynchronize(d.stream));
+    if (d.chunks[chunk].next < 0) {
+        if (int rc = queue_topr(ctx, d, d.chunks[chunk], nvalid, r)) return rc;
+        HIP_TRY(hipMemcpyAsync(scores, d.topr_scores.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipMemcpyAsync(index, d.topr_index.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        return 0;
+    }
+    // a chunk in two pieces: the r best of each, indices counted from the chunk's first sequence, merged in the same order
+    std::vector<int32_t> cs, ps(cnt);
+    std::vector<uint32_t> ci, pi(cnt);
+    uint32_t first = 0, pieces = 0;
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) {
+        Chunk &c = d.chunks[k];
+        const uint32_t have = c.ngroups * c.W, nv = nvalid > first ? std::min(nvalid - first, have) : 0u;
+        if (nv > 0) {
+            if (int rc = queue_topr(ctx, d, c, nv, r)) return rc;
+            HIP_TRY(hipMemcpyAsync(ps.data(), d.topr_scores.p, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipMemcpyAsync(pi.data(), d.topr_index.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipStreamSynchronize(d.stream));
+            for (size_t i = 0; i < cnt; ++i) if (ps[i] >= 0) pi[i] += first;
+        } else {
+            std::fill(ps.begin(), ps.end(), -1);
+            std::fill(pi.begin(), pi.end(), 0u);
+        }
+        cs.insert(cs.end(), ps.begin(), ps.end());
+        ci.insert(ci.end(), pi.begin(), pi.end());
+        first += have;
+        ++pieces;
+    }
+    // [piece][nq][r] -> [nq][pieces * r]
+    std::vector<int32_t> ms(cs.size());
+    std::vector<uint32_t> mi(ci.size());
+    for (uint32_t pc = 0; pc < pieces; ++pc)
+        for (uint32_t q = 0; q < ctx->nq; ++q)
+            for (uint32_t j = 0; j < r; ++j) {
+                ms[((size_t)q * pieces + pc) * r + j] = cs[((size_t)pc * ctx->nq + q) * r + j];
+                mi[((size_t)q * pieces + pc) * r + j] = ci[((size_t)pc * ctx->nq + q) * r + j];
+            }
+    merge_candidates(ctx->nq, (size_t)pieces * r, ms.data(), mi.data(), r, scores, index);
+    return 0;
+}
+
+static int set_index_slot(Device &d, Chunk &c, uint32_t first_index, uint32_t nvalid, const uint32_t *index_map)
+{
+    c.first_index = first_index;
+    c.nvalid = nvalid;
+    c.index_map = false;
+    if (index_map && nvalid > 0) {
+        // the map goes to the device (the chunk's top list is selected there, on database keys) by way of a page-locked copy
+        // made here: the caller's array is free when the call returns, and the copy engine reads nothing pageable
+        const int k = c.map_cur ^ 1;
+        if (c.ev_map[k]) HIP_TRY(hipEventSynchronize(c.ev_map[k])); // (the copy that last read this staging buffer: two maps ago)
+        else HIP_TRY(hipEventCreateWithFlags(&c.ev_map[k], hipEventDisableTiming));
+        HIP_TRY(c.map_pin[k].reserve((size_t)nvalid * sizeof(uint32_t)));
+        memcpy(c.map_pin[k].p, index_map, (size_t)nvalid * sizeof(uint32_t));
+        // (the device buffer: the search that read it last -- of the chunk this slot held two maps ago -- is long through; a map
+        // given twice to one upload flips to the other buffer, which a running search of the chunk does not read)
+        HIP_TRY(c.index_map_dev[k].reserve((size_t)nvalid * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(c.index_map_dev[k].p, c.map_pin[k].p, (size_t)nvalid * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream_copy));
+        HIP_TRY(hipEventRecord(c.ev_map[k], d.stream_copy));
+        c.map_cur = k;
+        c.map_pending = true;
+        c.index_map = true;
+    }
+    c.has_index = true;
     return 0;
 }
 
 int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t first_index, uint32_t nvalid, const uint32_t *index_map)
 {
-    if (int r = check_dev(ctx, dev)) return r;
+    if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
-    if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
-    Chunk &c = d.chunks[chunk];
-    if (nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "nvalid %u exceeds the chunk's %u lanes", nvalid, c.ngroups * c.W);
+    uint32_t lanes = 0;
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) lanes += d.chunks[k].ngroups * d.chunks[k].W;
+    if (nvalid > lanes) return fail(OSWALD_HIP_EINVAL, "nvalid %u exceeds the chunk's %u lanes", nvalid, lanes);
     if (!index_map && (uint64_t)first_index + nvalid > 0xffffffffull) return fail(OSWALD_HIP_EINVAL, "database indices must fit 32 bits");
     HIP_TRY(hipSetDevice(d.id));
-    if (c.index_map) { // a map given twice to the same upload: the old one may still be on its way, or being read by a search of the chunk
-        HIP_TRY(hipStreamSynchronize(d.stream_copy));
-        HIP_TRY(hipStreamSynchronize(d.stream));
-        c.index_map.reset();
+    uint32_t first = 0; // sequences of the chunk in front of the piece
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) {
+        Chunk &c = d.chunks[k];
+        const uint32_t have = c.ngroups * c.W, nv = nvalid > first ? std::min(nvalid - first, have) : 0u;
+        if (int r = set_index_slot(d, c, index_map ? 0u : first_index + first, nv, index_map ? index_map + first : nullptr)) return r;
+        first += have;
     }
-    c.first_index = first_index;
-    c.nvalid = nvalid;
-    if (index_map && nvalid > 0) {
-        // the map goes to the device (the chunk's top list is selected there, on database keys); the host copy is the
-        // source of that asynchronous upload and lives as long as the chunk's index does
-        c.index_map = std::make_shared<const std::vector<uint32_t>>(index_map, index_map + nvalid);
-        c.map_cur ^= 1;
-        if (!c.ev_map) HIP_TRY(hipEventCreateWithFlags(&c.ev_map, hipEventDisableTiming));
-        HIP_TRY(c.index_map_dev[c.map_cur].reserve((size_t)nvalid * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpyAsync(c.index_map_dev[c.map_cur].p, c.index_map->data(), (size_t)nvalid * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream_copy));
-        HIP_TRY(hipEventRecord(c.ev_map, d.stream_copy));
-        c.map_pending = true;
-    }
-    c.has_index = true;
     return 0;
 }
 
@@ -1460,9 +1810,9 @@ int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *
         HIP_TRY(hipSetDevice(d.id));
         HIP_TRY(hipStreamSynchronize(d.stream));
         HIP_TRY(hipStreamSynchronize(d.stream_down));
-        if (!d.retired_maps.empty()) HIP_TRY(hipStreamSynchronize(d.stream_copy)); // (their copies ran on the copy stream)
         for (Chunk &c : d.chunks) c.down_pending = false;
         release_registered(d);
+        if (g_debug_slow) drain_events(d);
     }
     memcpy(scores, ctx->top_host, out_cnt * sizeof(int32_t));
     memcpy(db_index, (const char *)ctx->top_host + out_cnt * sizeof(int32_t), out_cnt * sizeof(uint32_t));
@@ -1500,6 +1850,20 @@ int oswald_hip_comm_init_rank(oswald_hip_ctx *ctx, const void *id, size_t id_byt
     ctx->pcomm = comm;
     ctx->pcomm_nranks = nranks;
     ctx->pcomm_rank = rank;
+    return 0;
+}
+
+int oswald_hip_comm_destroy(oswald_hip_ctx *ctx)
+{
+    if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
+    if (!ctx->pcomm) return 0;
+    HIP_TRY(hipSetDevice(ctx->dev[0].id));
+    HIP_TRY(hipStreamSynchronize(ctx->dev[0].stream)); // (an all-gather of an earlier oswald_hip_topr has long finished: it waits for its devices)
+    const ncclResult_t nr = ncclCommAbort(ctx->pcomm); // no rank waits for another one: a rank that never joined cannot keep this one here
+    ctx->pcomm = nullptr;
+    ctx->pcomm_nranks = 0;
+    ctx->pcomm_rank = -1;
+    if (nr != ncclSuccess) return fail(OSWALD_HIP_ECOMM, "ncclCommAbort: %s", ncclGetErrorString(nr));
     return 0;
 }
 
@@ -1585,27 +1949,27 @@ int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2)
 
 int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out8)
 {
-    if (int r = check_dev(ctx, dev)) return r;
+    if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
-    if (chunk < 0 || chunk >= (int)d.chunks.size() || !d.chunks[chunk].live) return fail(OSWALD_HIP_EINVAL, "invalid chunk handle %d", chunk);
     if (!out8) return fail(OSWALD_HIP_EINVAL, "null output");
-    uint64_t *out6 = out8;
-    Chunk &c = d.chunks[chunk];
     HIP_TRY(hipSetDevice(d.id));
-    if (int r = finish_upload(d, c)) return r;
-    HIP_TRY(hipStreamSynchronize(d.stream));
-    std::vector<OswBlock> blocks(c.nblocks);
-    if (c.nblocks) HIP_TRY(hipMemcpy(blocks.data(), c.blocks.p, c.nblocks * sizeof(OswBlock), hipMemcpyDeviceToHost));
-    uint64_t alloc = 0, live = 0;
-    for (const OswBlock &b : blocks) { alloc += b.ncols4_alloc; live += b.ncols4; }
-    out6[0] = c.nblocks;
-    out6[1] = alloc;
-    out6[2] = live;
-    out6[3] = live * 64 * sizeof(uint2);
-    out6[4] = c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg; // wave-level work items (a phase-1 entry is four)
-    out6[5] = c.max_lg;
-    out8[6] = c.planned_spill_bytes;
-    out8[7] = 0;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) { // (a chunk the library cut in two: the sums over its pieces)
+        Chunk &c = d.chunks[k];
+        if (int r = finish_upload(d, c)) return r;
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        std::vector<OswBlock> blocks(c.nblocks);
+        if (c.nblocks) HIP_TRY(hipMemcpy(blocks.data(), c.blocks.p, c.nblocks * sizeof(OswBlock), hipMemcpyDeviceToHost));
+        uint64_t alloc = 0, live = 0;
+        for (const OswBlock &b : blocks) { alloc += b.ncols4_alloc; live += b.ncols4; }
+        out8[0] += c.nblocks;
+        out8[1] += alloc;
+        out8[2] += live;
+        out8[3] += live * 64 * sizeof(uint2);
+        out8[4] += c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg; // wave-level work items (a phase-1 entry is four)
+        out8[5] = std::max<uint64_t>(out8[5], c.max_lg);
+        out8[6] += c.planned_spill_bytes;
+    }
     return 0;
 }
 

@@ -155,6 +155,8 @@ hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          bool intsum, uint4 *prof_pair, hipStream_t s);
 hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s); // a search-shaped fill (see sw_kernels.hip)
+hipError_t osw_launch_copy16(const void *src_host_pinned, void *dst, size_t bytes, hipStream_t s); // page-locked host -> device by a kernel that reads the host buffer in place
+hipError_t osw_warm_aux_kernels(hipStream_t s); // first launches of the profile / top-list kernels (bring-up)
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);
 hipError_t osw_launch_build_profile(const uint8_t *a, const uint32_t *a_disp, const uint16_t *qlen, const uint32_t *prof_off,
@@ -174,6 +176,10 @@ hipError_t osw_launch_topr_fold_lists2(const unsigned long long *a, const unsign
 hipError_t osw_launch_topr_untag(const unsigned long long *keys, uint32_t nq, uint32_t r, uint32_t r_out, int32_t *out_scores, uint32_t *out_index,
                                  hipStream_t s);
 int osw_occupancy_pk16(int *blocks_per_cu);
+#ifdef OSW_DIAG
+// osw_diag.cpp (the -DOSW_DIAG build only): per-workgroup time stamps of a DP launch as text on stderr
+void osw_diag_report_times(const unsigned long long *t, uint32_t grid, uint32_t reload_k);
+#endif
 int osw_occupancy_q8(int *blocks_per_cu);
 
 #endif

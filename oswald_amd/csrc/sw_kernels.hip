@@ -1533,6 +1533,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile8(const 
 // slower (tools/plan_probe3.py, orders C / D: 123 instead of 110 ms).  Workgroups of the search's own shape leave holes a
 // search workgroup fits exactly.  The re-tile runs a little slower for it (three workgroups per CU).
 // ---------------------------------------------------------------------------
+
 #define OSW_SEARCH_SHAPED_VGPRS() asm volatile("v_mov_b32 v167, 0" ::: "v167")
 
 // the pad columns of `tiled` (and everything else a chunk's re-tile does not write): dummy residues; instead of the runtime's fill
@@ -1542,6 +1543,15 @@ extern "C" __global__ __launch_bounds__(256) void osw_fill16(uint4 *__restrict__
     OSW_SEARCH_SHAPED_VGPRS();
     const uint4 v = make_uint4(word, word, word, word);
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) p[k] = v;
+}
+
+
+// page-locked host memory -> device (or back), by a kernel that reads / writes the host buffer in place (the small inputs of a query set:
+// oswald_hip.cpp::sync_queries); n16 = 16-byte words
+extern "C" __global__ __launch_bounds__(256) void osw_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    OSW_SEARCH_SHAPED_VGPRS(); // (it runs on the upload stream beside searches: see "search-shaped" above)
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) dst[k] = src[k];
 }
 
 // Re-tile the reference's W-lane interleaved groups (a4: b[disp_g + j*W + l],
@@ -1959,6 +1969,33 @@ hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s)
     const size_t n16 = bytes / 16;
     const uint32_t grid = (uint32_t)std::min<size_t>((n16 + 255) / 256, 768u * 4u);
     hipLaunchKernelGGL(osw_fill16, dim3(grid), dim3(256), osw_shape_lds((const void *)osw_fill16), s, (uint4 *)p, (uint32_t)byte * 0x01010101u, n16);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+static size_t osw_shape_lds(const void *kern);
+hipError_t osw_launch_copy16(const void *src_host_pinned, void *dst, size_t bytes, hipStream_t s)
+{
+    const size_t n16 = (bytes + 15) / 16; // (both buffers are sized with slack beyond a multiple of 16)
+    if (n16 == 0 && src_host_pinned) return hipSuccess; // (null, 0: the first launch of the kernel, at bring-up)
+    hipLaunchKernelGGL(osw_copy16, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n16 + 255) / 256, 64))), dim3(256), osw_shape_lds((const void *)osw_copy16), s, (const uint4 *)src_host_pinned, (uint4 *)dst, n16);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// first launches of the kernels a query set's bring-up and a search's top list use, on empty inputs (oswald_hip_init: before any clock)
+hipError_t osw_warm_aux_kernels(hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_copy16, dim3(1), dim3(256), 0, s, (const uint4 *)nullptr, (uint4 *)nullptr, (size_t)0);
+    hipLaunchKernelGGL(osw_build_profile, dim3(1, 1), dim3(256), 0, s, (const uint8_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)nullptr,
+                       (const int8_t *)nullptr, 0u, 0, (uint2 *)nullptr, (uint4 *)nullptr);
+    hipLaunchKernelGGL(osw_build_pair_profile, dim3(1, 1), dim3(256), 0, s, (const uint2 *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, (const uint16_t *)nullptr, 0u, 0u, (uint4 *)nullptr);
+    hipLaunchKernelGGL(osw_build_pair_profile8, dim3(1, 1), dim3(256), 0, s, (const uint2 *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, (const uint16_t *)nullptr, 0u, 0, (uint2 *)nullptr);
+    hipLaunchKernelGGL(osw_topr_part, dim3(1, 1), dim3(256), 0, s, (const int32_t *)nullptr, 0u, 0u, 0u, 1u, (const uint32_t *)nullptr, 0u, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(osw_topr_fold, dim3(1), dim3(256), 0, s, (const unsigned long long *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0, 0u, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(osw_topr_untag, dim3(1), dim3(256), 0, s, (const unsigned long long *)nullptr, 0u, 0u, 0u, (int32_t *)nullptr, (uint32_t *)nullptr);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

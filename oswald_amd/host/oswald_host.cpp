@@ -450,6 +450,14 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
     return db;
 }
 
+std::vector<std::pair<const void *, size_t>> residue_ranges(const Database &db)
+{
+    std::vector<std::pair<const void *, size_t>> r;
+    if (db.cache) r.push_back({db.cache->p, db.cache->bytes});
+    else for (const Chunk &c : db.chunks) if (c.b && c.b_size) r.push_back({c.b, (size_t)c.b_size});
+    return r;
+}
+
 std::vector<std::string> load_database_headers(const std::string &sequences_filename, uint64_t sequences_count)
 {
     std::ifstream f(sequences_filename + ".desc", std::ios::binary);

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace oswald {
@@ -101,6 +102,10 @@ struct Database {
 };
 Database assemble_multiple_chunks_db(const std::string &sequences_filename, int vector_length, uint64_t max_buffer_size,
                                      unsigned num_devices);
+// The memory the chunks' residues live in, as (start, bytes) ranges a caller may page-lock for DMA: the mapped group cache
+// as ONE range (the chunks are slices of it), else every chunk's own buffer.  The reference allocates these buffers
+// 64-byte aligned "for DMA" (posix_memalign(AOCL_ALIGNMENT, ...), host/src/sequences.c:470-476).
+std::vector<std::pair<const void *, size_t>> residue_ranges(const Database &db);
 
 // Host compute path (`-m 2`, and the host share of `-m 1`; host_search.cpp): exact scores of every query against the
 // groups [g0, g1) of a chunk, written to scores[qi * row_stride + col0 + (g - g0) * 16 + lane].  A mode of its own,

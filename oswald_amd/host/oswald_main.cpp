@@ -16,6 +16,7 @@
 #include <atomic>
 #include <utility>
 #include <sys/time.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -139,14 +140,45 @@ double dwalltime()
     return tv.tv_sec + tv.tv_usec / 1000000.0;
 }
 
-// the reference's convention: any accelerator error prints and terminates (utils.c:256-262)
+// the reference's convention: any accelerator error prints and terminates (utils.c:256-262).  Off the main thread -- the
+// threads that drive the devices, the hybrid mode's accelerator thread, OpenMP workers -- the process leaves through _exit():
+// exit() would run the atexit handlers and static destructors (the HIP runtime's among them) under the feet of the other
+// threads, which are inside runtime calls at that moment, and a clean message could end in a crash or a hang instead.
+const std::thread::id g_main_thread = std::this_thread::get_id();
 void check(int rc, const char *what)
 {
     if (rc != 0) {
         fprintf(stderr, "OSWALD: %s failed: %s\n", what, oswald_hip_last_error());
+        fflush(stdout);
+        fflush(stderr);
+        if (std::this_thread::get_id() != g_main_thread) _exit(EXIT_FAILURE);
         exit(EXIT_FAILURE);
     }
 }
+
+// The database's residues page-locked in place for the length of the search (oswald_hip_host_register): the uploads are then
+// plain asynchronous DMA at the rate of the link (57 GB/s on the round-5 box) and their calls return at once; from pageable
+// memory -- a private mapping of the group cache -- the runtime stages every copy through its own buffers on the caller's
+// thread (18 - 26 GB/s, and an upload call holds the host for as long).  Registering the mapped 378 MB of a 1 M-sequence
+// database takes 4 ms (tools/pin_probe.hip, profiles/r05_pin_probe.txt).  Before the clock, like the reference's aligned
+// buffers (sequences.c:470-476).  OSWALD_NO_PIN=1 (A/B hook) leaves the memory pageable; so does a kernel that refuses
+// (a message with OSWALD_DEBUG_PHASES, no error: uploads from pageable memory work).
+struct PinnedResidues {
+    std::vector<void *> held;
+    explicit PinnedResidues(const oswald::Database &db)
+    {
+        if (getenv("OSWALD_NO_PIN")) return;
+        for (const auto &r : oswald::residue_ranges(db)) {
+            // (whole pages: the start of a chunk's own buffer need not be page-aligned)
+            const uintptr_t a = (uintptr_t)r.first & ~(uintptr_t)4095, e = ((uintptr_t)r.first + r.second + 4095) & ~(uintptr_t)4095;
+            if (oswald_hip_host_register((void *)a, (size_t)(e - a)) == 0) held.push_back((void *)a);
+            else if (getenv("OSWALD_DEBUG_PHASES")) fprintf(stderr, "[oswald] residues stay pageable: %s\n", oswald_hip_last_error());
+        }
+    }
+    ~PinnedResidues() { for (void *p : held) (void)oswald_hip_host_unregister(p); }
+    PinnedResidues(const PinnedResidues &) = delete;
+    PinnedResidues &operator=(const PinnedResidues &) = delete;
+};
 
 // devices 0 .. num_devices-1, or the list in OSWALD_DEVICE_IDS ("0,0": two context devices on one GPU; test hook)
 int bring_up(const Options &o, oswald_hip_ctx **ctx)
@@ -237,6 +269,17 @@ void tops_from_table(const Options &o, const oswald::Database &db, const std::ve
     for (uint64_t i = 0; i < nq; ++i) oswald::top_scores(scores.data() + i * db.vect_sequences_count * W, db.sequences_count, o.top, top_s[i], top_i[i]);
 }
 
+// -k adapted to what the devices can hold BEFORE the database is cut, in every mode that uses them -- the reference does it in
+// init() (utils.c:162-168, called from main.c:46 whatever -m says)
+void clamp_chunk_size(Options &o, oswald_hip_ctx *ctx, uint64_t nq)
+{
+    for (unsigned d = 0; d < o.num_devices; ++d) {
+        uint64_t fits = 0;
+        check(oswald_hip_max_chunk_size(ctx, (int)d, (uint32_t)nq, oswald::kMaxSequenceLength, &fits), "chunk size limit");
+        if (fits < o.max_chunk_size) o.max_chunk_size = fits;
+    }
+}
+
 // -m 2: every group on the host cores; no accelerator call at all.
 int do_search_host_only(Options &o)
 {
@@ -295,14 +338,16 @@ int do_search_hybrid_static(Options &o)
     printf("\nOSWALD v%s \n\n", oswald::kVersion);
     printf("Database file:\t\t\t%s\n", o.db);
     oswald::Queries q = oswald::load_query_sequences(o.queries);
+    oswald_hip_ctx *ctx = nullptr;
+    check(bring_up(o, &ctx), "device bring-up");
+    clamp_chunk_size(o, ctx, q.m.size());
     oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, o.num_devices);
+    PinnedResidues pinned(db);
     const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength, G = db.vect_sequences_count, row = G * W;
     print_header(o, db);
     if (db.sequences_count < o.top) o.top = db.sequences_count;
     const int8_t *sm = oswald::submat_by_name(o.submat);
     std::vector<int32_t> scores(nq * row, 0);
-    oswald_hip_ctx *ctx = nullptr;
-    check(bring_up(o, &ctx), "device bring-up");
     check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space");
     check(oswald_hip_set_scoring(ctx, sm, o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
@@ -445,7 +490,11 @@ int do_search_hybrid(Options &o)
     printf("\nOSWALD v%s \n\n", oswald::kVersion);
     printf("Database file:\t\t\t%s\n", o.db);
     oswald::Queries q = oswald::load_query_sequences(o.queries);
+    oswald_hip_ctx *ctx = nullptr;
+    check(bring_up(o, &ctx), "device bring-up");
+    clamp_chunk_size(o, ctx, q.m.size());
     oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, 1);
+    PinnedResidues pinned(db);
     const uint64_t nq = q.m.size(), W = oswald::kFpgaVectorLength, G = db.vect_sequences_count, row = G * W;
     print_header(o, db);
     if (db.sequences_count < o.top) o.top = db.sequences_count;
@@ -464,9 +513,12 @@ int do_search_hybrid(Options &o)
     }
     const uint64_t host_min_groups = std::max<uint64_t>(1, (2 * (uint64_t)host_threads + nq - 1) / std::max<uint64_t>(nq, 1)); // >= two (group, query) cells per host thread
     std::vector<int32_t> scores(nq * row, 0); // the host's columns only
-    oswald_hip_ctx *ctx = nullptr;
-    check(bring_up(o, &ctx), "device bring-up");
     check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space");
+    {   // (the chunk slots too, before the clock: a piece is a run of groups of one chunk)
+        uint32_t mg = 0;
+        for (const oswald::Chunk &c : db.chunks) mg = std::max<uint32_t>(mg, (uint32_t)c.n.size());
+        if (db.max_chunk_vD) check(oswald_hip_reserve_chunks(ctx, -1, db.max_chunk_vD, mg, (uint32_t)W, (uint32_t)nq, 3), "device work space");
+    }
     check(oswald_hip_set_scoring(ctx, sm, o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
     check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");
@@ -491,10 +543,10 @@ int do_search_hybrid(Options &o)
         keep.push_back(std::move(l));
         return keep.back()->handle;
     };
-    auto gpu_search = [&](int dev, int handle) {
-        check(oswald_hip_chunk_search(ctx, dev, handle, nullptr), "chunk search");
-        check(oswald_hip_chunk_release(ctx, dev, handle), "chunk release");
-    };
+    // (the slot is given back separately, AFTER the next piece's upload has been queued: the release returns when the piece's own
+    // upload has landed, and the next piece must be on the link by then)
+    auto gpu_search = [&](int dev, int handle) { check(oswald_hip_chunk_search(ctx, dev, handle, nullptr), "chunk search"); };
+    auto gpu_release = [&](int dev, int handle) { check(oswald_hip_chunk_release(ctx, dev, handle), "chunk release"); };
     auto cpu_groups = [&](uint64_t g0, uint64_t g1, int32_t *dst, uint64_t dst_row, uint64_t dst_g0, const std::atomic<bool> *cancel = nullptr,
                           std::atomic<uint64_t> *done = nullptr) {
         for (const oswald::Chunk &c : db.chunks) {
@@ -539,10 +591,12 @@ int do_search_hybrid(Options &o)
             const uint64_t cal_bytes = std::min<uint64_t>(8ull << 20, pre[G] / 20); // (a twentieth of a small database at most)
             while (g1 < G && pre[g1] < cal_bytes) ++g1;
             const double t = dwalltime();
+            std::vector<int> test_handles;
             for (uint64_t g = gpu_done; g < g1;) { // (a portion may span chunks)
                 const oswald::Chunk &c = chunk_of(g);
                 const uint64_t e = std::min<uint64_t>(g1, c.accum + c.n.size());
-                gpu_search(0, gpu_upload(0, g, e, keep0));
+                test_handles.push_back(gpu_upload(0, g, e, keep0));
+                gpu_search(0, test_handles.back());
                 g = e;
             }
             // the accelerator's first piece of the rest comes in beside the test search: what follows the test portion in its
@@ -558,6 +612,7 @@ int do_search_hybrid(Options &o)
                 spec_handle = gpu_upload(0, g1, e, keep0);
             }
             check(oswald_hip_wait(ctx, -1), "wait");
+            for (int h : test_handles) gpu_release(0, h);
             const double dt = dwalltime() - t;
             gpu_gcups = cells(gpu_done, g1) / (std::max(dt, 1e-9) * 1e9);
             test_gpu_time += dt;
@@ -637,8 +692,11 @@ int do_search_hybrid(Options &o)
                     const double t0 = dwalltime();
                     gpu_search((int)d, cur);
                     const double t1 = dwalltime();
-                    if (!take_gpu(g0, g1)) break;
-                    cur = gpu_upload((int)d, g0, g1, keep[d]);
+                    const int searched = cur;
+                    const bool more = take_gpu(g0, g1);
+                    if (more) cur = gpu_upload((int)d, g0, g1, keep[d]);
+                    gpu_release((int)d, searched);
+                    if (!more) break;
                     if (phases) fprintf(stderr, "[oswald] device %u at %.1f ms: search + release calls %.1f ms, next piece %.1f MiB queued in %.1f ms\n", d, (t0 - tick) * 1e3, (t1 - t0) * 1e3,
                                         (double)(pre[g1] - pre[g0]) / 1048576.0, (dwalltime() - t1) * 1e3);
                 }
@@ -797,51 +855,6 @@ std::vector<std::vector<Piece>> dealt_pieces(const oswald::Database &db, unsigne
     return per_dev;
 }
 
-// The first piece of a device is what nothing can hide: its upload, its re-tile and the planning of its search all happen
-// before the device has anything to do (7 ms of a 349-ms search at 1 M sequences).  A piece of more than 32 MiB is
-// therefore cut into a head of about a twelfth of its bytes -- whole 128-sequence blocks; in a sorted database its
-// shortest sequences, a search of ~10 ms -- and the rest, which comes in and is planned while the head is searched.
-void split_first_piece(std::vector<Piece> &v)
-{
-    // (OSWALD_SPLIT_FIRST_PIECE_BYTES: the size from which a first piece is cut; a test hook -- the test databases are small)
-    const char *env = getenv("OSWALD_SPLIT_FIRST_PIECE_BYTES");
-    const uint64_t min_bytes = env ? strtoull(env, nullptr, 10) : (32ull << 20);
-    if (v.empty() || v[0].bytes < min_bytes || v[0].ngroups < 24) return;
-    const uint64_t W = oswald::kFpgaVectorLength;
-    const Piece &p = v[0];
-    uint32_t g = 0;
-    while (g + 8 < p.ngroups && p.disp[g] < p.bytes / 12) g += 8;
-    if (g == 0 || g + 8 >= p.ngroups) return;
-    const uint64_t head_seqs = (uint64_t)g * W;
-    if (head_seqs >= p.nvalid) return; // (cannot happen in a sorted database: the padding lanes are at the very end)
-    Piece head, rest;
-    head.b = p.b; head.bytes = p.disp[g]; head.n = p.n; head.disp = p.disp; head.ngroups = g;
-    rest.b = p.b + p.disp[g]; rest.bytes = p.bytes - p.disp[g]; rest.n = p.n + g; rest.ngroups = p.ngroups - g;
-    rest.owned_disp.resize(rest.ngroups);
-    for (uint32_t k = 0; k < rest.ngroups; ++k) rest.owned_disp[k] = p.disp[g + k] - p.disp[g];
-    head.first_index = p.first_index; head.nvalid = (uint32_t)head_seqs;
-    rest.first_index = p.first_index + (uint32_t)head_seqs; rest.nvalid = p.nvalid - (uint32_t)head_seqs;
-    if (!p.index_map.empty()) {
-        head.index_map.assign(p.index_map.begin(), p.index_map.begin() + head_seqs);
-        rest.index_map.assign(p.index_map.begin() + head_seqs, p.index_map.end());
-    }
-    // (the residues stay where they are: in the mapped cache, or in the piece's own buffer, which moves into `rest`)
-    Piece old = std::move(v[0]);
-    rest.owned_b = std::move(old.owned_b);
-    rest.owned_n = std::move(old.owned_n);
-    const std::vector<uint32_t> old_disp = std::move(old.owned_disp);
-    if (!old_disp.empty()) { // the head's displacements were the old piece's own vector: keep a copy of its first g entries
-        head.owned_disp.assign(old_disp.begin(), old_disp.begin() + g);
-        head.disp = nullptr;
-    }
-    v[0] = std::move(rest);
-    v.insert(v.begin(), std::move(head));
-    // pointers into moved vectors: moving a std::vector keeps its buffer, so b / n still point at the residues / lengths;
-    // the displacement tables are re-pointed here
-    v[0].disp = v[0].owned_disp.empty() ? v[0].disp : v[0].owned_disp.data();
-    v[1].disp = v[1].owned_disp.data();
-}
-
 int do_search(Options &o)
 {
     if (o.execution_mode == 2) return do_search_host_only(o);
@@ -861,11 +874,7 @@ int do_search(Options &o)
     oswald_hip_ctx *ctx = nullptr;
     check(bring_up(o, &ctx), "device bring-up");
     lap("device bring-up");
-    for (unsigned d = 0; d < o.num_devices; ++d) {
-        uint64_t fits = 0;
-        check(oswald_hip_max_chunk_size(ctx, (int)d, (uint32_t)nq, oswald::kMaxSequenceLength, &fits), "chunk size limit");
-        if (fits < o.max_chunk_size) o.max_chunk_size = fits;
-    }
+    clamp_chunk_size(o, ctx, nq);
     lap("chunk size limit");
 
     // The report needs the top-r scores per query only.  For r <= 1024 they are selected on the devices, chunk by
@@ -875,18 +884,27 @@ int do_search(Options &o)
     const bool device_top = o.top <= 1024;
     oswald::Database db = oswald::assemble_multiple_chunks_db(o.db, oswald::kFpgaVectorLength, o.max_chunk_size, device_top ? 1 : o.num_devices);
     lap("load database + assemble chunks");
+    PinnedResidues pinned(db);
+    lap("page-lock the residues");
     print_header(o, db);
     if (db.sequences_count < o.top) o.top = db.sequences_count;
     std::vector<std::vector<Piece>> pieces;
     if (device_top) {
+        // (a device's first piece is cut into a head and the rest by the library, at its upload: oswald_hip_chunk_upload_async)
         pieces = o.num_devices > 1 ? dealt_pieces(db, o.num_devices, o.max_chunk_size, std::max(o.cpu_threads, 1)) : contiguous_pieces(db);
-        for (auto &v : pieces) split_first_piece(v);
         lap("deal blocks to the devices");
     }
     std::vector<int32_t> scores;
     if (!device_top) scores.assign(nq * db.vect_sequences_count * W, 0);
     std::vector<std::vector<int32_t>> tmp(o.num_devices);
     check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space"); // buffers sized before the clock starts, FPGAsearch.c:85-96
+    if (device_top)
+        for (unsigned d = 0; d < pieces.size(); ++d) { // ... the chunk slots' too: the largest piece of the device, one slot more than it keeps in flight
+            uint64_t mb = 0;
+            uint32_t mg = 0;
+            for (const Piece &p : pieces[d]) { mb = std::max(mb, p.bytes); mg = std::max(mg, p.ngroups); }
+            if (mb) check(oswald_hip_reserve_chunks(ctx, (int)d, mb, mg, (uint32_t)W, (uint32_t)nq, (uint32_t)std::min<size_t>(pieces[d].size() + 1, 4)), "device work space");
+        }
     lap("device work space");
 
     const double tick = dwalltime();
@@ -906,9 +924,9 @@ int do_search(Options &o)
         // (two rounds ahead: the copies of round k+2 run beside the search of round k, its re-tile -- a kernel, for which the
         // persistent search grid leaves no room -- when that search drains; the host meanwhile plans and queues round k+1,
         // so the device goes from one search into the next without waiting for the host)
-        std::vector<std::vector<int>> h(3, std::vector<int>(o.num_devices, -1));
+        std::vector<std::vector<int>> h(4, std::vector<int>(o.num_devices, -1));
         auto upload = [&](size_t k) {
-            std::vector<int> &hk = h[k % 3];
+            std::vector<int> &hk = h[k % 4];
             // one thread per device (the C ABI allows concurrent calls for DIFFERENT devices of a context): with N devices
             // driven one after the other, device N-1 would get its search N-1 plans late (~1 ms each)
 #pragma omp parallel for num_threads((int)pieces.size()) schedule(static, 1) if (pieces.size() > 1)
@@ -921,23 +939,25 @@ int do_search(Options &o)
             }
             lap("  queue uploads of a round");
         };
-        // The first search starts as soon as its own upload is in.  Behind the search of round k the upload of round k+1
-        // is queued if it is not yet, and -- from the second round on, when a search of full length is running -- that of
-        // round k+2 (with pageable sources an upload call holds the host for the milliseconds of its staging: behind the
-        // short head search only the one upload the next search waits for).
+        // The first search is queued as soon as its own upload is (the library cuts a large first piece in two, so that the device
+        // starts on its head while the rest is still on the link).  Behind the search of round k the uploads of rounds k+1 and
+        // k+2 are queued: from page-locked memory an upload call returns at once, and the copy stream runs ahead of the searches.
         size_t next_up = 0;
         upload(next_up++);
         for (size_t k = 0; k < rounds; ++k) {
-            std::vector<int> &cur = h[k % 3];
+            std::vector<int> &cur = h[k % 4];
 #pragma omp parallel for num_threads((int)pieces.size()) schedule(static, 1) if (pieces.size() > 1)
-            for (unsigned d = 0; d < pieces.size(); ++d) {
-                if (cur[d] < 0) continue;
-                check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search"); // (plans and queues the search behind the piece's upload; waits for nothing)
-                check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release");        // (the upload has landed; the device re-uses the slot when it is through with it)
-            }
+            for (unsigned d = 0; d < pieces.size(); ++d)
+                if (cur[d] >= 0) check(oswald_hip_chunk_search(ctx, (int)d, cur[d], nullptr), "chunk search"); // (plans and queues the search behind the piece's upload; waits for nothing)
             lap("  queue searches of a round");
-            const size_t ahead = k == 0 ? k + 1 : k + 2;
+            const size_t ahead = k + 2;
             while (next_up <= ahead && next_up < rounds) upload(next_up++);
+            // the slot goes back LAST: the call returns when the piece's upload has landed (its re-tile runs when the search before
+            // it drains), and the uploads of the rounds to come must be on the link by then, not behind that wait
+#pragma omp parallel for num_threads((int)pieces.size()) schedule(static, 1) if (pieces.size() > 1)
+            for (unsigned d = 0; d < pieces.size(); ++d)
+                if (cur[d] >= 0) check(oswald_hip_chunk_release(ctx, (int)d, cur[d]), "chunk release");
+            lap("  slots of the round given back");
         }
         // top lists of all queries (inside the timed region: they stand for the download of the score table)
         std::vector<int32_t> ms(nq * o.top);

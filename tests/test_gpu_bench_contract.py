@@ -36,6 +36,10 @@ def test_bench_line_schema(first_pass):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["gpu_scores_equal_on_sample"] is True
     assert d["value"] > 100 and d["dtype"] == "int16"
+    # the reference's own timed region (upload + kernels + download), measured in the same run over its own timed steps
+    i = d["inclusive"]
+    assert i["unit"] == "GCUPS" and i["steps"] == 2 and i["value"] == d["value_inclusive"] and 0 < i["value"] <= 1.05 * d["value"] and "FPGAsearch.c:80-276" in i["what"]
+    assert len(d["ranks"]) == 1 and d["ranks"][0]["pci_bus_id"] != "unknown" and d["ranks"][0]["device_count"] >= 1
 
 
 def _bench(args, env):
@@ -61,6 +65,9 @@ def test_bench_sharded_ranks_rehearsal(first_pass):
     assert one["config"]["chunks_rank0"] >= 3 and two["config"]["chunks_rank0"] >= 2          # several chunks, dealt round-robin
     assert two["config"]["db_residues_total"] == one["config"]["db_residues_total"]            # one database, not one per rank
     assert two["top1_scores"] == one["top1_scores"] and two["value"] > 100 and two["config"]["shard_rule"] == "deal"
+    # every rank says what it ran on and how long its steps took (the first line from a real multi-GPU node explains itself)
+    assert [r["rank"] for r in two["ranks"]] == [0, 1] and all(r["pci_bus_id"] != "unknown" and r["device_count"] >= 1 and r["shard_residues"] > 0 and r["ms_per_step"] > 0 for r in two["ranks"])
+    assert sum(r["shard_residues"] for r in two["ranks"]) == two["config"]["db_residues_total"] and two["rank_ms_per_step"]["max"] >= two["rank_ms_per_step"]["min"] > 0
     ref = _bench(["--gpus", "2", "--shard-rule", "reference"] + common, dict(env, OSWALD_BENCH_BACKEND="gloo", MASTER_PORT="29612"))
     assert ref["top1_scores"] == one["top1_scores"] and ref["config"]["db_residues_total"] == one["config"]["db_residues_total"]
     assert "chunk rule" in ref["config"]["sharding"] and ref["config"]["chunks_rank0"] >= 2
@@ -117,6 +124,13 @@ def test_bench_two_gpus_over_rccl(first_pass):
     assert c["collective_backend"] == "RCCL (nccl)" and c["collective_ranks"] == 2 and c["collective_via"] == "torch.distributed.all_gather"
     assert "oswald_hip_comm_init_rank failed" in c["collective_note"]
     assert d["top_equals_single_gpu_golden"] is True and d["top1_scores"] == gold
+    # ... and the partial case: ONE rank reports a failure, the other holds a working communicator -- both must give it up
+    # (oswald_hip_comm_destroy) before the lists go through torch, or the rank that kept it would all-gather alone inside oswald_hip_topr
+    d = _bench(common, dict(env, MASTER_PORT="29628", OSWALD_BENCH_FAIL_LIB_COMM="rank:1"))
+    c = d["config"]
+    assert c["collective_ranks"] == 2 and c["collective_via"] == "torch.distributed.all_gather" and "another rank" in c["collective_note"]
+    assert d["top_equals_single_gpu_golden"] is True and d["top1_scores"] == gold
+    assert len(d["ranks"]) == 2 and d["rank_ms_per_step"]["distinct_devices"] == 2 and all(r["device_count"] >= 2 for r in d["ranks"])
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--gather", "lib"], cwd=ROOT, capture_output=True, text=True, timeout=900,
                        env=dict(env, MASTER_PORT="29627", OSWALD_BENCH_FAIL_LIB_COMM="1"))
     assert r.returncode != 0 and "communicator could not be made" in r.stderr

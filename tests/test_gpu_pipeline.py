@@ -131,3 +131,185 @@ def test_pipeline_beside_running_searches(oracle):
             ctx.wait()
             for k in range(len(chunks)):
                 np.testing.assert_array_equal(outs[k][:, :want[k].shape[1]], want[k][:, :outs[k].shape[1]])
+
+
+def _toplists(want, nvalid, r):
+    """descending score, ties by descending database index (utils.c:3-86), over the real sequences"""
+    sc, ix = [], []
+    for q in range(want.shape[0]):
+        key = np.sort((want[q, :nvalid].astype(np.int64) << 32) | np.arange(nvalid))[::-1][:r]
+        sc.append((key >> 32).astype(np.int32))
+        ix.append(key & 0xFFFFFFFF)
+    return np.array(sc), np.array(ix)
+
+
+@pytest.mark.parametrize("use_map", [False, True])
+def test_first_chunk_cut_in_two_by_the_library(oracle, monkeypatch, use_map):
+    """An asynchronous upload of some size that finds its device idle is cut by the library into a head of whole
+    128-sequence blocks and the rest (two copies, two re-tiles, two searches behind one another).  Nothing of it
+    shows at the boundary: one handle, one score table, one index (first index or map), chunk-level and context-level
+    top lists, geometry, release -- all against the oracle, and the same chunk uploaded synchronously (never cut)."""
+    from oswald_amd import capi
+    monkeypatch.setenv("OSWALD_HIP_SPLIT_BYTES", "20000")
+    qs = synth.make_queries([33, 150, 301], seed=81)
+    bfull, nfull, dfull, parts = _chunks(2100, qs, 1 << 30, seed=82)
+    assert len(parts) == 1
+    b, n, disp, first, nvalid = parts[0]
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = _want("cut", oracle, qs, bfull, nfull, dfull, sm, 10, 2)
+    rng = np.random.default_rng(5)
+    index_map = rng.permutation(nvalid).astype(np.uint32) + 1000 if use_map else None
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        whole = ctx.chunk_upload(b, n, disp, 16)                    # synchronous: one piece
+        g_whole = ctx.chunk_geometry(whole)
+        ctx.chunk_release(whole)
+        ctx.wait()
+        for rep in range(3):
+            ctx.topr_begin(12)
+            h = ctx.chunk_upload(b, n, disp, 16, wait=False)        # the device is idle: cut in two
+            ctx.chunk_set_index(h, 7, nvalid, index_map)
+            out = np.full((len(qs), len(n) * 16), -3, np.int32)
+            ctx.chunk_search(h, out)
+            sc, ix = ctx.topr(12)
+            ctx.wait()
+            np.testing.assert_array_equal(out, want)
+            g = ctx.chunk_geometry(h)
+            assert g["blocks"] == g_whole["blocks"] and g["col4_live"] == g_whole["col4_live"]
+            wsc, wix = _toplists(want, nvalid, 12)
+            if use_map:   # keys are (score, database index): re-rank the oracle's table on the mapped indices
+                wsc, wix = [], []
+                for q in range(len(qs)):
+                    key = np.sort((want[q, :nvalid].astype(np.int64) << 32) | index_map.astype(np.int64))[::-1][:12]
+                    wsc.append((key >> 32).astype(np.int32)); wix.append(key & 0xFFFFFFFF)
+                wsc, wix = np.array(wsc), np.array(wix)
+            else:
+                wix = wix + 7
+            np.testing.assert_array_equal(sc, wsc)
+            np.testing.assert_array_equal(ix.astype(np.int64), wix)
+            csc, cix = ctx.chunk_topr(h, nvalid, 12)                # chunk-level list: indices inside the chunk
+            psc, pix = _toplists(want, nvalid, 12)
+            np.testing.assert_array_equal(csc, psc)
+            np.testing.assert_array_equal(cix.astype(np.int64), pix)
+            ctx.chunk_release(h)
+
+
+def test_registered_mapping_is_uploaded_by_dma(oracle, tmp_path):
+    """The CLI's path of round 5: the database lives in a read-only private file mapping (the group cache), page-locked
+    in place with oswald_hip_host_register; chunks are slices of it, uploaded asynchronously two ahead, searched and
+    released; tables and top lists against the oracle.  (Registered memory makes the uploads plain DMA: profiles/r05_pin_probe.txt.)"""
+    from oswald_amd import capi
+    qs = synth.make_queries([120, 260, 77, 410], seed=91)
+    bfull, nfull, dfull, parts = _chunks(3000, qs, 150000, seed=92)
+    assert len(parts) >= 5
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = _want("registered", oracle, qs, bfull, nfull, dfull, sm, 10, 2)
+    path = tmp_path / "groups.bin"
+    np.concatenate([p[0] for p in parts]).tofile(path)
+    mm = np.memmap(path, dtype=np.uint8, mode="r")        # PROT_READ mapping of the file
+    offs = np.concatenate([[0], np.cumsum([p[0].size for p in parts])])
+    nvalid = sum(p[4] for p in parts)
+    with capi.Context(1) as ctx:
+        reg = capi.Registered(mm)
+        try:
+            ctx.set_scoring(sm, 10, 2)
+            ctx.set_queries(a, m, ad)
+            for rep in range(2):
+                outs = [np.full((len(qs), len(p[1]) * 16), -3, np.int32) for p in parts]
+                ctx.topr_begin(10)
+                hs = {}
+                def up(k):
+                    hs[k] = ctx.chunk_upload(mm[offs[k]:offs[k + 1]], parts[k][1], parts[k][2], 16, wait=False)
+                    ctx.chunk_set_index(hs[k], parts[k][3], parts[k][4])
+                up(0)
+                for k in range(len(parts)):
+                    ctx.chunk_search(hs[k], outs[k])
+                    ctx.chunk_release(hs[k])
+                    for j in (k + 1, k + 2):
+                        if j < len(parts) and j not in hs:
+                            up(j)
+                sc, ix = ctx.topr(10)
+                ctx.wait()
+                np.testing.assert_array_equal(np.concatenate(outs, axis=1), want)
+                wsc, wix = _toplists(want, nvalid, 10)
+                np.testing.assert_array_equal(sc, wsc)
+                np.testing.assert_array_equal(ix.astype(np.int64), wix)
+        finally:
+            reg.close()
+
+
+def test_replanned_chunk_does_not_overwrite_queues_in_use(oracle):
+    """upload X (async); search X while the upload is in flight (plan on the group lengths, queue set 1); search X
+    again at once (the upload has landed: a re-plan on the live extents would go to set 0 -- the library keeps the plan the
+    running search uses); release X; upload Y into the slot; search Y -- whose plan must not land in a set a search of X is
+    still pulling from.  No wait anywhere in between; many rounds; every table against the oracle."""
+    from oswald_amd import capi
+    qlens = synth.default_query_lengths()[:8]
+    qs = synth.make_queries(qlens)
+    plan = synth.DatabasePlan(24000, qs, synth.SEED_DB, 6)
+    from oswald_amd import multigpu
+    shard = multigpu.ShardedDatabase(plan, 16, 3 << 20, 1, 0, "reference")
+    chunks = [shard.chunk(k) for k in range(len(shard.mine))]
+    assert len(chunks) >= 3
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = [oracle.search_chunk_simd(a, m, ad, c["b"], c["n"], c["disp"].astype(np.uint32), 16, sm, 10, 2, 256, oracle.max_threads())[0] for c in chunks]
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        for rep in range(4):
+            outs = [[np.full((len(qs), len(c["n"]) * 16), -3, np.int32) for _ in range(2)] for c in chunks]
+            for k, c in enumerate(chunks):
+                h = ctx.chunk_upload(c["b"], c["n"], c["disp"], 16, wait=False)
+                ctx.chunk_search(h, outs[k][0])
+                ctx.chunk_search(h, outs[k][1])
+                ctx.chunk_release(h)
+            ctx.wait()
+            for k in range(len(chunks)):
+                for o in outs[k]:
+                    np.testing.assert_array_equal(o[:, :want[k].shape[1]], want[k][:, :o.shape[1]])
+
+
+def test_one_call_search_is_asynchronous(oracle):
+    """oswald_hip_search_chunk_async returns without waiting for its upload (the reference's four
+    clEnqueueWriteBuffer per device are non-blocking, FPGAsearch.c:180-198): with two context devices the second call is
+    made -- and returns -- while the first device's chunk is still on the link.  A chunk of ~190 MB from page-locked
+    memory takes ~3.4 ms to copy; both calls together must return in a fraction of the time until the devices are through."""
+    import time
+    from oswald_amd import capi
+    qs = synth.make_queries([24], seed=3)
+    rng = np.random.default_rng(77)
+    ngroups, cols = 4096, 2912                      # 4096 groups of 16 sequences of 2912 residues: 190 MB
+    n = np.full(ngroups, cols, np.uint16)
+    disp = (np.arange(ngroups, dtype=np.uint64) * cols * 16).astype(np.uint32)
+    b = rng.integers(0, 20, size=ngroups * cols * 16, dtype=np.uint8)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = oracle.search_chunk_simd(a, m, ad, b, n, disp, 16, sm, 10, 2, 256, oracle.max_threads())[0]
+    with capi.Context(2, [0, 0]) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        ctx.reserve(cols)
+        hb = [capi.pinned_copy(x) for x in (b, n, disp)]
+        outs = [capi.HostBuffer((1, ngroups * 16), np.int32) for _ in range(2)]
+        best = None
+        for rep in range(4):
+            for o in outs:
+                o.a[...] = -3
+            ctx.wait()
+            t0 = time.perf_counter()
+            ctx.search_chunk_async(hb[0].a, hb[1].a, hb[2].a, outs[0].a, 16, dev=0)
+            ctx.search_chunk_async(hb[0].a, hb[1].a, hb[2].a, outs[1].a, 16, dev=1)
+            t_calls = time.perf_counter() - t0
+            ctx.wait()
+            t_all = time.perf_counter() - t0
+            for o in outs:
+                np.testing.assert_array_equal(o.a, want)
+            if rep > 0 and (best is None or t_calls / t_all < best[0] / best[1]):   # (the first pass allocates the slots)
+                best = (t_calls, t_all)
+        assert best[0] < 0.5 * best[1], f"the two calls held the host {best[0] * 1e3:.2f} ms of the {best[1] * 1e3:.2f} ms until both devices were through"
+        for x in hb + outs:
+            x.close()
