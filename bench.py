@@ -153,7 +153,14 @@ def main():
     # runtime's few hardware queues with torch's.  torch.distributed is what N > 1 needs torch for (rendezvous, barrier, MAX of the
     # elapsed times); a single rank needs none of it: its barrier is the library's own wait for every stream it has.
     from oswald_amd import capi, multigpu
-    ngpu_visible = capi.device_count()
+    torch = None
+    if world > 1:
+        # (torch first: it brings its own copy of the HIP runtime, and a process in which the library has loaded the system's copy
+        # before torch initialises finds "no HIP GPUs" in torch; loaded second, the library shares torch's)
+        import torch
+        ngpu_visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    else:
+        ngpu_visible = capi.device_count()
     if ngpu_visible <= 0:
         raise SystemExit("bench.py needs a GPU: the search path is HIP only (no CPU fallback)")
     # one rank per GPU over RCCL ("nccl").  OSWALD_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
@@ -162,10 +169,8 @@ def main():
     backend = os.environ.get("OSWALD_BENCH_BACKEND", "nccl")
     gpu = local_rank % ngpu_visible
     dist = None
-    torch = None
     dev = coll_dev = None
     if world > 1:
-        import torch
         torch.cuda.set_device(gpu)
         dev = torch.device("cuda", gpu)
         if backend == "nccl" and world > torch.cuda.device_count():
