@@ -552,7 +552,10 @@ def cpu_baseline(args, a, m, a_disp, chunks, ctx, sm, wl, sum_m):
     import pyoracle
     from oswald_amd import dblayout
     W = args.cpu_lanes
-    threads = pyoracle.max_threads()
+    # the host threads this process may really keep busy: the box gives its container a CPU quota (16 CPUs' worth of a 256-thread host on
+    # the round-5 pool) -- a team beyond it is throttled for most of every scheduling period, and `cores` would name threads that never ran
+    from oswald_amd import hostinfo
+    threads = max(1, min(pyoracle.max_threads(), hostinfo.usable_cpus()))
     gpu_tables = pcie_inclusive.last_scores
 
     def sample(stride):
@@ -597,7 +600,7 @@ def cpu_baseline(args, a, m, a_disp, chunks, ctx, sm, wl, sum_m):
     gpu = np.concatenate([tab[:, p] for tab, p in zip(gpu_tables, picks)], axis=1)[:, order]
     equal = bool(np.array_equal(gpu, sc_cpu[:, :gpu.shape[1]]))
     nsamp = int(sum(len(p) for p in picks))
-    return {"value": round(sum_m * dres / t / 1e9, 3), "unit": "GCUPS", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+    return {"value": round(sum_m * dres / t / 1e9, 3), "unit": "GCUPS", "cores": threads, "host_threads_visible": pyoracle.max_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"every {stride}-th {W}-lane group of each of rank 0's {len(chunks)} chunks = of the whole benched database ({nsamp} sequences, {dres} residues, "
                       f"mean length {dres / max(nsamp, 1):.0f}) x all {len(m)} queries, {'AVX2' if W == 32 else 'SSE4.1'} int8->int16->int32 port, block 256, {t:.1f} s",
             "gpu_scores_equal_on_sample": equal,

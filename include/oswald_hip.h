@@ -190,6 +190,11 @@ int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk);
 int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                                   const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int32_t *scores_out);
 
+/* Blocks until the LAST SEARCH queued for this chunk is through (its upload, its kernels, its top list; the download of its score
+ * table, if one was asked for) -- whatever else has been queued on the device behind it meanwhile.  Replaces the
+ * clWaitForEvents on one device's kernel events, FPGAsearch.c:223, for a caller that keeps the device's queue filled ahead. */
+int oswald_hip_chunk_wait(oswald_hip_ctx *ctx, int dev, int chunk);
+
 /* Blocks until everything queued on `dev` has finished (dev < 0: all devices).
  * Replaces clFinish / clWaitForEvents, FPGAsearch.c:197, :223, :279. */
 int oswald_hip_wait(oswald_hip_ctx *ctx, int dev);

@@ -29,6 +29,7 @@ SYMBOLS = (
     "oswald_hip_comm_unique_id", "oswald_hip_comm_init_rank", "oswald_hip_comm_info", "oswald_hip_max_chunk_size",
     "oswald_hip_host_alloc", "oswald_hip_host_free", "oswald_hip_rerun_stats",
     "oswald_hip_host_register", "oswald_hip_host_unregister", "oswald_hip_comm_destroy", "oswald_hip_reserve_chunks",
+    "oswald_hip_chunk_wait",
 )
 COMM_ID_BYTES = 128   # OSWALD_HIP_COMM_ID_BYTES
 
@@ -65,6 +66,7 @@ def load():
     lib.oswald_hip_rerun_counts.argtypes = [vp, i32, C.POINTER(u64)]
     lib.oswald_hip_chunk_search.argtypes = [vp, i32, i32, vp]
     lib.oswald_hip_chunk_release.argtypes = [vp, i32, i32]
+    lib.oswald_hip_chunk_wait.argtypes = [vp, i32, i32]
     lib.oswald_hip_search_chunk_async.argtypes = [vp, i32, vp, u64, vp, vp, u32, u32, vp]
     lib.oswald_hip_wait.argtypes = [vp, i32]
     lib.oswald_hip_chunk_topr.argtypes = [vp, i32, i32, u32, u32, vp, vp]
@@ -246,6 +248,10 @@ class Context:
             assert out.dtype == np.int32 and out.flags.c_contiguous
             self._keep.append(out)
         _chk(self.lib.oswald_hip_chunk_search(self.h, dev, chunk, _ptr(out)))
+
+    def chunk_wait(self, chunk: int, dev: int = 0):
+        """Blocks until the chunk's last search is through (whatever has been queued behind it)."""
+        _chk(self.lib.oswald_hip_chunk_wait(self.h, dev, chunk))
 
     def chunk_release(self, chunk: int, dev: int = 0):
         _chk(self.lib.oswald_hip_chunk_release(self.h, dev, chunk))

@@ -1588,6 +1588,20 @@ int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b
     return r;
 }
 
+int oswald_hip_chunk_wait(oswald_hip_ctx *ctx, int dev, int chunk)
+{
+    if (int r = check_chunk(ctx, dev, chunk)) return r;
+    Device &d = ctx->dev[dev];
+    HIP_TRY(hipSetDevice(d.id));
+    for (int k = chunk; k >= 0; k = d.chunks[k].next) {
+        Chunk &c = d.chunks[k];
+        if (int r = finish_upload(d, c)) return r;
+        if (c.use_pending) { HIP_TRY(hipEventSynchronize(c.ev_use)); c.use_pending = false; }
+        if (c.down_pending) { HIP_TRY(hipEventSynchronize(c.ev_down)); c.down_pending = false; }
+    }
+    return 0;
+}
+
 int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");

@@ -12,6 +12,8 @@
 #include <nmmintrin.h>
 
 #include <fcntl.h>
+#include <sched.h>
+#include <thread>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -450,6 +452,47 @@ Database assemble_multiple_chunks_db(const std::string &sequences_filename, int 
     return db;
 }
 
+unsigned usable_cpus(const char *cgroup_root)
+{
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+    if (n == 0) n = 1;
+    const std::string root = cgroup_root ? cgroup_root : "/sys/fs/cgroup";
+    // cgroup v2: "<quota> <period>" or "max <period>", in the process's own group and in every group above it (inside a container
+    // the mount point IS the container's group); cgroup v1: two files
+    std::vector<std::string> dirs = {root};
+    {
+        std::ifstream f("/proc/self/cgroup");
+        std::string line;
+        while (std::getline(f, line))
+            if (line.rfind("0::", 0) == 0) {
+                std::string path = line.substr(3);
+                while (!path.empty() && path != "/") {
+                    dirs.push_back(root + path);
+                    const size_t k = path.find_last_of('/');
+                    path = k == std::string::npos || k == 0 ? "" : path.substr(0, k);
+                }
+            }
+    }
+    for (const std::string &d : dirs) {
+        std::ifstream f(d + "/cpu.max");
+        std::string q;
+        double period = 0;
+        if (f >> q >> period && q != "max" && period > 0) {
+            const double cpus = atof(q.c_str()) / period;
+            if (cpus > 0) n = std::min<unsigned>(n, std::max(1u, (unsigned)cpus));
+        }
+    }
+    {
+        std::ifstream fq(root + "/cpu/cpu.cfs_quota_us"), fp(root + "/cpu/cpu.cfs_period_us");
+        double quota = 0, period = 0;
+        if (fq >> quota && fp >> period && quota > 0 && period > 0) n = std::min<unsigned>(n, std::max(1u, (unsigned)(quota / period)));
+    }
+    return n;
+}
+
 std::vector<std::pair<const void *, size_t>> residue_ranges(const Database &db)
 {
     std::vector<std::pair<const void *, size_t>> r;
@@ -530,6 +573,8 @@ int oswald_host_preprocess(const char *fasta, const char *out, int threads, uint
 }
 
 uint8_t oswald_host_encode(uint8_t c) { return oswald::encode_residue(c); }
+
+unsigned oswald_host_usable_cpus(const char *cgroup_root) { return oswald::usable_cpus(cgroup_root); }
 
 const int8_t *oswald_host_submat(const char *name) { return oswald::submat_by_name(name); }
 

@@ -124,6 +124,13 @@ std::vector<std::string> load_database_headers(const std::string &sequences_file
 // one std::string per database sequence.  Lines the file does not have come back empty, like above.
 std::vector<std::string> load_database_headers_at(const std::string &sequences_filename, const std::vector<uint64_t> &indices);
 
+// Hardware threads this process may really keep busy: those of its affinity mask, and no more than its cgroup's CPU
+// bandwidth allows (cgroup v2 cpu.max / v1 cpu.cfs_quota_us: a container of 16 CPUs' worth on a 256-thread host shows 256
+// threads, and a team of 128 is throttled for the rest of every 100-ms period once it has burnt the quota -- round 5 found
+// the hybrid mode's 10-ms accelerator test taking 90 ms that way).  cgroup_root: where the cgroup file
+// system is mounted (tests point it elsewhere).  The reference takes -c as given (arguments.h:27).
+unsigned usable_cpus(const char *cgroup_root = "/sys/fs/cgroup");
+
 // The r best entries of scores[0..n) in the order the reference's sort_scores
 // leaves them: descending score, ties by descending index.
 void top_scores(const int32_t *scores, uint64_t n, uint64_t r, std::vector<int32_t> &out_scores, std::vector<uint64_t> &out_index);

@@ -281,6 +281,17 @@ void clamp_chunk_size(Options &o, oswald_hip_ctx *ctx, uint64_t nq)
 }
 
 // -m 2: every group on the host cores; no accelerator call at all.
+// -c as asked for, but no more threads than the process may keep busy (see usable_cpus: beyond a container's CPU quota a team
+// is throttled for most of every scheduling period)
+int team_size(const Options &o, unsigned reserve = 0)
+{
+    const unsigned hw = oswald::usable_cpus();
+    const int room = hw > reserve ? (int)(hw - reserve) : 1;
+    const int want = std::max(o.cpu_threads, 1);
+    if (want > room) fprintf(stderr, "oswald: %d host threads (-c %d asked for; the process may keep %u hardware threads busy)\n", room, want, hw);
+    return std::min(want, room);
+}
+
 int do_search_host_only(Options &o)
 {
     const time_t current_time = time(nullptr);
@@ -292,9 +303,10 @@ int do_search_host_only(Options &o)
     print_header(o, db);
     if (db.sequences_count < o.top) o.top = db.sequences_count;
     std::vector<int32_t> scores(nq * db.vect_sequences_count * W, 0);
+    const int threads = team_size(o);
     const double tick = dwalltime();
     for (const oswald::Chunk &c : db.chunks)
-        oswald::host_search_groups(q, c, 0, c.n.size(), (int)W, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, o.cpu_threads, scores.data(),
+        oswald::host_search_groups(q, c, 0, c.n.size(), (int)W, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, threads, scores.data(),
                                    db.vect_sequences_count * W, c.accum * W, o.cpu_vector_length);
     const double work_time = dwalltime() - tick;
     std::vector<std::vector<int32_t>> top_s;
@@ -357,6 +369,7 @@ int do_search_hybrid_static(Options &o)
             for (uint64_t g = std::max(g0, c.accum); g < std::min<uint64_t>(g1, c.accum + c.n.size()); ++g) v += (uint64_t)c.n[g - c.accum] * W;
         return v;
     };
+    const int static_team = team_size(o, 2 * o.num_devices + 2);
     // searches database groups [g0, g1) on the accelerator(s), chunk by chunk, into the score table
     auto gpu_groups = [&](uint64_t g0, uint64_t g1) {
         std::vector<GroupRun> runs;
@@ -386,7 +399,7 @@ int do_search_hybrid_static(Options &o)
                           std::atomic<uint64_t> *done = nullptr) {
         for (const oswald::Chunk &c : db.chunks) {
             const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
-            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, o.cpu_threads, dst, dst_row, (a0 - dst_g0) * W, o.cpu_vector_length,
+            if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, static_team, dst, dst_row, (a0 - dst_g0) * W, o.cpu_vector_length,
                                                     cancel, done);
         }
     };
@@ -499,15 +512,18 @@ int do_search_hybrid(Options &o)
     print_header(o, db);
     if (db.sequences_count < o.top) o.top = db.sequences_count;
     const int8_t *sm = oswald::submat_by_name(o.submat);
-    // The host's team leaves a hardware thread to every thread that drives an accelerator (and one to the rest of the process):
-    // with -c = all hardware threads the accelerators' calls -- a pageable upload is staged by the CPU -- waited for a time
-    // slice, and the search ran at half speed.  The report prints the -c that was asked for.
+    // The host's team leaves a hardware thread to every thread that drives an accelerator (and one to the rest of the process),
+    // out of the hardware threads the process may really keep busy (oswald::usable_cpus: its affinity mask AND its cgroup's CPU
+    // bandwidth).  Round 4 saw the accelerator's 10-ms test take 130 - 190 ms with -c 96 ... 128 "although a quarter of the cores
+    // were idle": the box gives its container 16 CPUs' worth of a 256-thread host, and a team that burns the quota of a 100-ms
+    // period in its first 12 ms is throttled -- every thread of the process, the one that drives the accelerator included --
+    // for the rest of it (round 5, profiles/r05_cli_hybrid.txt).  The report prints the -c that was asked for.
     int host_threads = std::max(o.cpu_threads, 1);
     {
-        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned hw = oswald::usable_cpus();
         const int room = hw > 2 * o.num_devices + 2 ? (int)(hw - 2 * o.num_devices - 2) : 1; // (a driving thread and a runtime thread per accelerator, two for the rest)
-        if (hw && host_threads > room) {
-            fprintf(stderr, "oswald: hybrid mode runs the host part on %d threads (-c %d asked for, %u hardware threads, %u of them drive the accelerators)\n", room, host_threads, hw, o.num_devices);
+        if (host_threads > room) {
+            fprintf(stderr, "oswald: hybrid mode runs the host part on %d threads (-c %d asked for; the process may keep %u hardware threads busy, %u of them drive the accelerators)\n", room, host_threads, hw, o.num_devices);
             host_threads = room;
         }
     }
@@ -592,11 +608,16 @@ int do_search_hybrid(Options &o)
             while (g1 < G && pre[g1] < cal_bytes) ++g1;
             const double t = dwalltime();
             std::vector<int> test_handles;
+            const bool tphases = getenv("OSWALD_DEBUG_PHASES") != nullptr;
+            auto stamp = [&](const char *what) { if (tphases) fprintf(stderr, "[oswald] accelerator test thread at %7.2f ms: %s\n", (dwalltime() - tick_test) * 1e3, what); };
+            stamp("started");
             for (uint64_t g = gpu_done; g < g1;) { // (a portion may span chunks)
                 const oswald::Chunk &c = chunk_of(g);
                 const uint64_t e = std::min<uint64_t>(g1, c.accum + c.n.size());
                 test_handles.push_back(gpu_upload(0, g, e, keep0));
+                stamp("test portion's upload queued");
                 gpu_search(0, test_handles.back());
+                stamp("test portion's search queued");
                 g = e;
             }
             // the accelerator's first piece of the rest comes in beside the test search: what follows the test portion in its
@@ -610,8 +631,14 @@ int do_search_hybrid(Options &o)
                 while (e < c.accum + c.n.size() && (double)(pre[e + 1] - pre[g1]) <= cap) ++e;
                 spec_g1 = e;
                 spec_handle = gpu_upload(0, g1, e, keep0);
+                // ... and its search is queued behind the test portion's at once: the device goes from one into the other, while
+                // this thread waits for the test portion alone (round 4 waited for the device, then planned the piece -- 2.5 ms of
+                // host work at 1 M sequences -- with the device idle)
+                gpu_search(0, spec_handle);
+                stamp("first piece of the rest queued, upload and search");
             }
-            check(oswald_hip_wait(ctx, -1), "wait");
+            for (int h : test_handles) check(oswald_hip_chunk_wait(ctx, 0, h), "wait for the test portion");
+            stamp("the device is through with the test portion");
             for (int h : test_handles) gpu_release(0, h);
             const double dt = dwalltime() - t;
             gpu_gcups = cells(gpu_done, g1) / (std::max(dt, 1e-9) * 1e9);
@@ -683,14 +710,16 @@ int do_search_hybrid(Options &o)
         for (unsigned d = 0; d < o.num_devices; ++d)
             devs.emplace_back([&, d] {
                 uint64_t g0, g1;
-                int cur = d == 0 ? spec_handle : -1; // (device 0 holds the piece that came in beside the test search)
+                int cur = d == 0 ? spec_handle : -1; // (device 0 holds the piece that came in beside the test search ...
+                bool queued = cur >= 0;               //  ... and whose search is queued already)
                 if (cur < 0) {
                     if (!take_gpu(g0, g1)) return;
                     cur = gpu_upload((int)d, g0, g1, keep[d]);
                 }
                 for (;;) { // search the piece in hand, then bring the next one in beside it
                     const double t0 = dwalltime();
-                    gpu_search((int)d, cur);
+                    if (!queued) gpu_search((int)d, cur);
+                    queued = false;
                     const double t1 = dwalltime();
                     const int searched = cur;
                     const bool more = take_gpu(g0, g1);
@@ -891,7 +920,7 @@ int do_search(Options &o)
     std::vector<std::vector<Piece>> pieces;
     if (device_top) {
         // (a device's first piece is cut into a head and the rest by the library, at its upload: oswald_hip_chunk_upload_async)
-        pieces = o.num_devices > 1 ? dealt_pieces(db, o.num_devices, o.max_chunk_size, std::max(o.cpu_threads, 1)) : contiguous_pieces(db);
+        pieces = o.num_devices > 1 ? dealt_pieces(db, o.num_devices, o.max_chunk_size, (int)std::min<unsigned>((unsigned)std::max(o.cpu_threads, 1), oswald::usable_cpus())) : contiguous_pieces(db);
         lap("deal blocks to the devices");
     }
     std::vector<int32_t> scores;

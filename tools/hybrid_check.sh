@@ -6,9 +6,9 @@ T=/tmp/osw_e2e_$N
 [ -f $T/db.info ] || python tools/cli_e2e.py $N $T > /dev/null 2>&1
 oswald_amd/oswald -O search -m 0 -q $T/q.fasta -d $T/db > /tmp/hc_m0.txt
 echo "-m 0: $(grep 'Search speed' /tmp/hc_m0.txt | tr -s '\t' ' ')"
-for c in 4 16 64; do
+for c in ${CS:-4 16 64}; do
   OSWALD_DEBUG_PHASES=1 oswald_amd/oswald -O search -m 1 -c $c -q $T/q.fasta -d $T/db > /tmp/hc_m1.txt 2> /tmp/hc_m1.err
   echo "-m 1 -c $c: $(grep 'estimated\|Search speed' /tmp/hc_m1.txt | tr -s '\t' ' ' | tr '\n' ';')"
-  grep -E "hybrid:|host done" /tmp/hc_m1.err | sed 's/^/      /'
+  grep -E "hybrid:|host done|test thread|held|runs the host part" /tmp/hc_m1.err | sed 's/^/      /'
   diff <(grep -v "Search\|estimated\|Test DB\|CPU threads" /tmp/hc_m0.txt) <(grep -v "Search\|estimated\|Test DB\|CPU threads" /tmp/hc_m1.txt) > /dev/null && echo "      report identical to -m 0's"
 done
