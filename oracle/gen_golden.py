@@ -126,13 +126,30 @@ def gen_alphabet(lib, tmp):
     json.dump({"upper": table, "other_bytes": table_extra}, open(os.path.join(OUT, "alphabet.json"), "w"), indent=1)
 
 
+def strip_uninitialised(lines, fasta_text):
+    """The reference keeps every title with ONE uninitialised byte behind it (titles[i][length] = 0 is written one position too
+    far, sequences.c:116, :333): its .desc lines and in-memory titles end in a byte that differs from run to run.  It is taken
+    off HERE, so that a regenerated fixture is byte-identical to the committed one: a line that is a
+    title line of the FASTA text plus one byte loses that byte.  (When the byte happens to be 0 the line has none to lose: how
+    many were stripped differs from run to run and is printed, not stored.)  -> (lines, how many were stripped)"""
+    titles = {l.encode() for l in fasta_text.split("\n") if l.startswith(">")}
+    out, n = [], 0
+    for l in lines:
+        if l not in titles and l[:-1] in titles:
+            l, n = l[:-1], n + 1
+        out.append(l)
+    return out, n
+
+
 def gen_preprocess(lib, tmp):
     cases = {}
     for name, text in FASTA_CASES.items():
         for threads in (1, 4):
             out, _ = preprocess(lib, tmp, text, f"{name}_{threads}", threads)
+            desc, stripped = strip_uninitialised(out["desc"].split(b"\n"), text)
             cases[f"{name}/threads{threads}"] = {"fasta": text, "threads": threads, "info": out["info"].decode(),
-                                                 "seq_b64": b64(out["seq"]), "desc_b64": b64(out["desc"])}
+                                                 "seq_b64": b64(out["seq"]), "desc_b64": b64(b"\n".join(desc))}
+            print(f"preprocess {name}/threads{threads}: {stripped} uninitialised title bytes stripped")
     json.dump(cases, open(os.path.join(OUT, "preprocess.json"), "w"), indent=1)
 
 
@@ -146,7 +163,9 @@ def gen_queries(lib, tmp):
     m = arr(lib.ref_queries_lengths(), C.c_ushort, nq)
     disp = arr(lib.ref_queries_disp(), C.c_uint, nq + 1)
     a = arr(lib.ref_queries_residues(), C.c_uint8, Q.value)
-    titles = [b64(lib.ref_queries_title(i)) for i in range(nq)]
+    titles, stripped = strip_uninitialised([lib.ref_queries_title(i) for i in range(nq)], text)
+    titles = [b64(t) for t in titles]
+    print(f"queries: {stripped} uninitialised title bytes stripped")
     json.dump({"fasta": text, "nq": int(nq), "Q": int(Q.value), "m": m.tolist(), "disp": disp.tolist(), "a": a.tolist(), "titles_b64": titles},
               open(os.path.join(OUT, "queries.json"), "w"), indent=1)
 
@@ -201,7 +220,9 @@ def gen_layout(lib, tmp):
         # the headers as the reference reads them back (for the report)
         if nseq == 17:
             lib.ref_load_headers(db.encode(), C.c_ulong(nseq), meta[f"n{nseq}/k128M_f1"]["maxtitle"])
-            meta["n17/headers_b64"] = [b64(lib.ref_header(i)) for i in range(nseq)]
+            heads, stripped = strip_uninitialised([lib.ref_header(i).rstrip(b"\n") for i in range(nseq)], open(db + ".fasta").read())
+            print(f"headers: {stripped} uninitialised title bytes stripped")
+            meta["n17/headers_b64"] = [b64(h + b"\n") for h in heads]
     np.savez_compressed(os.path.join(OUT, "layout.npz"), **store)
     json.dump(meta, open(os.path.join(OUT, "layout.json"), "w"), indent=1)
 

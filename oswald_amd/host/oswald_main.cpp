@@ -1060,7 +1060,7 @@ int main(int argc, char *argv[])
         {"execution_mode", 'm', "<integer>", 0, "0 for accelerator mode, 1 for hybrid mode (host + accelerator), 2 or host-only for host mode (default: 1).", 3},
         {"cpu_threads", 'c', "<integer>", 0, "Number of CPU threads (default: 4).", 3},
         {"vector_length", 'v', "<integer>", 0, "Vector length in host: 16 (SSE4.1 kernel) or 32 (AVX2 kernel) (default: 16).", 3},
-        {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (accepted for compatibility) (default: 256).", 3},
+        {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (default: 256).  Accepted and printed for compatibility with the reference's command line and report; it has NO effect in this build: the host kernel here streams the database column by column and blocks nothing.", 3},
         {"num_fpgas", 'f', "<integer>", 0, "Number of GPUs (the reference's number of FPGAs) (default: 1).", 3},
         {"max_chunk_size", 'k', "<integer>", 0, "Maximum chunk size on the accelerator (bytes, default: 134217728).", 3},
         {"db_percentage", 'p', "<integer>", 0, "Database percentage for testing computational power (hybrid mode only) (default: 0.01).  An upper bound in this build: the host's test is called off once the GPU's is over, and the host is rated on what it finished; the ratings then only size the pieces -- host and GPU take work from the two ends of the database until they meet.", 3},
