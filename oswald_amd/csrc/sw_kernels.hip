@@ -527,14 +527,20 @@ typedef CellQueryPair<ArithI16B> CellPK16BQ;
 typedef CellSeqPair<ArithI16S<false>> CellPK16S;
 typedef CellQueryPair<ArithI16S<true>> CellPK16SQ;
 
-// Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.
-// Compiler-scheduled throughout (rare path: re-run of saturated lanes).
+// Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.  Compiler-scheduled (rare path: the re-run of
+// what reached the int16 cells' ceiling; whole searches with cell_bits = 32), but since round 5 in the COLUMN-FRAME formulation
+// of the int16 cell (see ArithI16S): every value of database column j is stored as  true + (j + G) * ge,  so the horizontal gap
+// needs no decay and the vertical one comes out of its maximum, and the zero floors are the third operand of a v_max3_i32:
+//   x = D + S + ge (one frame on: v_add3_u32);  H = max3(x, E, F);  u = H - go;  E = max3(E, u, fl1);  F = max3(F, u, fl1) - ge;
+//   cm = max(cm, H)                                   -- 7 instructions + the unpacking of S per row of 64 cells (12.4 before)
+// fl1 = "zero" in the frame of column j + 1; the round turns the column's maximum cm back into a true score (cm - fl).  int32
+// has room for any frame: 65535 columns x ge <= 32767 < 2^31.  `goe` carries the gap OPEN penalty for this cell.
 struct CellI32 {
     typedef int T;
     typedef int GapT;
     static constexpr bool kFast = false;
     static constexpr uint32_t kFloorBits = 0;
-    static constexpr bool kShifted = false;
+    static constexpr bool kShifted = true; // (framed values travel between strips: run_item's pad columns hold the frame's zero)
     static constexpr int kRows = OSW_RMAX32;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
     static constexpr int kCodes = 32;
@@ -544,35 +550,35 @@ struct CellI32 {
     static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
     static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
-    // (the compiler-scheduled round asks the cell for its representation of "zero": the 8-bit cell's depends on the scoring system)
-    static __device__ __forceinline__ uint32_t zero_bits(GapT) { return 0u; }
     static __device__ __forceinline__ T score_init(GapT) { return 0; }
-    template <int R>
-    static __device__ __forceinline__ void init_state(T (&D)[R], T (&E)[R], T &top_prev, GapT)
-    {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { D[r] = 0; E[r] = 0; }
-        top_prev = 0;
-    }
 
+    // The profile slice of a round is INTERLEAVED over the G lane groups (round 5): entry (row-block rb, code, group g) at
+    // ((rb * 32 + code) * G + g) * 8 bytes.  These kernels run at wide geometries -- the re-run at G = 64: every lane a strip of
+    // its own, i.e. a table of its own -- and with the tables one behind the other 32 lanes read 32 different tables at
+    // code-dependent places: ~4 lanes per 8-byte slot, every ds_read_b64 several times its two LDS cycles.  Interleaved, a lane's
+    // slot is (code * G + g) mod 32 = g mod 32 for G >= 32: the 32 lanes of a hardware half never collide, whatever their residues.
+    static constexpr bool kInterleaved = true;
+    // fl1: zero in the frame of the NEXT column; cm: the column's maximum in this column's frame (written by row 0);
+    // base: LDS address of the lane group's first entry (region + 8 g); G: lane groups of the geometry
     template <int R>
-    static __device__ __forceinline__ void column(uint32_t base, uint32_t codes, int half, T (&D)[R], T (&E)[R],
-                                                  T top_prev, T &f, T &hl, GapT goe, GapT ge, T &score)
+    static __device__ __forceinline__ void column(uint32_t base, uint32_t G, uint32_t codes, int half, T (&D)[R], T (&E)[R],
+                                                  T top_prev, T &f, T &hl, GapT go, GapT ge, T fl1, T &cm)
     {
-        const lds_cp lp = (lds_cp)(uintptr_t)(base + ((codes >> (half * 8)) & 0xffu));
+        const lds_cp lp = (lds_cp)(uintptr_t)(base + ((codes >> (half * 8)) & 0xffu) * G); // (`tiled` holds 8 * code)
         T diag = top_prev;
 #pragma unroll
         for (int rb = 0; rb < R / 4; ++rb) {
-            const u32x2 p = *(lds_u2p)(lp + rb * 256);
+            const u32x2 p = *(lds_u2p)(lp + rb * 256 * G);
             const int s[4] = {(int)(short)(p.x & 0xffffu), (int)p.x >> 16, (int)(short)(p.y & 0xffffu), (int)p.y >> 16};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = rb * 4 + k;
-                T h = vmax(vmax(diag + s[k], E[r]), f);
-                const T t = vmax(h - goe, 0);
-                E[r] = vmax(vmax(E[r] - ge, 0), t);
-                f = vmax(vmax(f - ge, 0), t);
-                score = vmax(score, h);
+                const T x = diag + s[k] + ge; // the diagonal sits one frame back
+                const T h = vmax(vmax(x, E[r]), f);
+                const T u = h - go;
+                E[r] = vmax(vmax(E[r], u), fl1);
+                f = vmax(vmax(f, u), fl1) - ge;
+                cm = r == 0 ? h : vmax(cm, h);
                 if (r + 1 < R) { diag = D[r + 1]; D[r + 1] = h; } else { hl = h; }
             }
         }
@@ -605,6 +611,10 @@ static __device__ __forceinline__ int osw_physical_lane(int l)
     const int r = (l >> 2) & 3, h = (l >> 4) & 1, b = (r << 1) | (h ^ ((r ^ (r >> 1)) & 1));
     return (l & 32) | (b << 2) | (l & 3);
 }
+
+// cells whose profile slice is interleaved over the lane groups (CellI32::kInterleaved)
+template <class C, class = void> struct osw_interleaved : std::false_type {};
+template <class C> struct osw_interleaved<C, std::enable_if_t<C::kInterleaved>> : std::true_type {};
 
 static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 {
@@ -881,40 +891,70 @@ static __device__ __forceinline__ void sw_round_q8f(const uint16_t *tcol, uint32
     score = (sc & gp.L) | (fl & gp.G);
 }
 
-// Compiler-scheduled version of the same round (int32 cell).
+// Compiler-scheduled version of the same round (int32 cell, column frames: see CellI32).  The inputs of a step -- the
+// column's residues and, behind a first round, the boundary entry of the round before -- are loaded OSW_PLAIN_AHEAD steps
+// ahead (round 5; the loads used to be issued in the step that needs them).
+#ifndef OSW_PLAIN_AHEAD
+#define OSW_PLAIN_AHEAD 4u
+#endif
 template <class C, int R>
 static __device__ __forceinline__ void sw_round_plain(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
                                                       const uint2 * /*top_pages*/, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
                                                       typename C::GapT goe, typename C::GapT ge, typename C::T &score)
 {
     typedef typename C::T T;
-    T D[R], E[R], top_prev;
-    C::template init_state<R>(D, E, top_prev, goe);
-    const uint32_t zb = C::zero_bits(goe); // H / F of a row above that does not exist, as they travel between strips
+    const uint32_t g = (uint32_t)lane / gl;
+    const T go = goe - ge; // (the cell wants the gap OPEN penalty)
+    // "zero" in the frame of this lane's current column: the lane starts at column -g, whose frame offset is (G - g) * ge
+    T fl = (T)((G - g) * (uint32_t)ge), fl_prev = fl - ge;
+    T D[R], E[R], top_prev = fl_prev;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { D[r] = fl_prev; E[r] = fl; }
     const bool g0 = (uint32_t)lane < gl;
     const bool glast = (uint32_t)lane >= 64u - gl;
     const int src = ((lane - (int)gl) & 63) << 2;
     const uint16_t *tb = tcol + u;
     uint2 *col = bnd + OSW_SCRATCH_DATA + u;
     const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
-    uint32_t hand_h = zb, hand_f = zb, hand_c = dummy;
+    uint32_t hand_h = (uint32_t)fl, hand_f = (uint32_t)fl, hand_c = dummy;
     const uint32_t nsteps = ncols + G - 1;
-#pragma unroll 1
-    for (uint32_t t = 0; t < nsteps; ++t) {
-        uint32_t codes = dummy, topb = zb, fb = zb;
+    uint32_t cq[OSW_PLAIN_AHEAD];
+    uint2 bq[OSW_PLAIN_AHEAD];
+    uint32_t bv[OSW_PLAIN_AHEAD]; // the boundary entry was read (else: the frame's zero)
+    auto load_step = [&](uint32_t t, uint32_t &c, uint2 &bb, uint32_t &valid) {
+        c = dummy;
+        bb = make_uint2(0u, 0u);
+        valid = 0;
         if (t < ncols) {
-            codes = tb[(size_t)t * 64];
-            if (!first) { const uint2 b = col[(size_t)t * gl]; topb = b.x; fb = b.y; }
+            c = tb[(size_t)t * 64];
+            if (!first) { bb = col[(size_t)t * gl]; valid = 1; }
         }
-        if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
-        T f = C::from_bits(fb), hl;
-        C::template column<R>(base, codes, half, D, E, top_prev, f, hl, goe, ge, score);
-        top_prev = C::from_bits(topb);
-        if (!last && t + 1 >= G && glast) col[(size_t)(t + 1 - G) * gl] = make_uint2(C::to_bits(hl), C::to_bits(f));
-        if (G > 1) {
-            hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(hl));
-            hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(f));
-            hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < OSW_PLAIN_AHEAD; ++k) load_step(k, cq[k], bq[k], bv[k]);
+#pragma unroll 1
+    for (uint32_t tg = 0; tg < nsteps; tg += OSW_PLAIN_AHEAD) {
+#pragma unroll
+        for (uint32_t k = 0; k < OSW_PLAIN_AHEAD; ++k) {
+            const uint32_t t = tg + k;
+            if (t < nsteps) {
+                // the row above: the round before's boundary entry, or -- a first round, a column past the block -- zero in this column's frame
+                uint32_t codes = cq[k], topb = bv[k] ? bq[k].x : (uint32_t)fl, fb = bv[k] ? bq[k].y : (uint32_t)fl;
+                load_step(t + OSW_PLAIN_AHEAD, cq[k], bq[k], bv[k]);
+                if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
+                T f = C::from_bits(fb), hl, cm;
+                const T fl1 = fl + ge;
+                C::template column<R>(base, G, codes, half, D, E, top_prev, f, hl, go, ge, fl1, cm);
+                score = C::vmax(score, cm - fl);
+                fl = fl1;
+                top_prev = C::from_bits(topb);
+                if (!last && t + 1 >= G && glast) col[(size_t)(t + 1 - G) * gl] = make_uint2(C::to_bits(hl), C::to_bits(f));
+                if (G > 1) {
+                    hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(hl));
+                    hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(f));
+                    hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
+                }
+            }
         }
     }
 }
@@ -982,6 +1022,20 @@ static __device__ __forceinline__ void fill_profile_slice(const E *prof_q, uint3
     }
 }
 
+// The same slice INTERLEAVED over the lane groups (CellI32): entry (row-block rb, code, group g) at (rb * NC + code) * G + g.
+template <class E, uint32_t NC = 32u>
+static __device__ __forceinline__ void fill_profile_slice_interleaved(const E *prof_q, uint32_t rb0, uint32_t rbg, uint32_t G, uint32_t rb_end, E *dst,
+                                                                      uint32_t tid, uint32_t nthr)
+{
+    const uint32_t per_group = rbg * NC, total = per_group * G;
+    for (uint32_t i = tid; i < total; i += nthr) {
+        const uint32_t g = i & (G - 1), e = i / G; // (G is a power of two; consecutive threads fill consecutive 8-byte slots)
+        const uint32_t rbs = rb0 + g * rbg;
+        const uint32_t valid = rb_end > rbs ? ((rb_end - rbs) < rbg ? (rb_end - rbs) : rbg) * NC : 0u;
+        dst[i] = e < valid ? prof_q[(size_t)rbs * NC + e] : E{};
+    }
+}
+
 // Diagnostics that exist only in the -DOSW_DIAG build of the library (liboswald_hip_diag.so, tools/): per-workgroup
 // time stamps, and a timing experiment that makes every round read the constant top row and store to the trash page
 // (WRONG scores, same instruction stream, no spill traffic).  The shipped library contains neither.
@@ -1046,7 +1100,8 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             __syncthreads(); // every wave is done with the previous slice
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
-            fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
+            if constexpr (osw_interleaved<C>::value) fill_profile_slice_interleaved<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
+            else fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
             __syncthreads();
 #ifdef OSW_DIAG
             if (p.wg_times && lane == 0) atomicAdd(&p.counters_ovf[4], (uint32_t)((__builtin_readcyclecounter() - tb) >> 10));
@@ -1055,11 +1110,13 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             // only this wave touches its region; LDS operations of one wave execute in order, the wave barriers
             // only pin the compiler's order
             __builtin_amdgcn_wave_barrier();
-            fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
+            if constexpr (osw_interleaved<C>::value) fill_profile_slice_interleaved<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
+            else fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
+        const uint32_t base = osw_interleaved<C>::value ? (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (uint32_t)sizeof(Entry))
+                                                        : (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
         sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, p.top_pages, rho == 0 || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
@@ -1271,8 +1328,13 @@ static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, u
                                                          int ge, int &score, volatile uint32_t *prog_src, volatile uint32_t *prog_mine, uint32_t rho)
 {
     typedef CellI32 C;
-    int D[R], E[R], top_prev;
-    C::template init_state<R>(D, E, top_prev, goe);
+    // column frames (see CellI32): "zero" in the frame of this lane's current column; the lane starts at column -g
+    const uint32_t g = (uint32_t)lane / gl;
+    const int go = goe - ge;
+    int fl = (int)((G - g) * (uint32_t)ge), fl_prev = fl - ge;
+    int D[R], E[R], top_prev = fl_prev;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { D[r] = fl_prev; E[r] = fl; }
     const bool g0 = (uint32_t)lane < gl;
     const bool glast = (uint32_t)lane >= 64u - gl;
     const int src = ((lane - (int)gl) & 63) << 2;
@@ -1280,7 +1342,7 @@ static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, u
     const uint2 *colr = src_region + OSW_SCRATCH_DATA + u;
     uint2 *colw = dst_region + OSW_SCRATCH_DATA + u;
     const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
-    uint32_t hand_h = 0, hand_f = 0, hand_c = dummy;
+    uint32_t hand_h = (uint32_t)fl, hand_f = (uint32_t)fl, hand_c = dummy;
     const uint32_t nsteps = ncols + G - 1;
     // The inputs of a step -- the column's residues and, behind a first round, the boundary entry of the round before --
     // are loaded OSW_PIPE_AHEAD steps ahead: a re-run item has one wave per SIMD (its workgroup is alone on its CU more
@@ -1290,22 +1352,24 @@ static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, u
     static_assert(OSW_PIPE_BATCH % AHEAD == 0, "a batch is whole groups of prefetched steps");
     uint32_t cq[AHEAD];
     uint2 bq[AHEAD];
+    uint32_t bv[AHEAD]; // the boundary entry was read (else: the frame's zero)
     auto wait_for = [&](uint32_t cols) { // columns 0 .. cols-1 of round rho - 1 (published under the tag rho) are stored and visible
         const uint32_t need = (rho << 20) | (cols < ncols ? cols : ncols);
         while (*prog_src < need) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    auto load_step = [&](uint32_t t, uint32_t &c, uint2 &bb) {
+    auto load_step = [&](uint32_t t, uint32_t &c, uint2 &bb, uint32_t &valid) {
         c = dummy;
         bb = make_uint2(0u, 0u);
+        valid = 0;
         if (t < ncols) {
             c = tb[(size_t)t * 64];
-            if (!first) bb = colr[(size_t)t * gl];
+            if (!first) { bb = colr[(size_t)t * gl]; valid = 1; }
         }
     };
     if (!first) wait_for(AHEAD);
 #pragma unroll
-    for (uint32_t k = 0; k < AHEAD; ++k) load_step(k, cq[k], bq[k]);
+    for (uint32_t k = 0; k < AHEAD; ++k) load_step(k, cq[k], bq[k], bv[k]);
 #pragma unroll 1
     for (uint32_t t0 = 0; t0 < nsteps; t0 += OSW_PIPE_BATCH) {
         const uint32_t t1 = t0 + OSW_PIPE_BATCH < nsteps ? t0 + OSW_PIPE_BATCH : nsteps;
@@ -1316,11 +1380,14 @@ static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, u
             for (uint32_t k = 0; k < AHEAD; ++k) {
                 const uint32_t t = tg + k;
                 if (t < t1) {
-                    uint32_t codes = cq[k], topb = bq[k].x, fb = bq[k].y;
-                    load_step(t + AHEAD, cq[k], bq[k]);
+                    uint32_t codes = cq[k], topb = bv[k] ? bq[k].x : (uint32_t)fl, fb = bv[k] ? bq[k].y : (uint32_t)fl;
+                    load_step(t + AHEAD, cq[k], bq[k], bv[k]);
                     if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
-                    int f = (int)fb, hl;
-                    C::template column<R>(base, codes, half, D, E, top_prev, f, hl, goe, ge, score);
+                    int f = (int)fb, hl, cm;
+                    const int fl1 = fl + ge;
+                    C::template column<R>(base, G, codes, half, D, E, top_prev, f, hl, go, ge, fl1, cm);
+                    score = cm - fl > score ? cm - fl : score;
+                    fl = fl1;
                     top_prev = (int)topb;
                     if (!last && t + 1 >= G && glast) colw[(size_t)(t + 1 - G) * gl] = make_uint2((uint32_t)hl, (uint32_t)f);
                     if (G > 1) {
@@ -1359,10 +1426,10 @@ static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, 
     for (uint32_t rho = (uint32_t)wv; rho < plan.rounds; rho += NW) {
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
         __builtin_amdgcn_wave_barrier();
-        fill_profile_slice<uint2>(prof_q, rb0, R / 4, G, rb_end, lds_wave, (uint32_t)lane, 64u);
+        fill_profile_slice_interleaved<uint2>(prof_q, rb0, R / 4, G, rb_end, lds_wave, (uint32_t)lane, 64u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_wave + g * (R * C::kRowBytes + (uint32_t)sizeof(uint2)));
+        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_wave + g * (uint32_t)sizeof(uint2));
         const bool first = rho == 0, last = rho + 1 == plan.rounds;
         volatile uint32_t *ps = prog + ((wv + NW - 1) % NW), *pm = prog + wv;
         switch (R) {
@@ -1392,7 +1459,10 @@ static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, 
 // geometry 64 (each lane one strip of the same sequence: the whole wave works
 // on one sequence at a time).  force_all: run `items` (cell_bits = 32 mode).
 // ---------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) void osw_sw_i32(OswSearchArgs p)
+#ifndef OSW_I32_ATTR
+#define OSW_I32_ATTR
+#endif
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) OSW_I32_ATTR void osw_sw_i32(OswSearchArgs p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8];
     const int lane = threadIdx.x & 63;

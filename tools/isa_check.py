@@ -175,11 +175,42 @@ def check_cell_shape(isa):
     return bad
 
 
+def check_int32_cell(isa):
+    """The exact kernels osw_sw_i32 / osw_sw_i32r (compiler-scheduled; round 5: column frames): no scratch at all -- a spill
+    inside their column loops is scratch traffic per cell --, the three-operand integer maximum and the three-operand add of
+    the frame formulation (H = max3(x, E, F), x = D + S + ge: CellI32), and the budget of two waves per SIMD their
+    launches assume (<= 256 VGPRs).  -> list of complaints"""
+    text, bad, counts, fn = "\n".join(isa), [], {}, None
+    for line in isa:
+        m = re.match(r'^(osw_\w+):', line)
+        if m:
+            fn = m.group(1)
+        if fn in ("osw_sw_i32", "osw_sw_i32r") and line.startswith("\t"):
+            op = line.split(";")[0].strip().split(" ")[0]
+            counts.setdefault(fn, {}).setdefault(op, 0)
+            counts[fn][op] += 1
+    for k in ("osw_sw_i32", "osw_sw_i32r"):
+        m = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)' % k, text)
+        m2 = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)' % k, text)
+        if not m or int(m.group(1)) > 256:
+            bad.append("%s needs %s VGPRs" % (k, m.group(1) if m else "?"))
+        if not m2 or int(m2.group(1)) != 0:
+            bad.append("%s spills %s bytes per lane" % (k, m2.group(1) if m2 else "?"))
+        c = counts.get(k, {})
+        if c.get("v_max3_i32", 0) < 100 or c.get("v_add3_u32", 0) < 40:
+            bad.append("%s: %d v_max3_i32, %d v_add3_u32 (the frame formulation has three and one per row)" % (k, c.get("v_max3_i32", 0), c.get("v_add3_u32", 0)))
+        if c.get("scratch_load_dword", 0) or c.get("scratch_store_dword", 0):
+            bad.append("%s has scratch traffic" % k)
+    return bad
+
+
 def check(isa=None):
     """All checks; raises AssertionError with the findings."""
     isa = isa or compile_to_asm()
     shape = check_cell_shape(isa)
     assert not shape, "; ".join(shape)
+    i32 = check_int32_cell(isa)
+    assert not i32, "; ".join(i32)
     for group in GROUPS:
         seen, bad = check_inflight_registers(isa, group)
         assert seen > group["min_asm_uses"], "%s: the asm blocks that use the fixed registers were not found" % (group["kernels"],)
@@ -217,7 +248,8 @@ def stamp():
             "checks": ["in-flight registers untouched by compiler-scheduled code",
                        "; ".join("%s: <= %d VGPRs, <= %d B of scratch outside the column loops" % ("/".join(g["kernels"]), g["budget"], g["scratch"]) for g in GROUPS),
                        "no compiler-issued vector memory (spill traffic included) inside the asm load windows",
-                       "single-query int16 kernels: one v_pk_mad_i16 per row, no v_perm_b32; profile reads are ds_read_b128"]}
+                       "single-query int16 kernels: one v_pk_mad_i16 per row, no v_perm_b32; profile reads are ds_read_b128",
+                       "osw_sw_i32 / osw_sw_i32r: no scratch, <= 256 VGPRs, v_max3_i32 / v_add3_u32 of the column-frame int32 cell"]}
     with open(STAMP, "w") as f:
         json.dump(info, f, indent=1)
     return info
