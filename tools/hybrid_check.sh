@@ -3,7 +3,7 @@
 # report's speed lines at several -c, the phases of the hybrid run, and that the reports are the same (GPU box).
 N=${1:-1000000}
 T=/tmp/osw_e2e_$N
-[ -f $T/db.info ] || python tools/cli_e2e.py $N $T > /dev/null 2>&1
+[ -f $T/db.info ] || python tools/cli_e2e.py $N $T > /dev/null 2>&1   # (tools/final_validation.sh leaves the 1 M database there)
 oswald_amd/oswald -O search -m 0 -q $T/q.fasta -d $T/db > /tmp/hc_m0.txt
 echo "-m 0: $(grep 'Search speed' /tmp/hc_m0.txt | tr -s '\t' ' ')"
 for c in ${CS:-4 16 64}; do
