@@ -67,6 +67,7 @@ struct Tunables {
     bool plan_on_estimates = false;     // OSWALD_HIP_PLAN_EST=1 (experiment): every search is planned on the group-length extents
     bool plan_waits_for_upload = false; // OSWALD_HIP_PLAN_WAITS=1 (test hook): a search waits for its chunk's upload and plans on the live extents (the behaviour before the second session of round 4)
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
+    bool no_direct_table = false;      // OSWALD_HIP_NO_DIRECT_TABLE=1 (A/B and test hook): score tables leave by DMA on the download stream even when the kernels could write them
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
     size_t split_bytes = 32u << 20;    // OSWALD_HIP_SPLIT_BYTES=bytes: from this size on an asynchronous upload that finds its device idle is cut into head + rest (0: never; a small value: test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
@@ -94,6 +95,7 @@ void Tunables::refresh()
     plan_on_estimates = flag("OSWALD_HIP_PLAN_EST");
     no_stream_classes = flag("OSWALD_HIP_NO_STREAM_CLASSES");
     no_pin = flag("OSWALD_HIP_NO_PIN");
+    no_direct_table = flag("OSWALD_HIP_NO_DIRECT_TABLE");
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     split_bytes = (size_t)num("OSWALD_HIP_SPLIT_BYTES", (double)(32u << 20));
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
@@ -1051,8 +1053,7 @@ static int upload_slot(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t 
         // waiting for a wave slot -- held the caller for 7 - 9 ms in a process's first pass)
         HIP_TRY(osw_launch_copy16(c.blocks_pin, c.blocks.p, c.nblocks * sizeof(OswBlock), up));
         ht.lap("upload: block table queued");
-        HIP_TRY(osw_launch_fill(c.tiled.p, OSW_DUMMY_CODE8, (off + OSW_TILED_TAIL_GROUPS) * 64 * sizeof(uint2), up)); // pads = dummy residue
-        ht.lap("upload: fill queued");
+        // (the all-dummy columns around every block are written by the re-tile itself: osw_write_pads)
         // (the base pointer moved back by the bias: base + disp[g] is the group's place in the staging copy)
         // (n[] and disp[] are read where they are: the slot's page-locked copy)
         HIP_TRY(osw_launch_retile((const uint8_t *)c.st_b.p - disp_bias, (const uint16_t *)c.nd_pin.p, (const uint32_t *)((const char *)c.nd_pin.p + disp_off),
@@ -1297,7 +1298,8 @@ static int search_plan(oswald_hip_ctx *ctx, Device &d, Chunk &c, PhaseTimer &pt,
     return 0;
 }
 
-static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht)
+// table_dev: the caller's score table as the device addresses it (columns of this slot: already offset), or null
+static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht, int32_t *table_dev, size_t table_stride)
 {
     if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return topr_after_search(ctx, d, c); }
     if (!d.bnd.p || d.bnd_stride == 0) return fail(OSWALD_HIP_ESTATE, "device %d has no spill scratch (an earlier allocation failed)", d.id);
@@ -1323,6 +1325,9 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     a.bnd_stride = d.bnd_stride + OSW_SCRATCH_DATA;
     a.scores = (int32_t *)c.scores.p;
     a.score_stride = c.score_stride;
+    a.scores_host = table_dev;
+    a.host_stride = (uint32_t)table_stride;
+    a.host_cols = c.ngroups * c.W;
     a.counters = (uint32_t *)d.counters.p;
     a.counters_ovf = (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT;
     a.ovf_items = (uint2 *)c.ovf.p;
@@ -1535,14 +1540,24 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
             pt.lap("search: pin caller's table");
         }
     }
+    // A table in page-locked memory is WRITTEN BY THE KERNELS as they finish their items (round 5): no copy, no download stream,
+    // no event between a search and the next one -- a table that left by DMA behind its search cost a one-query search 0.3 ms
+    // per chunk (0.17 ms before the next search could start, 0.1 ms in the search itself: profiles/r05_inclusive_probe_q1.txt).
+    // Anything else (a small pageable table, OSWALD_HIP_NO_DIRECT_TABLE) leaves by DMA as before.
+    int32_t *table_dev = nullptr;
+    if (scores_out && out_stride && out_stride <= 0xffffffffull && !ctx->tun.no_direct_table) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, scores_out, 0) == hipSuccess && dp) table_dev = (int32_t *)dp;
+        else (void)hipGetLastError();
+    }
     // a chunk the library cut in two at its upload: head, then rest, behind one another on the device
     size_t col0 = 0;
     for (int k = chunk; k >= 0; k = d.chunks[k].next) {
         Chunk &c = d.chunks[k];
         if (int r = search_plan(ctx, d, c, pt, ht)) return r;
-        if (int r = search_launch(ctx, d, c, ht)) return r;
+        if (int r = search_launch(ctx, d, c, ht, table_dev ? table_dev + col0 : nullptr, out_stride)) return r;
         if (pt.on) { HIP_TRY(hipStreamSynchronize(d.stream)); pt.lap("search: kernels"); }
-        if (scores_out) if (int r = search_download(ctx, d, c, scores_out, out_stride, col0, pt, ht)) return r;
+        if (scores_out && !table_dev) if (int r = search_download(ctx, d, c, scores_out, out_stride, col0, pt, ht)) return r;
         col0 += (size_t)c.ngroups * c.W;
     }
     return 0;

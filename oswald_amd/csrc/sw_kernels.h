@@ -150,6 +150,12 @@ struct OswSearchArgs {
     uint64_t bnd_stride;       // uint2 per region (OSW_SCRATCH_DATA + columns x lanes per group)
     int32_t *scores;           // [nq][score_stride]
     uint32_t score_stride;
+    // the caller's table, when it lies in page-locked memory the device can write (oswald_hip_host_alloc / _register, or pinned by
+    // the library for the call): every score is ALSO stored there by the kernel that computes it -- column seq of row q at
+    // scores_host[q * host_stride + seq] for seq < host_cols (the chunk's ngroups x W lanes; a wave block's padding lanes beyond them
+    // have no place in the caller's row) -- and no copy, no download stream and no event stand between a search and the next one
+    int32_t *scores_host;
+    uint32_t host_stride, host_cols;
     uint32_t *counters;        // this launch's queue counters (OSW_CTR_*)
     uint32_t *counters_ovf;    // shared by all launches of a search: [0] = items queued for the int32 kernel, [1] = for the int16 re-run
     const uint32_t *nitems_dev;// packed-int16 kernels: if set, the number of workgroup entries is read from the device (re-run queue of the 8-bit pass)

@@ -1143,6 +1143,23 @@ static __device__ __forceinline__ void set_wave_prio(uint32_t prio)
     }
 }
 
+// A score goes to the device's table (the top lists are selected there, the re-run tiers overwrite what they redo) and, if the
+// caller's table is page-locked, straight into it as well (OswSearchArgs::scores_host): 4 bytes per (query, sequence) over the link.
+static __device__ __forceinline__ void osw_store_score(const OswSearchArgs &p, uint32_t q, size_t seq, int v)
+{
+    p.scores[(size_t)q * p.score_stride + seq] = v;
+    if (p.scores_host && seq < p.host_cols) p.scores_host[(size_t)q * p.host_stride + seq] = v;
+}
+static __device__ __forceinline__ void osw_store_score2(const OswSearchArgs &p, uint32_t q, size_t seq /* even */, int2 v)
+{
+    *(int2 *)(p.scores + (size_t)q * p.score_stride + seq) = v;
+    if (p.scores_host) {
+        int32_t *h = p.scores_host + (size_t)q * p.host_stride + seq;
+        if (seq + 1 < p.host_cols && (((uintptr_t)h) & 7u) == 0) *(int2 *)h = v;
+        else { if (seq < p.host_cols) h[0] = v.x; if (seq + 1 < p.host_cols) h[1] = v.y; }
+    }
+}
+
 // Scores of one packed 16-bit item: written for the lanes of group 0; lanes at
 // the ceiling of the cell arithmetic are queued for the exact int32 kernel.
 template <class A>
@@ -1155,7 +1172,7 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
         int2 out;
         out.x = A::to_int(score.x);
         out.y = A::to_int(score.y);
-        *(int2 *)(p.scores + (size_t)q * p.score_stride + blk.seq0 + 2 * lam) = out;
+        osw_store_score2(p, q, (size_t)blk.seq0 + 2 * lam, out);
         const uint32_t hm = (A::over(score.x) ? 1u : 0u) | (A::over(score.y) ? 2u : 0u);
         if (hm) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
@@ -1176,8 +1193,8 @@ static __device__ __forceinline__ void pk16q_finish(const OswSearchArgs &p, uint
         const uint32_t qa = p.pair_q[2 * pair], qb = p.pair_q[2 * pair + 1];
         const size_t seq = (size_t)blk.seq0 + 2 * lam + half;
         const int sa = A::to_int(score.x), sb = A::to_int(score.y);
-        p.scores[(size_t)qa * p.score_stride + seq] = sa;
-        p.scores[(size_t)qb * p.score_stride + seq] = sb;
+        osw_store_score(p, qa, seq, sa);
+        osw_store_score(p, qb, seq, sb);
         if (A::over(score.x)) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(qa, lam, 6u, 1u << half), B);
@@ -1486,7 +1503,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) OSW_I32_ATTR void osw_sw
             if (!((hm >> half) & 1u)) continue;
             const int score = run_item<CellI32>(p, p.prof, q, B, blk, sigma, lg, lane, half, false, lds_wave, bnd_wave, p.goe, p.ge);
             if ((uint32_t)lane < gl)
-                p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
+                osw_store_score(p, q, (size_t)blk.seq0 + 2 * (sigma * gl + lane) + half, score);
         }
     }
 }
@@ -1523,7 +1540,7 @@ extern "C" __global__ __launch_bounds__(OSW_I32R_WAVES * 64) void osw_sw_i32r(Os
             if (!((hm >> half) & 1u)) continue;
             const int score = run_item_i32_pipe<OSW_I32R_WAVES>(p, q, B, blk, sigma, lg, lane, wv, half, lds_wave, bnd_wg, prog, red);
             if (wv == 0 && (uint32_t)lane < gl)
-                p.scores[(size_t)q * p.score_stride + blk.seq0 + 2 * (sigma * gl + lane) + half] = score;
+                osw_store_score(p, q, (size_t)blk.seq0 + 2 * (sigma * gl + lane) + half, score);
         }
     }
 }
@@ -1569,8 +1586,8 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 6) OSW8_COMPILER_VGPRS v
             rb.x = (int)((score >> 8) & 0x7fu) - off;  // B . s0
             ra.y = (int)((score >> 16) & 0x7fu) - off; // A . s1
             rb.y = (int)((score >> 24) & 0x7fu) - off; // B . s1
-            *(int2 *)(p.scores + (size_t)qa * p.score_stride + seq) = ra;
-            *(int2 *)(p.scores + (size_t)qb * p.score_stride + seq) = rb;
+            osw_store_score2(p, qa, seq, ra);
+            osw_store_score2(p, qb, seq, rb);
             if (!(lane & 3)) { // (gl < 4: the other lanes of the quad belong to other items, which queue it again if they flag: harmless)
                 // one workgroup entry of the packed-int16 kernel: its four waves take the four lanes of the quad at
                 // geometry 64 (every lane group 1/64 of the query: the shortest critical path the kernel offers)
@@ -1682,6 +1699,23 @@ static __device__ __forceinline__ uint32_t osw_original_code(uint32_t slot)
     return (w >> (8u * (slot & 3u))) & 0xffu;
 }
 
+// The all-dummy columns around a block -- OSW_TILED_PAD_GROUPS groups behind it (and, block 0, in front of it; the last block,
+// the readable tail too): what the lane groups of the search kernels warm up, prefetch and drain through.  Written by the block's
+// own re-tile workgroup since round 5: until then a fill kernel wrote the WHOLE buffer with dummies first (a second pass over
+// 128 MiB per chunk, and one more kernel that wants wave slots while the search before is draining).
+static __device__ __forceinline__ void osw_write_pads(uint16_t *__restrict__ tiled, const OswBlock &blk, uint32_t B, uint32_t nblocks, uint32_t t)
+{
+    const uint32_t D = OSW_DUMMY_CODE8 * 0x01010101u;
+    const uint4 v = make_uint4(D, D, D, D);
+    uint4 *behind = (uint4 *)(tiled + ((size_t)blk.col4_off + blk.ncols4_alloc) * 4 * 64); // 8 x 16 B per column
+    const uint32_t n_behind = (OSW_TILED_PAD_GROUPS + (B + 1 == nblocks ? OSW_TILED_TAIL_GROUPS : 0)) * 4 * 8;
+    for (uint32_t k = t; k < n_behind; k += 256) behind[k] = v;
+    if (B == 0) {
+        uint4 *front = (uint4 *)tiled;
+        for (uint32_t k = t; k < blk.col4_off * 4 * 8; k += 256) front[k] = v;
+    }
+}
+
 extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__restrict__ b, const uint16_t *__restrict__ n,
                                                               const uint32_t *__restrict__ disp, uint32_t ngroups, uint32_t W,
                                                               const OswBlock *__restrict__ blocks, uint16_t *__restrict__ tiled)
@@ -1689,6 +1723,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile(const uint8_t *__re
     OSW_SEARCH_SHAPED_VGPRS();
     const uint32_t B = blockIdx.x;
     const OswBlock blk = blocks[B];
+    osw_write_pads(tiled, blk, B, gridDim.x, threadIdx.x);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t gpb = 128 / W;                  // groups per block
     const uint32_t g = B * gpb + (2 * lane) / W;   // this lane's group
@@ -1728,6 +1763,7 @@ extern "C" __global__ __launch_bounds__(256) void osw_retile16(const uint8_t *__
     const uint32_t B = blockIdx.x, t = threadIdx.x;
     const OswBlock blk = blocks[B];
     if (t < 64) lane_n[t] = 0;
+    osw_write_pads(tiled, blk, B, gridDim.x, t);
     __syncthreads();
     const uint32_t gi = t >> 5, jl = t & 31;      // group of the block (0..7), column inside a run of 32
     const uint32_t g = B * 8 + gi;

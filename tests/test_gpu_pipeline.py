@@ -103,11 +103,18 @@ def test_resident_chunk_is_replanned_on_its_live_extents(oracle):
             np.testing.assert_array_equal(out, want)
 
 
-def test_pipeline_beside_running_searches(oracle):
+@pytest.mark.parametrize("tables", ["pageable (pinned by the library for the call)", "page-locked: written by the kernels", "page-locked, by DMA"])
+def test_pipeline_beside_running_searches(oracle, monkeypatch, tables):
     """The same flow with searches long enough (milliseconds each) for the next chunk's plan and upload to arrive while a
     search is running: 20 queries x 60 000 sequences in chunks of 6 MiB, uploads two chunks ahead.  Checked against the
-    oracle's SIMD port (itself pinned to the reference's goldens in tests/test_oracle_golden.py)."""
+    oracle's SIMD port (itself pinned to the reference's goldens in tests/test_oracle_golden.py).  The score tables reach the
+    caller in three ways: a page-locked table (oswald_hip_host_alloc) is written by the kernels themselves as they finish their
+    items (round 5), a pageable one of this size is pinned by the library for the call and written the same way, and
+    OSWALD_HIP_NO_DIRECT_TABLE=1 sends tables by DMA on the download stream behind every search (the way of rounds 2 - 4, and of
+    small pageable tables still)."""
     from oswald_amd import capi, multigpu
+    if tables.endswith("by DMA"):
+        monkeypatch.setenv("OSWALD_HIP_NO_DIRECT_TABLE", "1")
     qlens = synth.default_query_lengths()
     qs = synth.make_queries(qlens)
     plan = synth.DatabasePlan(60000, qs, synth.SEED_DB, 12)
@@ -121,7 +128,13 @@ def test_pipeline_beside_running_searches(oracle):
         ctx.set_scoring(sm, 10, 2)
         ctx.set_queries(a, m, ad)
         for rep in range(3):
-            outs = [np.full((len(qs), len(c["n"]) * 16), -3, np.int32) for c in chunks]
+            if tables.startswith("pageable"):
+                outs = [np.full((len(qs), len(c["n"]) * 16), -3, np.int32) for c in chunks]
+            else:
+                bufs = [capi.HostBuffer((len(qs), len(c["n"]) * 16), np.int32) for c in chunks]
+                outs = [hb.a for hb in bufs]
+                for o in outs:
+                    o[...] = -3
             hs = {k: ctx.chunk_upload(chunks[k]["b"], chunks[k]["n"], chunks[k]["disp"], 16, wait=False) for k in range(2)}
             for k in range(len(chunks)):
                 ctx.chunk_search(hs[k], outs[k])
