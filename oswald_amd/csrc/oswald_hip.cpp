@@ -1111,15 +1111,23 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     const uint32_t gpb = OSW_BLOCK_SEQS / W;
     uint32_t head_groups = 0;
     if (async && ctx->tun.split_bytes && vD >= ctx->tun.split_bytes && ngroups >= 3 * gpb && disp[0] == 0 && device_is_idle(d)) {
-        double sum_m = 0;
-        if (ctx->have_queries) for (uint16_t m : ctx->m) sum_m += m;
+        double sum_m = 0, max_m = 0;
+        if (ctx->have_queries) for (uint16_t m : ctx->m) { sum_m += m; max_m = std::max<double>(max_m, m); }
         const double frac = std::min(0.5, std::max(1.0 / 12.0, sum_m > 0 ? 1.0 / (1.0 + sum_m / 200.0) : 1.0 / 12.0));
+        // ... and two searches instead of one end twice: the last items of a launch run on a GPU that is emptying, and an item --
+        // a query against a block -- lasts as long as the query is long (one 5000-residue query against 100 000 sequences, 38 MB:
+        // cut in two the pass took 22.4 instead of 19.4 ms for 0.6 ms of copy hidden).  The cut is made only where what it hides --
+        // the rest's share of the copy at the link's ~57 GB/s -- clearly exceeds two such endings
+        // (~ longest query x mean columns x 6.5 instructions x 4 cycles x 3 waves per SIMD / 128 cells, at 2.3 GHz).
+        const double mean_cols = (double)vD / ((double)ngroups * W);
+        const double gain_ms = (1.0 - frac) * (double)vD / 57.0e6, loss_ms = 2.0 * max_m * mean_cols * 6.5 * 4.0 * 3.0 / 128.0 / 2.3e6 * (ctx->nq > 1 ? 2.0 : 1.0);
+        const bool pays = gain_ms >= 1.5 * loss_ms || ctx->tun.split_bytes < (1u << 20); // (a split size below 1 MiB is the tests' hook: always)
         uint32_t g = gpb;
         while (g + gpb < ngroups && (double)disp[g + gpb] <= frac * (double)vD) g += gpb;
         // (the reference's layout: the groups back to back in order -- anything else is uploaded in one piece)
         bool in_order = true;
         for (uint32_t k = 0; k + 1 < ngroups && in_order; ++k) in_order = (uint64_t)disp[k] + (uint64_t)n[k] * W <= disp[k + 1];
-        if (in_order && g + gpb <= ngroups && disp[g] > 0 && disp[g] < vD) head_groups = g;
+        if (pays && in_order && g + gpb <= ngroups && disp[g] > 0 && disp[g] < vD) head_groups = g;
     }
     if (head_groups == 0) {
         int slot = -1;
