@@ -419,11 +419,11 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     // brought over by ONE kernel that reads the staging buffer in place -- no copy engine, nothing pageable: round 5 found the
     // six little hipMemcpyAsync from the context's std::vectors holding the caller for 8.6 ms of a 25-ms search (the runtime
     // stages a pageable copy on the caller's thread, and the copy engine was busy with the chunk coming in).
-    const bool alt_ = first_pass_is_frame(ctx), q8_ = first_pass_is_q8(ctx);
+    const bool alt_ = first_pass_is_frame(ctx), q8_ = first_pass_is_q8(ctx), i32_ = ctx->cell_bits == 32; // (the hand-scheduled int32 cell reads S + ge too)
     const uint32_t np_ = (uint32_t)ctx->pair_len.size();
     const size_t prof8 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096, prof16 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096;
     const size_t pair16 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096, pair8 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint2) + 4096;
-    const size_t pages_bytes = (size_t)(128 + OSW_I16S_TABLE + 64) * 2 * sizeof(uint32_t);
+    const size_t pages_bytes = (size_t)(128 + OSW_I16S_TABLE + 64 + (i32_ ? OSW_I32F_TABLE : 0u)) * 2 * sizeof(uint32_t);
     struct Slice { DevBuf *buf; size_t bytes; const void *src; size_t src_bytes; };
     const Slice slices[] = {// inputs (src: what the staging buffer holds at the slice's offset; top_pages is generated in place below)
                             {&d.queries, ctx->a.size() + 16, ctx->a.data(), ctx->a.size()},
@@ -436,7 +436,7 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
                             {&d.pair_len, np_ ? np_ * sizeof(uint16_t) + 16 : 0, ctx->pair_len.data(), np_ * sizeof(uint16_t)},
                             {&d.top_pages, pages_bytes, nullptr, 0},
                             // built on the device
-                            {&d.prof, prof8, nullptr, 0}, {&d.prof_seq, prof16, nullptr, 0}, {&d.prof_alt, alt_ ? prof8 : 0, nullptr, 0}, {&d.prof_seq_alt, alt_ ? prof16 : 0, nullptr, 0},
+                            {&d.prof, prof8, nullptr, 0}, {&d.prof_seq, prof16, nullptr, 0}, {&d.prof_alt, alt_ || i32_ ? prof8 : 0, nullptr, 0}, {&d.prof_seq_alt, alt_ || i32_ ? prof16 : 0, nullptr, 0},
                             {&d.prof_pair, np_ ? pair16 : 0, nullptr, 0}, {&d.prof_pair8, np_ && q8_ ? pair8 : 0, nullptr, 0}, {&d.prof_pair_i16, np_ && alt_ ? pair16 : 0, nullptr, 0}};
     constexpr size_t kInputs = 9;
     size_t total = 0, inputs_bytes = 0;
@@ -471,6 +471,12 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
         const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
         pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);
     }
+    // ... and, for whole searches on the int32 cells, that cell's floor table: entry k = k * ge (CellI32F)
+    if (i32_)
+        for (size_t k = 0; k < OSW_I32F_TABLE; ++k) {
+            const size_t i = 128 + OSW_I16S_TABLE + 64 + k;
+            pages[2 * i] = pages[2 * i + 1] = (uint32_t)k * (uint32_t)ctx->extend_gap;
+        }
     ht.lap("queries: buffers and staging");
     HIP_TRY(osw_launch_copy16(d.qstage, d.qset.slab.p, inputs_bytes, d.stream));
     // plain integer profile: the exact int32 kernel and the pair profiles read `prof`, the plain single-query int16 cell `prof_seq`
@@ -479,7 +485,7 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
                                      0, (uint2 *)d.prof.p, (uint4 *)d.prof_seq.p, d.stream));
     // the column-frame int16 cell reads S + ge
     const bool alt = first_pass_is_frame(ctx);
-    if (alt) {
+    if (alt || i32_) {
         HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
                                          (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
                                          ctx->extend_gap, (uint2 *)d.prof_alt.p, (uint4 *)d.prof_seq_alt.p, d.stream));
@@ -1324,6 +1330,7 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     a.two_ended_waves = ctx->tun.two_ended;
     a.one_ended_wg = ctx->tun.one_ended_wg;
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
+    if (ctx->cell_bits == 32) a.prof_fb = (const uint2 *)d.prof_alt.p; // S + ge: the hand-scheduled int32 cell (a.prof: the plain profile of its fallback and of the re-run)
     a.debug_nospill = ctx->tun.debug_nospill ? 1u : 0u; // -DOSW_DIAG builds only (timing experiment: results are wrong); always 0 otherwise
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;

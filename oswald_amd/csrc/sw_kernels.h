@@ -13,6 +13,8 @@
 #define OSW_SEQ_CODES 24     // residue codes per row-block of the single-query int16 kernels' profile (16 B each: 96 B per query row)
 #define OSW_LDS_ROWS16_SEQ 128 // ... of which a wave's 12 KB hold 128 rows (the query-pair profile: 32 codes x 16 B, OSW_LDS_ROWS16 / 2 rows)
 #define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
+#define OSW_RMAX32F 48       // query rows per strip of the hand-scheduled int32 cell (whole searches with cell_bits = 32: the int16 kernels' register budget)
+#define OSW_LDS_ROWS32F 192   // ... and its profile rows per wave (64 B per row: 12 KB, three workgroups per CU)
 #define OSW_RMAX8 12         // query rows per strip, SWAR 8-bit kernel (compiler-scheduled; 12 rows keep it within the 80 VGPRs of six waves per SIMD)
 #define OSW_LDS_ROWS8 96     // profile rows a wave keeps in LDS per round, SWAR 8-bit kernel (6 KB: six workgroups per CU)
 #define OSW_LDS_SKEW8 128    // extra 8-byte units per wave region: group g's slice sits g entries (<= 16 B) further on, G <= 64
@@ -30,6 +32,7 @@
 #define OSW_TILED_PAD_GROUPS 18  // all-dummy 4-column groups stored after every block (prefetch + drain of G <= 64: 66 columns)
 #define OSW_TILED_TAIL_GROUPS 2  // readable groups past the last block
 #define OSW_I16S_TABLE 8448u     // entries of the column-frame cell's floor table (frame offsets stay <= 8192, + drain)
+#define OSW_I32F_TABLE 66048u    // entries of the hand-scheduled int32 cell's floor table (cell_bits = 32 only): 65 535 columns + prefetch + drain of G <= 64
 #define OSW_DUMMY_CODE8 0xB8u    // residue code 23 (dummy), pre-multiplied by 8 as stored in `tiled`
 
 // Residue codes inside the device (round 5): the re-tile kernels store, and every profile is indexed by, a RELABELLED code.

@@ -361,6 +361,97 @@ static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_
         }                                                                                                                        \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// The int32 cell, hand-scheduled (round 5, second session): the column-frame row of the int16 cell with v_max3_i32 where that has
+// v_pk_maximum3_f16 -- ONE sequence per lane (the `half` of its pair), exact for any score.  The diagonal add takes the row's
+// int16 score S + ge straight out of a half of the profile entry's register: v_add_u32_sdwa with a sign-extended WORD_0 / WORD_1
+// source (no unpacking: the compiler's version spent 1 of its 9.3 instructions per row on v_bfe_i32 / v_ashrrev_i32 and ~2 on
+// copies around the D[r + 1] shuffle).  6.5 instructions per row of 64 cells: add, H = max3, u = H - go, E = max3, F = max3,
+// F - ge, 1/2 column maximum.  Profile entry: 8 B per code = 4 rows x int16 (`prof_alt`: S + ge), ds_read_b64, two blocks ahead.
+// ---------------------------------------------------------------------------
+#define OSW_WA0 "v150"
+#define OSW_WA1 "v151"
+#define OSW_WA_ALL "v[150:151]"
+#define OSW_WB0 "v154"
+#define OSW_WB1 "v155"
+#define OSW_WB_ALL "v[154:155]"
+#define OSW_W_SEL(REG, W) "sext(" REG ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" W
+#define OSW_TADD_SDWA(XN, DN, SN) "v_add_u32_sdwa " XN ", " DN ", " SN "\n\t"
+#define OSW_WMAX(SC, SCI, DP, DN) "v_max3_i32 " SC ", " SCI ", " DP ", " DN "\n\t"
+#define OSW_WC_RUN(DP, DN) OSW_WMAX("%[sc_]", "%[sc_]", DP, DN)
+#define OSW_WC_START(DP, DN) OSW_WMAX("%[sc_]", DP, DN, DN)
+#define OSW_W_ROW(XN, DN, SN, X, E, CMAX)                                          \
+    OSW_TADD_SDWA(XN, DN, SN)                                                      \
+    "v_max3_i32 " DN ", " X ", " E ", " OSW_VF "\n\t"                              \
+    "v_subrev_u32 " OSW_VT ", %[go_], " DN "\n\t"                                  \
+    CMAX                                                                           \
+    "v_max3_i32 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                              \
+    "v_max3_i32 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]\n\t"                    \
+    "v_subrev_u32 " OSW_VF ", %[ge_], " OSW_VF "\n\t"
+#define OSW_W_ROW_LAST(HL, X, E, CMAX)                                             \
+    "v_max3_i32 " HL ", " X ", " E ", " OSW_VF "\n\t"                              \
+    "v_subrev_u32 " OSW_VT ", %[go_], " HL "\n\t"                                  \
+    CMAX                                                                           \
+    "v_max3_i32 " E ", " E ", " OSW_VT ", %[fl_]\n\t"                              \
+    "v_max3_i32 " OSW_VF ", " OSW_VF ", " OSW_VT ", %[fl_]\n\t"                    \
+    "v_subrev_u32 " OSW_VF ", %[ge_], " OSW_VF
+// four rows: C1..C3 = the score operands of the block's rows 1..3, N0 = row 0 of the next block (the other buffer), MID = the load of
+// the block after next into this block's buffer and the wait for the next block's (the query-pair cell's schedule)
+#define OSW_W_ROWS3(C1, C2, C3, SC1)                                               \
+    OSW_W_ROW("%[xb_]", "%[D1_]", C1, "%[x_]", "%[E0_]", "")                       \
+    OSW_W_ROW("%[x_]", "%[D2_]", C2, "%[xb_]", "%[E1_]", SC1("%[D1_]", "%[D2_]"))  \
+    OSW_W_ROW("%[xb_]", "%[D3_]", C3, "%[x_]", "%[E2_]", "")
+#define OSW_W_MID(C1, C2, C3, N0, SC1, MID)                                        \
+    OSW_W_ROWS3(C1, C2, C3, SC1) MID                                               \
+    OSW_W_ROW("%[x_]", "%[D4_]", N0, "%[xb_]", "%[E3_]", OSW_WC_RUN("%[D3_]", "%[D4_]"))
+#define OSW_W_LAST(C1, C2, C3, SC1)                                                \
+    OSW_W_ROWS3(C1, C2, C3, SC1)                                                   \
+    OSW_W_ROW_LAST("%[hl_]", "%[xb_]", "%[E3_]", OSW_WC_RUN("%[D3_]", "%[hl_]"))
+#define OSW_W_LD(BUF) "ds_read_b64 " BUF ", %[a0_] offset:%[off_]\n\ts_waitcnt lgkmcnt(1)\n\t"
+#define OSW_W_BLOCK(SC1, SCC1, P0, P1, PALL, N0R)                                                                                      \
+    do {                                                                                                                             \
+        if constexpr (LAST) OSW_BLOCK_STMT_LAST(OSW_W_LAST(OSW_W_SEL(P0, "1"), OSW_W_SEL(P1, "0"), OSW_W_SEL(P1, "1"), SC1), SCC1, "v"); \
+        else if constexpr (LD) OSW_BLOCK_STMT_MID(OSW_W_MID(OSW_W_SEL(P0, "1"), OSW_W_SEL(P1, "0"), OSW_W_SEL(P1, "1"), OSW_W_SEL(N0R, "0"), SC1, OSW_W_LD(PALL)), SCC1, "v"); \
+        else OSW_BLOCK_STMT_MID(OSW_W_MID(OSW_W_SEL(P0, "1"), OSW_W_SEL(P1, "0"), OSW_W_SEL(P1, "1"), OSW_W_SEL(N0R, "0"), SC1, OSW_WAIT0), SCC1, "v"); \
+    } while (0)
+// head of a column: LDS address of the lane's residue (`tiled` holds 8 * code = the byte offset of the code's 8-byte entry), the
+// loads of blocks 0 and 1, the first diagonal sum
+#define OSW_W_HEAD(VC, LD1)                                                        \
+    "v_bfe_u32 %[a0_], " VC ", %[sh_], 8\n\t"                                      \
+    "v_add_u32 %[a0_], %[a0_], %[base_]\n\t"                                       \
+    "ds_read_b64 " OSW_WA_ALL ", %[a0_]\n\t"                                       \
+    LD1                                                                            \
+    OSW_TADD_SDWA("%[x_]", "%[tp_]", OSW_W_SEL(OSW_WA0, "0"))
+#define OSW_W_HEAD_LD1 "ds_read_b64 " OSW_WB_ALL ", %[a0_] offset:%[off_]\n\ts_waitcnt lgkmcnt(1)\n\t"
+#define OSW_W_HEAD_STMT(TXT)                                                                                                     \
+    asm volatile(TXT                                                                                                             \
+                 : [a0_] "=&v"(a0), [x_] "=&v"(x)                                                                                \
+                 : [base_] "v"(base), [tp_] "v"(top_prev), [sh_] "s"(sh), [off_] "i"(BLOCK_BYTES)                                \
+                 : "memory", OSW_INFLIGHT)
+
+struct ArithI32F {
+    static constexpr int BLOCK_BYTES = 256; // 32 codes x 8 B (4 rows x int16)
+    template <int P, int NB>
+    static __device__ __forceinline__ void head(uint32_t base, uint32_t sh, int top_prev, uint32_t &a0, int &x)
+    {
+        if constexpr (P == 0 && NB > 1) OSW_W_HEAD_STMT(OSW_W_HEAD(OSW_VC0, OSW_W_HEAD_LD1));
+        else if constexpr (P == 0) OSW_W_HEAD_STMT(OSW_W_HEAD(OSW_VC0, OSW_WAIT0));
+        else if constexpr (NB > 1) OSW_W_HEAD_STMT(OSW_W_HEAD(OSW_VC1, OSW_W_HEAD_LD1));
+        else OSW_W_HEAD_STMT(OSW_W_HEAD(OSW_VC1, OSW_WAIT0));
+    }
+    template <int RB, int NB>
+    static __device__ __forceinline__ void block(uint32_t a0, int (&D)[NB * 4], int (&E)[NB * 4], int &x, int &hl, int &sc, uint32_t ge, uint32_t go, int fl)
+    {
+        constexpr bool LAST = RB == NB - 1, LD = RB + 2 < NB;
+        const uint32_t a1 = a0; // (the block statements name a second address operand: the sequence-pair cell's)
+        (void)a1;
+        int xb;
+        if constexpr (RB == 0) OSW_W_BLOCK(OSW_WC_START, "=&v", OSW_WA0, OSW_WA1, OSW_WA_ALL, OSW_WB0);
+        else if constexpr ((RB & 1) == 0) OSW_W_BLOCK(OSW_WC_RUN, "+v", OSW_WA0, OSW_WA1, OSW_WA_ALL, OSW_WB0);
+        else OSW_W_BLOCK(OSW_WC_RUN, "+v", OSW_WB0, OSW_WB1, OSW_WB_ALL, OSW_WA0);
+    }
+};
+
 // Cell arithmetic policies: the blocks of a column and what a finished score means.
 //   head<P, NB, SEQ>: a0 / a1 out (LDS addresses), x out (diagonal sum of row 0); sh = bit offset of the lane's residue
 //   block<RB, NB, SEQ>: rows RB*4..RB*4+3 of NB*4; x in/out, hl out (last block), sc = running / column maximum
@@ -444,6 +535,14 @@ struct CellSeqPair {
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
+    // column frames: the floor of the next column's frame; the column's maximum (in its frame) folded into the true running score
+    static constexpr uint32_t kTopTable = 128; // first entry of the cell's floor table in top_pages
+    static __device__ __forceinline__ T frame_next(T fl, GapT ge) { return fl + as_v2s(ge); }
+    static __device__ __forceinline__ void fold(T &score, T cm, T fl)
+    {
+        const v2u tru = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, cm), __builtin_bit_cast(v2u, fl));
+        score = __builtin_bit_cast(v2s, __builtin_elementwise_max(__builtin_bit_cast(v2u, score), tru));
+    }
 
     // One database column against the R rows of the strip, inputs in register set P:
     //   residues {8*code of the lane's first sequence, 8*code of the second} in bytes 0 / 1 of
@@ -500,6 +599,14 @@ struct CellQueryPair {
     static __device__ __forceinline__ T from_bits(uint32_t x) { return as_v2s(x); }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return as_u32(x); }
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
+    // column frames: the floor of the next column's frame; the column's maximum (in its frame) folded into the true running score
+    static constexpr uint32_t kTopTable = 128; // first entry of the cell's floor table in top_pages
+    static __device__ __forceinline__ T frame_next(T fl, GapT ge) { return fl + as_v2s(ge); }
+    static __device__ __forceinline__ void fold(T &score, T cm, T fl)
+    {
+        const v2u tru = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, cm), __builtin_bit_cast(v2u, fl));
+        score = __builtin_bit_cast(v2s, __builtin_elementwise_max(__builtin_bit_cast(v2u, score), tru));
+    }
 
     // profile entry of the lane's residue: 16 B per code = 2 x (8*code); the loads run two blocks ahead, inside
     // the blocks' statements (ArithI16*::block)
@@ -535,14 +642,15 @@ typedef CellQueryPair<ArithI16S<true>> CellPK16SQ;
 //   cm = max(cm, H)                                   -- 7 instructions + the unpacking of S per row of 64 cells (12.4 before)
 // fl1 = "zero" in the frame of column j + 1; the round turns the column's maximum cm back into a true score (cm - fl).  int32
 // has room for any frame: 65535 columns x ge <= 32767 < 2^31.  `goe` carries the gap OPEN penalty for this cell.
-struct CellI32 {
+template <int RMAX, int LDSROWS>
+struct CellI32T {
     typedef int T;
     typedef int GapT;
     static constexpr bool kFast = false;
     static constexpr uint32_t kFloorBits = 0;
     static constexpr bool kShifted = true; // (framed values travel between strips: run_item's pad columns hold the frame's zero)
-    static constexpr int kRows = OSW_RMAX32;
-    static constexpr int kLdsRows = OSW_LDS_ROWS32;
+    static constexpr int kRows = RMAX;
+    static constexpr int kLdsRows = LDSROWS;
     static constexpr int kCodes = 32;
     static constexpr int kRowBytes = 64;
     typedef uint2 Entry;
@@ -582,6 +690,48 @@ struct CellI32 {
                 if (r + 1 < R) { diag = D[r + 1]; D[r + 1] = h; } else { hl = h; }
             }
         }
+    }
+};
+typedef CellI32T<OSW_RMAX32, OSW_LDS_ROWS32> CellI32;    // the re-run pipeline (osw_sw_i32r)
+
+// The hand-scheduled int32 cell (ArithI32F) for whole searches with cell_bits = 32: 48-row strips and the packed-int16 kernels'
+// column loop (sw_round_fast: fixed registers, loads two columns ahead, three waves per SIMD).  go = gap OPEN, ge = gap extend,
+// plain 32-bit values (wave-uniform); floors / frames as in ArithI16S without the fp16 bias; a first round reads the row above
+// it from the int32 floor table (top_pages, entry k = k * ge, behind the 8-bit cell's page; OSW_I32F_TABLE entries: every block
+// the library accepts -- columns are 16-bit -- fits, so this cell needs no fallback).
+struct CellI32F {
+    typedef int T;
+    typedef uint32_t GapT;
+    static constexpr bool kFast = true;
+    static constexpr uint32_t kFloorBits = 0;
+    static constexpr bool kShifted = true;
+    static constexpr int kRows = OSW_RMAX32F;
+    static constexpr int kLdsRows = OSW_LDS_ROWS32F;
+    static constexpr int kCodes = 32;
+    static constexpr int kRowBytes = 64;
+    typedef uint2 Entry;
+    static constexpr uint32_t kTopTable = 128 + OSW_I16S_TABLE + 64;
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
+    static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
+    static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
+    static __device__ __forceinline__ T frame_next(T fl, GapT ge) { return fl + (int)ge; }
+    static __device__ __forceinline__ void fold(T &score, T cm, T fl) { score = cm - fl > score ? cm - fl : score; }
+    template <int R, int RB>
+    struct Blocks {
+        static __device__ __forceinline__ void run(uint32_t a, T (&D)[R], T (&E)[R], T &x, T &hl, GapT go, GapT ge, T &cm, T fl1)
+        {
+            ArithI32F::template block<RB, R / 4>(a, D, E, x, hl, cm, ge, go, fl1);
+            if constexpr (RB + 1 < R / 4) Blocks<R, RB + 1>::run(a, D, E, x, hl, go, ge, cm, fl1);
+        }
+    };
+    template <int R, int P>
+    static __device__ __forceinline__ void column(uint32_t base, int half, T (&D)[R], T (&E)[R], T top_prev, T &hl, GapT go, GapT ge, T &cm, T fl1)
+    {
+        uint32_t a;
+        T x;
+        ArithI32F::template head<P, R / 4>(base, (uint32_t)half * 8u, top_prev, a, x);
+        Blocks<R, 0>::run(a, D, E, x, hl, go, ge, cm, fl1);
     }
 };
 
@@ -691,11 +841,14 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     const uint32_t g = (uint32_t)lane / gl;
     // "zero" for this lane's first step.  Column-frame cell: the lane starts at column -g, whose frame offset is
     // (G - g) * ge (see ArithI16S); the state that belongs to the column before it sits one frame back.
-    T fl = as_v2s(C::kFloorBits), fl_prev = fl;
+    T fl = C::from_bits(C::kFloorBits), fl_prev = fl;
     if constexpr (C::kShifted) {
-        fl = as_v2s(C::kFloorBits + (G - g) * ge);        // ge holds the penalty in both halves: no carry between them below 2^15
-        fl_prev = as_v2s(C::kFloorBits + (G - g - 1u) * ge);
+        fl = C::from_bits(C::kFloorBits + (G - g) * ge);        // (packed cells: ge holds the penalty in both halves: no carry between them below 2^15)
+        fl_prev = C::from_bits(C::kFloorBits + (G - g - 1u) * ge);
     }
+    // (int32 cell: the floors are the same in every round of an item, and the compiler would set the 2 R state registers of every strip
+    // height up ONCE, outside the rounds, and keep them: ~40 registers spilled to scratch.  Opaque values stay where they are used.)
+    if constexpr (std::is_same<T, int>::value) asm volatile("" : "+v"(fl), "+v"(fl_prev));
     T D[R], E[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { D[r] = fl_prev; E[r] = fl; }
@@ -712,7 +865,7 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     // (entry k = 1024 + k * ge; column 0 is entry G), 8 B per column, the same entry for every lane.
     const uint32_t lstep = !first ? gl * 8u : C::kShifted ? 8u : 0u;
     const uint32_t voffl = first && C::kShifted ? 0u : voff;
-    uint64_t lptr = !first ? data : C::kShifted ? (uint64_t)(top_pages + 128 + G) : (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0));
+    uint64_t lptr = !first ? data : C::kShifted ? (uint64_t)(top_pages + C::kTopTable + G) : (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0));
     uint64_t sptr = last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u;
     uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * 128u;
     uint64_t sv;
@@ -740,11 +893,10 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     // returns the column's maximum in its frame, which is turned into a true score here
 #define OSW_COLUMN(P)                                                                                              \
     if constexpr (C::kShifted) {                                                                                   \
-        const T fl1 = fl + as_v2s(ge);                                                                             \
+        const T fl1 = C::frame_next(fl, ge);                                                                       \
         T cm; /* started by the first odd row */                                                                   \
         C::template column<R, P>(base, half, D, E, top_prev, hl, goe, ge, cm, fl1);                                \
-        const v2u tru = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, cm), __builtin_bit_cast(v2u, fl));   \
-        score = __builtin_bit_cast(v2s, __builtin_elementwise_max(__builtin_bit_cast(v2u, score), tru));           \
+        C::fold(score, cm, fl);                                                                                    \
         fl = fl1;                                                                                                  \
     } else {                                                                                                       \
         C::template column<R, P>(base, half, D, E, top_prev, hl, goe, ge, score, fl);                              \
@@ -1476,19 +1628,17 @@ static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, 
 // geometry 64 (each lane one strip of the same sequence: the whole wave works
 // on one sequence at a time).  force_all: run `items` (cell_bits = 32 mode).
 // ---------------------------------------------------------------------------
-#ifndef OSW_I32_ATTR
-#define OSW_I32_ATTR
-#endif
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) OSW_I32_ATTR void osw_sw_i32(OswSearchArgs p)
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_i32(OswSearchArgs p)
 {
-    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8];
-    const int lane = threadIdx.x & 63;
+    __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS32F * 8 + OSW_LDS_SKEW8];
+    const int lane = osw_logical_lane(threadIdx.x & 63); // (the hand-scheduled cell numbers its lanes like the packed-int16 kernels; lane 0 is lane 0)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
     uint2 *lds_wave = lds_prof[wv];
     const uint32_t nitems = p.nitems;                  // cell_bits = 32: the item list of the plan (wave items)
     const uint2 *items = p.items + (size_t)p.nitems_wg * 4;
+    const uint32_t go = (uint32_t)(p.goe - p.ge), ge = (uint32_t)p.ge;
     for (;;) {
         uint32_t it = 0;
         if (lane == 0) it = atomicAdd(&p.counters[OSW_CTR_WORK32], 1u);
@@ -1501,9 +1651,8 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS) OSW_I32_ATTR void osw_sw
         const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
-            const int score = run_item<CellI32>(p, p.prof, q, B, blk, sigma, lg, lane, half, false, lds_wave, bnd_wave, p.goe, p.ge);
-            if ((uint32_t)lane < gl)
-                osw_store_score(p, q, (size_t)blk.seq0 + 2 * (sigma * gl + lane) + half, score);
+            const int score = run_item<CellI32F, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, false, lds_wave, bnd_wave, go, ge);
+            if ((uint32_t)lane < gl) osw_store_score(p, q, (size_t)blk.seq0 + 2 * (sigma * gl + lane) + half, score);
         }
     }
 }

@@ -34,6 +34,9 @@ GROUPS = (
     dict(kernels=("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q"), define="OSW_INFLIGHT", file="sw_kernels.hip",
          budget=168,   # three waves per SIMD; the compiler gets 140, the asm statements 27 fixed ones (v158 is spare; v148, v149 unused)
          scratch=32, min_asm_uses=1000, nfixed=27),
+    dict(kernels=("osw_sw_i32",), define="OSW_INFLIGHT", file="sw_kernels.hip",
+         budget=168,   # the hand-scheduled int32 cell (cell_bits = 32): the int16 kernels' column loop and register budget
+         scratch=0, min_asm_uses=500, nfixed=27),
     dict(kernels=("osw_sw_q8",), define="OSW8_INFLIGHT", file="q8_cell.h",
          budget=80,    # six waves per SIMD; the compiler gets 72, the asm 8 more
          scratch=0, min_asm_uses=100, nfixed=8),
@@ -176,10 +179,12 @@ def check_cell_shape(isa):
 
 
 def check_int32_cell(isa):
-    """The exact kernels osw_sw_i32 / osw_sw_i32r (compiler-scheduled; round 5: column frames): no scratch at all -- a spill
-    inside their column loops is scratch traffic per cell --, the three-operand integer maximum and the three-operand add of
-    the frame formulation (H = max3(x, E, F), x = D + S + ge: CellI32), and the budget of two waves per SIMD their
-    launches assume (<= 256 VGPRs).  -> list of complaints"""
+    """The exact kernels.  osw_sw_i32 (whole searches with cell_bits = 32; hand-scheduled since the second session of round 5):
+    the row is v_add_u32_sdwa + 3.5 v_max3_i32 + 2 v_subrev_u32 -- no unpacking of the int16 scores (v_bfe_i32 /
+    v_ashrrev_i32), no three-operand add --, profile by ds_read_b64, three waves per SIMD (168 VGPRs), no scratch.
+    osw_sw_i32r (the re-run pipeline, compiler-scheduled, column frames): no scratch at all -- a spill inside its column
+    loops is scratch traffic per cell --, v_max3_i32 / v_add3_u32 of the frame formulation, <= 256 VGPRs (two waves per
+    SIMD).  -> list of complaints"""
     text, bad, counts, fn = "\n".join(isa), [], {}, None
     for line in isa:
         m = re.match(r'^(osw_\w+):', line)
@@ -189,18 +194,25 @@ def check_int32_cell(isa):
             op = line.split(";")[0].strip().split(" ")[0]
             counts.setdefault(fn, {}).setdefault(op, 0)
             counts[fn][op] += 1
-    for k in ("osw_sw_i32", "osw_sw_i32r"):
+    for k, vmax in (("osw_sw_i32", 168), ("osw_sw_i32r", 256)):
         m = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)' % k, text)
         m2 = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)' % k, text)
-        if not m or int(m.group(1)) > 256:
+        if not m or int(m.group(1)) > vmax:
             bad.append("%s needs %s VGPRs" % (k, m.group(1) if m else "?"))
         if not m2 or int(m2.group(1)) != 0:
             bad.append("%s spills %s bytes per lane" % (k, m2.group(1) if m2 else "?"))
         c = counts.get(k, {})
-        if c.get("v_max3_i32", 0) < 100 or c.get("v_add3_u32", 0) < 40:
-            bad.append("%s: %d v_max3_i32, %d v_add3_u32 (the frame formulation has three and one per row)" % (k, c.get("v_max3_i32", 0), c.get("v_add3_u32", 0)))
         if c.get("scratch_load_dword", 0) or c.get("scratch_store_dword", 0):
             bad.append("%s has scratch traffic" % k)
+        if k == "osw_sw_i32":
+            rows = c.get("v_add_u32_sdwa", 0)
+            if rows < 600 or c.get("v_max3_i32", 0) < 3.4 * rows or c.get("v_bfe_i32", 0) or c.get("v_ashrrev_i32_e32", 0) or c.get("v_add3_u32", 0) > 60:
+                bad.append("%s: %d v_add_u32_sdwa, %d v_max3_i32, %d v_bfe_i32, %d v_add3_u32 (one SDWA add and 3.5 maxima per row, no unpacking)"
+                           % (k, rows, c.get("v_max3_i32", 0), c.get("v_bfe_i32", 0), c.get("v_add3_u32", 0)))
+            if c.get("ds_read_b64", 0) < 100 or c.get("ds_read_b128", 0):
+                bad.append("%s reads its profile with %d ds_read_b64, %d ds_read_b128" % (k, c.get("ds_read_b64", 0), c.get("ds_read_b128", 0)))
+        elif c.get("v_max3_i32", 0) < 100 or c.get("v_add3_u32", 0) < 40:
+            bad.append("%s: %d v_max3_i32, %d v_add3_u32 (the frame formulation has three and one per row)" % (k, c.get("v_max3_i32", 0), c.get("v_add3_u32", 0)))
     return bad
 
 
@@ -249,7 +261,7 @@ def stamp():
                        "; ".join("%s: <= %d VGPRs, <= %d B of scratch outside the column loops" % ("/".join(g["kernels"]), g["budget"], g["scratch"]) for g in GROUPS),
                        "no compiler-issued vector memory (spill traffic included) inside the asm load windows",
                        "single-query int16 kernels: one v_pk_mad_i16 per row, no v_perm_b32; profile reads are ds_read_b128",
-                       "osw_sw_i32 / osw_sw_i32r: no scratch, <= 256 VGPRs, v_max3_i32 / v_add3_u32 of the column-frame int32 cell"]}
+                       "osw_sw_i32: hand-scheduled rows (v_add_u32_sdwa + 3.5 v_max3_i32, ds_read_b64), 168 VGPRs, no scratch; osw_sw_i32r: no scratch, <= 256 VGPRs, v_max3_i32 / v_add3_u32 of the column-frame int32 cell"]}
     with open(STAMP, "w") as f:
         json.dump(info, f, indent=1)
     return info
