@@ -311,7 +311,7 @@ struct Device {
     uint32_t grid = 0;               // persistent workgroups per launch
     uint32_t grid_q8 = 0;            // ... of the 8-bit kernel (more workgroups per CU; at most 2 x grid: it runs alone and may use both halves of the spill scratch)
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_seq, prof_seq_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters;
-    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8;
+    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8, floor_i32;
     Arena qset;                           // what the buffers of the current query set (queries ... top_pages, prof_pair8) are slices of
     uint8_t *qstage = nullptr;            // page-locked: the small inputs of the query set as the arena holds them, read in place by the copy kernel
     size_t qstage_cap = 0;
@@ -419,11 +419,11 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     // brought over by ONE kernel that reads the staging buffer in place -- no copy engine, nothing pageable: round 5 found the
     // six little hipMemcpyAsync from the context's std::vectors holding the caller for 8.6 ms of a 25-ms search (the runtime
     // stages a pageable copy on the caller's thread, and the copy engine was busy with the chunk coming in).
-    const bool alt_ = first_pass_is_frame(ctx), q8_ = first_pass_is_q8(ctx), i32_ = ctx->cell_bits == 32; // (the hand-scheduled int32 cell reads S + ge too)
+    const bool alt_ = first_pass_is_frame(ctx), q8_ = first_pass_is_q8(ctx);
     const uint32_t np_ = (uint32_t)ctx->pair_len.size();
     const size_t prof8 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096, prof16 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096;
     const size_t pair16 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096, pair8 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint2) + 4096;
-    const size_t pages_bytes = (size_t)(128 + OSW_I16S_TABLE + 64 + (i32_ ? OSW_I32F_TABLE : 0u)) * 2 * sizeof(uint32_t);
+    const size_t pages_bytes = (size_t)(128 + OSW_I16S_TABLE + 64) * 2 * sizeof(uint32_t);
     struct Slice { DevBuf *buf; size_t bytes; const void *src; size_t src_bytes; };
     const Slice slices[] = {// inputs (src: what the staging buffer holds at the slice's offset; top_pages is generated in place below)
                             {&d.queries, ctx->a.size() + 16, ctx->a.data(), ctx->a.size()},
@@ -436,7 +436,7 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
                             {&d.pair_len, np_ ? np_ * sizeof(uint16_t) + 16 : 0, ctx->pair_len.data(), np_ * sizeof(uint16_t)},
                             {&d.top_pages, pages_bytes, nullptr, 0},
                             // built on the device
-                            {&d.prof, prof8, nullptr, 0}, {&d.prof_seq, prof16, nullptr, 0}, {&d.prof_alt, alt_ || i32_ ? prof8 : 0, nullptr, 0}, {&d.prof_seq_alt, alt_ || i32_ ? prof16 : 0, nullptr, 0},
+                            {&d.prof, prof8, nullptr, 0}, {&d.prof_seq, prof16, nullptr, 0}, {&d.prof_alt, prof8, nullptr, 0}, {&d.prof_seq_alt, alt_ ? prof16 : 0, nullptr, 0}, {&d.floor_i32, (size_t)OSW_I32F_TABLE * sizeof(uint2), nullptr, 0},
                             {&d.prof_pair, np_ ? pair16 : 0, nullptr, 0}, {&d.prof_pair8, np_ && q8_ ? pair8 : 0, nullptr, 0}, {&d.prof_pair_i16, np_ && alt_ ? pair16 : 0, nullptr, 0}};
     constexpr size_t kInputs = 9;
     size_t total = 0, inputs_bytes = 0;
@@ -471,12 +471,6 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
         const uint32_t v = (uint32_t)std::min<uint64_t>(1024ull + (uint64_t)k * (uint64_t)ctx->extend_gap, 0x7bffull);
         pages[2 * (128 + k)] = pages[2 * (128 + k) + 1] = v | (v << 16);
     }
-    // ... and, for whole searches on the int32 cells, that cell's floor table: entry k = k * ge (CellI32F)
-    if (i32_)
-        for (size_t k = 0; k < OSW_I32F_TABLE; ++k) {
-            const size_t i = 128 + OSW_I16S_TABLE + 64 + k;
-            pages[2 * i] = pages[2 * i + 1] = (uint32_t)k * (uint32_t)ctx->extend_gap;
-        }
     ht.lap("queries: buffers and staging");
     HIP_TRY(osw_launch_copy16(d.qstage, d.qset.slab.p, inputs_bytes, d.stream));
     // plain integer profile: the exact int32 kernel and the pair profiles read `prof`, the plain single-query int16 cell `prof_seq`
@@ -484,12 +478,12 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
                                      (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
                                      0, (uint2 *)d.prof.p, (uint4 *)d.prof_seq.p, d.stream));
     // the column-frame int16 cell reads S + ge
+    // S + ge: the column-frame int16 cell, and the int32 cell of the re-run and of cell_bits = 32 (its floor table: built on the device too)
     const bool alt = first_pass_is_frame(ctx);
-    if (alt || i32_) {
-        HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
-                                         (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
-                                         ctx->extend_gap, (uint2 *)d.prof_alt.p, (uint4 *)d.prof_seq_alt.p, d.stream));
-    }
+    HIP_TRY(osw_launch_build_profile((const uint8_t *)d.queries.p, (const uint32_t *)d.a_disp.p, (const uint16_t *)d.qlen.p,
+                                     (const uint32_t *)d.prof_off.p, (const int8_t *)d.submat.p, nq, ctx->max_rowblocks,
+                                     ctx->extend_gap, (uint2 *)d.prof_alt.p, alt ? (uint4 *)d.prof_seq_alt.p : nullptr, d.stream));
+    HIP_TRY(osw_launch_floor_i32((uint2 *)d.floor_i32.p, OSW_I32F_TABLE, (uint32_t)ctx->extend_gap, d.stream));
     const uint32_t np = (uint32_t)ctx->pair_len.size();
     if (np > 0) {
         HIP_TRY(osw_launch_build_pair_profile((const uint2 *)(alt ? d.prof_alt.p : d.prof.p), (const uint32_t *)d.prof_off.p, (const uint16_t *)d.qlen.p,
@@ -830,7 +824,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; } }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_seq, &d.prof_seq_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
-                          &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8,
+                          &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8, &d.floor_i32,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
             b->release();
         d.qset.slab.release();
@@ -1330,7 +1324,8 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     a.two_ended_waves = ctx->tun.two_ended;
     a.one_ended_wg = ctx->tun.one_ended_wg;
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
-    if (ctx->cell_bits == 32) a.prof_fb = (const uint2 *)d.prof_alt.p; // S + ge: the hand-scheduled int32 cell (a.prof: the plain profile of its fallback and of the re-run)
+    a.prof_i32 = (const uint2 *)d.prof_alt.p; // S + ge: the int32 cell (re-run and cell_bits = 32)
+    a.floor_i32 = (const uint2 *)d.floor_i32.p;
     a.debug_nospill = ctx->tun.debug_nospill ? 1u : 0u; // -DOSW_DIAG builds only (timing experiment: results are wrong); always 0 otherwise
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;

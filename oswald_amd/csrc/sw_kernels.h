@@ -145,6 +145,8 @@ struct OswSearchArgs {
     const uint2 *prof;         // [(prof_off[q] + i/4)*32 + code] = 4 x int16 (column-frame kernels: S + ge); the single-query int16 kernels
                                // (osw_sw_pk16 / osw_sw_s16): uint4 entries, a 32-bit word {S, 1} per row; query-pair kernels: uint4, 4 x (S_A, S_B)
     const uint2 *prof_fb;      // column-frame kernels: the plain profile of the same queries / pairs (blocks run on the plain cell)
+    const uint2 *prof_i32;     // the hand-scheduled int32 cell's profile: S + ge, 8 B per code = 4 rows x int16 (osw_sw_i32, osw_sw_i32r)
+    const uint2 *floor_i32;    // ... and its floor table: entry k = {k * ge, k * ge}, OSW_I32F_TABLE entries (the row above a first round)
     const uint32_t *prof_off;
     const uint16_t *qlen;
     const uint2 *top_pages;    // constant {H,F} entries, the row above a first round: 64 of zeros, 64 of the biased-int16 floor,
@@ -188,6 +190,8 @@ hipError_t osw_launch_build_pair_profile(const uint2 *prof, const uint32_t *prof
                                          const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,
                                          bool intsum, uint4 *prof_pair, hipStream_t s);
 hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s); // a search-shaped fill (see sw_kernels.hip)
+// the int32 cell's floor table, built on the device: t[k] = {k * ge, k * ge}, k < n
+hipError_t osw_launch_floor_i32(uint2 *t, uint32_t n, uint32_t ge, hipStream_t s);
 hipError_t osw_launch_copy16(const void *src_host_pinned, void *dst, size_t bytes, hipStream_t s); // page-locked host -> device by a kernel that reads the host buffer in place
 hipError_t osw_warm_aux_kernels(hipStream_t s); // first launches of the profile / top-list kernels (bring-up)
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,

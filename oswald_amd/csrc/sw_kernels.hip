@@ -65,6 +65,7 @@ typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const u32x2 *lds_u2p;
 typedef __attribute__((address_space(3))) const char *lds_cp;
+typedef __attribute__((address_space(3))) volatile uint32_t *lds_flagp; // a progress word of the re-run pipeline (LDS: ds_read / ds_write, not a flat access)
 
 static __device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
 static __device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
@@ -537,6 +538,7 @@ struct CellSeqPair {
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
     // column frames: the floor of the next column's frame; the column's maximum (in its frame) folded into the true running score
     static constexpr uint32_t kTopTable = 128; // first entry of the cell's floor table in top_pages
+    static __device__ __forceinline__ const uint2 *top_pages(const OswSearchArgs &p) { return p.top_pages; }
     static __device__ __forceinline__ T frame_next(T fl, GapT ge) { return fl + as_v2s(ge); }
     static __device__ __forceinline__ void fold(T &score, T cm, T fl)
     {
@@ -601,6 +603,7 @@ struct CellQueryPair {
     static __device__ __forceinline__ T vmax(T a, T b) { return __builtin_elementwise_max(a, b); }
     // column frames: the floor of the next column's frame; the column's maximum (in its frame) folded into the true running score
     static constexpr uint32_t kTopTable = 128; // first entry of the cell's floor table in top_pages
+    static __device__ __forceinline__ const uint2 *top_pages(const OswSearchArgs &p) { return p.top_pages; }
     static __device__ __forceinline__ T frame_next(T fl, GapT ge) { return fl + as_v2s(ge); }
     static __device__ __forceinline__ void fold(T &score, T cm, T fl)
     {
@@ -697,8 +700,8 @@ typedef CellI32T<OSW_RMAX32, OSW_LDS_ROWS32> CellI32;    // the re-run pipeline 
 // The hand-scheduled int32 cell (ArithI32F) for whole searches with cell_bits = 32: 48-row strips and the packed-int16 kernels'
 // column loop (sw_round_fast: fixed registers, loads two columns ahead, three waves per SIMD).  go = gap OPEN, ge = gap extend,
 // plain 32-bit values (wave-uniform); floors / frames as in ArithI16S without the fp16 bias; a first round reads the row above
-// it from the int32 floor table (top_pages, entry k = k * ge, behind the 8-bit cell's page; OSW_I32F_TABLE entries: every block
-// the library accepts -- columns are 16-bit -- fits, so this cell needs no fallback).
+// it from the int32 floor table (OswSearchArgs::floor_i32, entry k = k * ge; OSW_I32F_TABLE entries: every block the library
+// accepts -- columns are 16-bit -- fits, so this cell needs no fallback).
 struct CellI32F {
     typedef int T;
     typedef uint32_t GapT;
@@ -710,7 +713,8 @@ struct CellI32F {
     static constexpr int kCodes = 32;
     static constexpr int kRowBytes = 64;
     typedef uint2 Entry;
-    static constexpr uint32_t kTopTable = 128 + OSW_I16S_TABLE + 64;
+    static constexpr uint32_t kTopTable = 0; // a table of its own (built on the device by osw_floor_i32)
+    static __device__ __forceinline__ const uint2 *top_pages(const OswSearchArgs &p) { return p.floor_i32; }
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
     static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
@@ -761,6 +765,12 @@ static __device__ __forceinline__ int osw_physical_lane(int l)
     const int r = (l >> 2) & 3, h = (l >> 4) & 1, b = (r << 1) | (h ^ ((r ^ (r >> 1)) & 1));
     return (l & 32) | (b << 2) | (l & 3);
 }
+
+// the same cell in the re-run pipeline (osw_sw_i32r): geometry 64, 4-row strips (a wave's 17 KB slice holds 64 tables of 4 rows)
+struct CellI32FP : CellI32F {
+    static constexpr int kRows = 4;
+    static constexpr int kLdsRows = OSW_LDS_ROWS32;
+};
 
 // cells whose profile slice is interleaved over the lane groups (CellI32::kInterleaved)
 template <class C, class = void> struct osw_interleaved : std::false_type {};
@@ -828,10 +838,18 @@ static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
                    [mg0] "s"(m_g0), [sptr] "s"(sptr), [lptr] "s"(lptr), [tptr] "s"(tptr)                      \
                  : "memory", "scc", OSW_INFLIGHT)
 
-template <class C, int R>
+#define OSW_PIPE_BATCH 32u
+// PIPE (the re-run pipeline, run_item_i32f_pipe): the round's row above comes from ANOTHER wave's region (src_region), column by
+// column while that wave is still producing it: before every batch of OSW_PIPE_BATCH steps the wave waits until the columns the
+// batch loads (two ahead of the steps) are published in *prog_src under the tag rho, and behind every batch it publishes how many
+// columns of its own bottom row are stored (s_waitcnt vmcnt(0) first: the stores have been performed; the waves of a workgroup share
+// the CU's L1, and a workgroup-scope fence orders the flag behind them).
+template <class C, int R, bool PIPE = false>
 static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
                                                      const uint2 *top_pages, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
-                                                     typename C::GapT goe, typename C::GapT ge, typename C::T &score)
+                                                     typename C::GapT goe, typename C::GapT ge, typename C::T &score,
+                                                     const uint2 *src_region = nullptr, lds_flagp prog_src = nullptr,
+                                                     lds_flagp prog_mine = nullptr, uint32_t rho = 0)
 {
     typedef typename C::T T;
     // (`lane` is the LOGICAL lane, see osw_logical_lane: the masks are over physical lanes)
@@ -855,7 +873,10 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     T top_prev = fl_prev; // H(i0-1, j-1)
     // group g reads its residues g columns behind group 0: the pointer runs G-1 columns behind,
     // the lanes' offsets make up for it (columns before the block are the dummy pad in front of it)
-    const uint32_t voff = u * 8u, voffc = u * 2u + (G - 1u - g) * 128u;
+    // (PIPE: `tcol` is a compact copy of the ONE sequence the workgroup works on, 2 bytes per column -- a lane's residue load of a step
+    // is then one cache line for the whole wave, not a line per lane: at geometry 64 every lane reads a different column)
+    constexpr uint32_t CS = PIPE ? 2u : 128u; // bytes from a column's residues to the next column's
+    const uint32_t voff = u * 8u, voffc = (PIPE ? 0u : u * 2u) + (G - 1u - g) * CS;
     // a last round stores into the trash page; so do the G-1 warm-up steps in which the last group is
     // still before column 0 (the store pointer starts G-1 columns before the data: inside the trash page)
     const uint64_t data = (uint64_t)(bnd + OSW_SCRATCH_DATA);
@@ -865,15 +886,22 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     // (entry k = 1024 + k * ge; column 0 is entry G), 8 B per column, the same entry for every lane.
     const uint32_t lstep = !first ? gl * 8u : C::kShifted ? 8u : 0u;
     const uint32_t voffl = first && C::kShifted ? 0u : voff;
-    uint64_t lptr = !first ? data : C::kShifted ? (uint64_t)(top_pages + C::kTopTable + G) : (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0));
+    uint64_t lptr = !first ? (PIPE ? (uint64_t)(src_region + OSW_SCRATCH_DATA) : data)
+                  : C::kShifted ? (uint64_t)(top_pages + C::kTopTable + G) : (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0));
+    [[maybe_unused]] auto wait_for = [&](uint32_t cols) { // columns 0 .. cols-1 of round rho - 1 (published under the tag rho) are stored and visible
+        const uint32_t need = (rho << 20) | (cols < ncols ? cols : ncols);
+        while (*prog_src < need) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    if constexpr (PIPE) { if (!first) wait_for(2); }
     uint64_t sptr = last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u;
-    uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * 128u;
+    uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * CS;
     uint64_t sv;
     // nothing has been handed over yet: zeros; columns 0 and 1 of the stream
     asm volatile("v_mov_b32 " OSW_VH ", %[fl]\n\t"
                  "v_mov_b32 " OSW_VF ", %[fl]\n\t"
                  "global_load_ushort " OSW_VC0 ", %[voffc], %[tptr]\n\t"
-                 "global_load_ushort " OSW_VC1 ", %[voffc], %[tptr] offset:128\n\t"
+                 "global_load_ushort " OSW_VC1 ", %[voffc], %[tptr] offset:%[cs]\n\t"
                  "s_mov_b64 %[sv], exec\n\t"
                  "s_mov_b64 exec, %[mg0]\n\t"
                  "global_load_dword " OSW_VLH0 ", %[voffl], %[lptr]\n\t"
@@ -884,10 +912,10 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
                  "s_waitcnt vmcnt(0)"
                  : [sv] "=&s"(sv)
                  : [voffl] "v"(voffl), [voffc] "v"(voffc), [mg0] "s"(m_g0), [lptr] "s"(lptr), [lptr2] "s"(lptr + lstep), [tptr] "s"(tptr),
-                   [fl] "v"(fl)
+                   [fl] "v"(fl), [cs] "i"(CS)
                  : "memory", OSW_INFLIGHT);
     lptr += 2 * lstep;
-    tptr += 256;
+    tptr += 2 * CS;
     const uint32_t nsteps = ncols + G - 1;
     // one column on input set P: the plain cells keep the running maximum themselves; the column-frame cell
     // returns the column's maximum in its frame, which is turned into a true score here
@@ -901,31 +929,53 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     } else {                                                                                                       \
         C::template column<R, P>(base, half, D, E, top_prev, hl, goe, ge, score, fl);                              \
     }
-#pragma unroll 1
-    for (uint32_t t = 0; t < nsteps; t += 2) {
-        {
-            OSW_STEP_BEGIN_ASM(OSW_VLF0);
-            T hl, tp;
-            OSW_COLUMN(0)
-            const uint32_t ho = C::to_bits(hl);
-            OSW_STEP_END_ASM(OSW_VC0, OSW_VLH0, OSW_VLF0);
-            top_prev = tp;
-            sptr += sstep;
-            lptr += lstep;
-            tptr += 128;
+#define OSW_STEP_PAIR(T_END)                                    \
+        {                                                       \
+            OSW_STEP_BEGIN_ASM(OSW_VLF0);                       \
+            T hl, tp;                                           \
+            OSW_COLUMN(0)                                       \
+            const uint32_t ho = C::to_bits(hl);                 \
+            OSW_STEP_END_ASM(OSW_VC0, OSW_VLH0, OSW_VLF0);      \
+            top_prev = tp;                                      \
+            sptr += sstep;                                      \
+            lptr += lstep;                                      \
+            tptr += CS;                                         \
+        }                                                       \
+        if (t + 1 < (T_END)) {                                  \
+            OSW_STEP_BEGIN_ASM(OSW_VLF1);                       \
+            T hl, tp;                                           \
+            OSW_COLUMN(1)                                       \
+            const uint32_t ho = C::to_bits(hl);                 \
+            OSW_STEP_END_ASM(OSW_VC1, OSW_VLH1, OSW_VLF1);      \
+            top_prev = tp;                                      \
+            sptr += sstep;                                      \
+            lptr += lstep;                                      \
+            tptr += CS;                                         \
         }
-        if (t + 1 < nsteps) {
-            OSW_STEP_BEGIN_ASM(OSW_VLF1);
-            T hl, tp;
-            OSW_COLUMN(1)
-            const uint32_t ho = C::to_bits(hl);
-            OSW_STEP_END_ASM(OSW_VC1, OSW_VLH1, OSW_VLF1);
-            top_prev = tp;
-            sptr += sstep;
-            lptr += lstep;
-            tptr += 128;
+    if constexpr (!PIPE) {
+#pragma unroll 1
+        for (uint32_t t = 0; t < nsteps; t += 2) {
+            OSW_STEP_PAIR(nsteps)
+        }
+    } else {
+        static_assert(OSW_PIPE_BATCH % 2 == 0, "a batch is whole pairs of steps");
+#pragma unroll 1
+        for (uint32_t t0 = 0; t0 < nsteps; t0 += OSW_PIPE_BATCH) {
+            const uint32_t t1 = t0 + OSW_PIPE_BATCH < nsteps ? t0 + OSW_PIPE_BATCH : nsteps;
+            if (!first) wait_for(t1 + 2); // the batch's steps load the row above two columns ahead: up to column t1 + 1
+#pragma unroll 1
+            for (uint32_t t = t0; t < t1; t += 2) {
+                OSW_STEP_PAIR(t1)
+            }
+            if (!last) {
+                // step t stores column t + 1 - G of this round's bottom row: columns 0 .. t1 - G are on their way; performed, then published
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory", OSW_INFLIGHT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 63) *prog_mine = ((rho + 1u) << 20) | (t1 >= G ? t1 + 1u - G : 0u);
+            }
         }
     }
+#undef OSW_STEP_PAIR
 #undef OSW_COLUMN
     // the prefetches of the two columns past the end are still in flight
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory", OSW_INFLIGHT);
@@ -1199,6 +1249,16 @@ static __device__ __forceinline__ void fill_profile_slice_interleaved(const E *p
 #define OSW_DIAG_STAMP(cond, slot) do { } while (0)
 #endif
 
+// the constant "row above a first round" of a cell: top_pages, or the cell's own table
+template <class C, class = void> struct osw_has_top_pages : std::false_type {};
+template <class C> struct osw_has_top_pages<C, std::void_t<decltype(&C::top_pages)>> : std::true_type {};
+template <class C>
+static __device__ __forceinline__ const uint2 *osw_top_pages(const OswSearchArgs &p)
+{
+    if constexpr (osw_has_top_pages<C>::value) return C::top_pages(p);
+    else return p.top_pages;
+}
+
 // One work item: all rounds of (query q, block B, sub-block sigma) at geometry G.
 // Returns the lane's best score (valid in the lanes of group 0 after the
 // cross-group reduction).
@@ -1269,7 +1329,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         }
         const uint32_t base = osw_interleaved<C>::value ? (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (uint32_t)sizeof(Entry))
                                                         : (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
-        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, p.top_pages, rho == 0 || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score);
+        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, osw_top_pages<C>(p), rho == 0 || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
     // addresses are computed here instead of being kept in registers across all the rounds)
@@ -1490,7 +1550,6 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 // by its owner's NEXT round (rho+4), which depends -- through rounds rho+3, rho+2, rho+1 -- on the reader of this
 // round's row having been there already.
 // ---------------------------------------------------------------------------
-#define OSW_PIPE_BATCH 32u
 template <int R>
 static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, const uint2 *src_region,
                                                          uint2 *dst_region, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half, int goe,
@@ -1623,6 +1682,66 @@ static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, 
     return best;
 }
 
+// The same pipeline on the hand-scheduled cell (round 5, second session): every lane loads its own residues two columns ahead (the
+// compiler-scheduled round handed them from lane to lane with the row: the profile read of a step waited for the hand-off of the
+// step before), rows as in CellI32F, the row above through sw_round_fast<.., PIPE>.  `lane` is the logical lane.
+template <int NW>
+static __device__ __forceinline__ int run_item_i32f_pipe(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma, uint32_t lg,
+                                                         int lane, int wv, int half, uint2 *lds_wave, uint2 *bnd_wg, volatile uint32_t *prog, int *red)
+{
+    typedef CellI32FP C;
+    const uint32_t G = 1u << lg, gl = 64u >> lg;
+    const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
+    const uint32_t ncols = __builtin_amdgcn_readfirstlane((uint32_t)p.sub_cols[(size_t)B * 128 + (G - 1u) + sigma]);
+    const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
+    const OswPlan plan = osw_plan(p.qlen[q], G, C::kLdsRows, C::kRows);
+    const uint2 *prof_q = p.prof_i32 + (size_t)p.prof_off[q] * 32u;
+    uint2 *mine = (uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)wv * p.bnd_stride));
+    const uint2 *prev = (const uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)((wv + NW - 1) % NW) * p.bnd_stride));
+    const uint32_t go = (uint32_t)(p.goe - p.ge), ge = (uint32_t)p.ge;
+    {
+        // the columns the prefetch and the drain steps of the NEXT round read past the block's last one: zero in their frames
+        uint2 *pad = mine + OSW_SCRATCH_DATA + (size_t)ncols * gl;
+        for (uint32_t k = (uint32_t)lane; k < (G + 2u) * gl; k += 64) {
+            const uint32_t z = (ncols + k / gl + G) * ge;
+            pad[k] = make_uint2(z, z);
+        }
+    }
+    // A compact copy of the item's residues: one uint16 per column (`tiled` keeps a 128-byte row per column for the block's 64 lanes; at
+    // geometry 64 every lane of a wave reads a different column of the SAME lane of the block: 64 cache lines per load).  It lives
+    // behind the columns of wave 0's spill region -- at one lane per group a region is used to a 32nd --, with the dummy columns the
+    // lane groups' warm-up and drain steps read in front of it and behind it (`tiled` has them around every block).
+    uint16_t *codes = (uint16_t *)osw_uniform64((uint64_t)((uint16_t *)(bnd_wg + OSW_SCRATCH_DATA + ncols + OSW_SCRATCH_PAD_COLS + 8u) + 64));
+    for (int c = (int)threadIdx.x - 64; c < (int)ncols + (int)OSW_SCRATCH_PAD_COLS; c += NW * 64) codes[c] = tcol[(ptrdiff_t)c * 64 + u];
+    if (lane == 0) prog[wv] = 0;
+    __syncthreads();
+    int score = 0;
+    for (uint32_t rho = (uint32_t)wv; rho < plan.rounds; rho += NW) {
+        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
+        __builtin_amdgcn_wave_barrier();
+        fill_profile_slice<uint2, 32u>(prof_q, rb0, R / 4, G, rb_end, lds_wave, (uint32_t)lane, 64u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_wave + g * (R * C::kRowBytes + (uint32_t)sizeof(uint2)));
+        const bool first = rho == 0, last = rho + 1 == plan.rounds;
+        const lds_flagp ps = (lds_flagp)(prog + ((wv + NW - 1) % NW)), pm = (lds_flagp)(prog + wv);
+        sw_round_fast<C, 4, true>(codes, u, ncols, base, mine, p.floor_i32, first, last, G, gl, lane, half, go, ge, score, prev, ps, pm, rho); // (R == 4: C::kRows)
+    }
+    // best over the strips = best over the lane groups, then over the waves
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    for (uint32_t off = gl; off < 64; off <<= 1) {
+        const int o = __builtin_amdgcn_ds_bpermute(osw_physical_lane(ln ^ (int)off) << 2, score);
+        score = o > score ? o : score;
+    }
+    red[wv * 64 + lane] = score;
+    __syncthreads();
+    int best = red[lane];
+    for (int w = 1; w < NW; ++w) best = red[w * 64 + lane] > best ? red[w * 64 + lane] : best;
+    __syncthreads(); // (red and prog are free for the next item)
+    return best;
+}
+
 // ---------------------------------------------------------------------------
 // Exact int32 kernel.  Default: re-run of the lanes queued by osw_sw_pk16 at
 // geometry 64 (each lane one strip of the same sequence: the whole wave works
@@ -1651,7 +1770,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
         const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
-            const int score = run_item<CellI32F, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, false, lds_wave, bnd_wave, go, ge);
+            const int score = run_item<CellI32F, true>(p, p.prof_i32, q, B, blk, sigma, lg, lane, half, false, lds_wave, bnd_wave, go, ge);
             if ((uint32_t)lane < gl) osw_store_score(p, q, (size_t)blk.seq0 + 2 * (sigma * gl + lane) + half, score);
         }
     }
@@ -1662,13 +1781,13 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 // length was produced by the kernels before it on this stream.  Wave w of workgroup b uses spill region 8 b + w: the grid
 // is at most an eighth of the regions (osw_launch_i32r).
 #define OSW_I32R_WAVES 8
-extern "C" __global__ __launch_bounds__(OSW_I32R_WAVES * 64) void osw_sw_i32r(OswSearchArgs p)
+extern "C" __global__ __launch_bounds__(OSW_I32R_WAVES * 64) OSW_COMPILER_VGPRS void osw_sw_i32r(OswSearchArgs p)
 {
     extern __shared__ uint2 lds_dyn[]; // OSW_I32R_WAVES profile slices of OSW_LDS_ROWS32 rows (139 KB: above the static limit)
     __shared__ uint32_t prog[OSW_I32R_WAVES];
     __shared__ uint32_t wg_it;
     __shared__ int red[OSW_I32R_WAVES * 64];
-    const int lane = threadIdx.x & 63;
+    const int lane = osw_logical_lane(threadIdx.x & 63); // (the hand-scheduled cell's lane numbering; lane 0 is lane 0)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint2 *lds_wave = lds_dyn + (size_t)wv * (OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8);
     uint2 *bnd_wg = p.bnd + (size_t)blockIdx.x * OSW_I32R_WAVES * p.bnd_stride;
@@ -1687,7 +1806,7 @@ extern "C" __global__ __launch_bounds__(OSW_I32R_WAVES * 64) void osw_sw_i32r(Os
         const uint32_t gl = 64u >> lg;
         for (int half = 0; half < 2; ++half) {
             if (!((hm >> half) & 1u)) continue;
-            const int score = run_item_i32_pipe<OSW_I32R_WAVES>(p, q, B, blk, sigma, lg, lane, wv, half, lds_wave, bnd_wg, prog, red);
+            const int score = run_item_i32f_pipe<OSW_I32R_WAVES>(p, q, B, blk, sigma, lg, lane, wv, half, lds_wave, bnd_wg, prog, red);
             if (wv == 0 && (uint32_t)lane < gl)
                 osw_store_score(p, q, (size_t)blk.seq0 + 2 * (sigma * gl + lane) + half, score);
         }
@@ -1796,6 +1915,13 @@ extern "C" __global__ __launch_bounds__(256) void osw_build_pair_profile8(const 
 // ---------------------------------------------------------------------------
 
 #define OSW_SEARCH_SHAPED_VGPRS() asm volatile("v_mov_b32 v167, 0" ::: "v167")
+
+// the hand-scheduled int32 cell's floor table (CellI32F): entry k = "zero" in the frame of column k - G
+extern "C" __global__ __launch_bounds__(256) void osw_floor_i32(uint2 *__restrict__ t, uint32_t n, uint32_t ge)
+{
+    OSW_SEARCH_SHAPED_VGPRS();
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) t[k] = make_uint2(k * ge, k * ge);
+}
 
 // the pad columns of `tiled` (and everything else a chunk's re-tile does not write): dummy residues; instead of the runtime's fill
 // kernel, which is not search-shaped
@@ -2273,6 +2399,14 @@ hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s)
     return hipSuccess;
 }
 
+hipError_t osw_launch_floor_i32(uint2 *t, uint32_t n, uint32_t ge, hipStream_t s)
+{
+    if (n == 0 && t) return hipSuccess; // (null, 0: the first launch of the kernel, at bring-up)
+    hipLaunchKernelGGL(osw_floor_i32, dim3(64), dim3(256), osw_shape_lds((const void *)osw_floor_i32), s, t, n, ge);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 static size_t osw_shape_lds(const void *kern);
 hipError_t osw_launch_copy16(const void *src_host_pinned, void *dst, size_t bytes, hipStream_t s)
 {
@@ -2293,6 +2427,7 @@ hipError_t osw_warm_aux_kernels(hipStream_t s)
                        (const uint32_t *)nullptr, (const uint16_t *)nullptr, 0u, 0u, (uint4 *)nullptr);
     hipLaunchKernelGGL(osw_build_pair_profile8, dim3(1, 1), dim3(256), 0, s, (const uint2 *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr, (const uint16_t *)nullptr, 0u, 0, (uint2 *)nullptr);
+    hipLaunchKernelGGL(osw_floor_i32, dim3(1), dim3(256), 0, s, (uint2 *)nullptr, 0u, 0u);
     hipLaunchKernelGGL(osw_topr_part, dim3(1, 1), dim3(256), 0, s, (const int32_t *)nullptr, 0u, 0u, 0u, 1u, (const uint32_t *)nullptr, 0u, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(osw_topr_fold, dim3(1), dim3(256), 0, s, (const unsigned long long *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0, 0u, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(osw_topr_untag, dim3(1), dim3(256), 0, s, (const unsigned long long *)nullptr, 0u, 0u, 0u, (int32_t *)nullptr, (uint32_t *)nullptr);

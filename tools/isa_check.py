@@ -37,6 +37,11 @@ GROUPS = (
     dict(kernels=("osw_sw_i32",), define="OSW_INFLIGHT", file="sw_kernels.hip",
          budget=168,   # the hand-scheduled int32 cell (cell_bits = 32): the int16 kernels' column loop and register budget
          scratch=0, min_asm_uses=500, nfixed=27),
+    dict(kernels=("osw_sw_i32r",), define="OSW_INFLIGHT", file="sw_kernels.hip",
+         budget=168,   # the same cell in the re-run pipeline (4-row strips only)
+         scratch=0, min_asm_uses=40, nfixed=27,
+         windows=False),  # (its batch loop polls / publishes progress words between the steps -- LDS accesses -- and stores the item's score behind
+                          # the rounds; the linear scan of check_vmem_windows does not follow that control flow)
     dict(kernels=("osw_sw_q8",), define="OSW8_INFLIGHT", file="q8_cell.h",
          budget=80,    # six waves per SIMD; the compiler gets 72, the asm 8 more
          scratch=0, min_asm_uses=100, nfixed=8),
@@ -179,12 +184,10 @@ def check_cell_shape(isa):
 
 
 def check_int32_cell(isa):
-    """The exact kernels.  osw_sw_i32 (whole searches with cell_bits = 32; hand-scheduled since the second session of round 5):
-    the row is v_add_u32_sdwa + 3.5 v_max3_i32 + 2 v_subrev_u32 -- no unpacking of the int16 scores (v_bfe_i32 /
-    v_ashrrev_i32), no three-operand add --, profile by ds_read_b64, three waves per SIMD (168 VGPRs), no scratch.
-    osw_sw_i32r (the re-run pipeline, compiler-scheduled, column frames): no scratch at all -- a spill inside its column
-    loops is scratch traffic per cell --, v_max3_i32 / v_add3_u32 of the frame formulation, <= 256 VGPRs (two waves per
-    SIMD).  -> list of complaints"""
+    """The exact kernels, hand-scheduled since the second session of round 5: osw_sw_i32 (whole searches with cell_bits = 32, strips of
+    4 .. 48 rows) and osw_sw_i32r (the re-run pipeline, 4-row strips).  The row is v_add_u32_sdwa + 3.5 v_max3_i32 + 2 v_subrev_u32 -- no
+    unpacking of the int16 scores (v_bfe_i32 / v_ashrrev_i32), no three-operand add --, profile by ds_read_b64, <= 168 VGPRs, no
+    scratch at all.  -> list of complaints"""
     text, bad, counts, fn = "\n".join(isa), [], {}, None
     for line in isa:
         m = re.match(r'^(osw_\w+):', line)
@@ -194,25 +197,22 @@ def check_int32_cell(isa):
             op = line.split(";")[0].strip().split(" ")[0]
             counts.setdefault(fn, {}).setdefault(op, 0)
             counts[fn][op] += 1
-    for k, vmax in (("osw_sw_i32", 168), ("osw_sw_i32r", 256)):
+    for k, min_rows in (("osw_sw_i32", 600), ("osw_sw_i32r", 8)):
         m = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)' % k, text)
         m2 = re.search(r'\.name:\s+%s\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)' % k, text)
-        if not m or int(m.group(1)) > vmax:
+        if not m or int(m.group(1)) > 168:
             bad.append("%s needs %s VGPRs" % (k, m.group(1) if m else "?"))
         if not m2 or int(m2.group(1)) != 0:
             bad.append("%s spills %s bytes per lane" % (k, m2.group(1) if m2 else "?"))
         c = counts.get(k, {})
         if c.get("scratch_load_dword", 0) or c.get("scratch_store_dword", 0):
             bad.append("%s has scratch traffic" % k)
-        if k == "osw_sw_i32":
-            rows = c.get("v_add_u32_sdwa", 0)
-            if rows < 600 or c.get("v_max3_i32", 0) < 3.4 * rows or c.get("v_bfe_i32", 0) or c.get("v_ashrrev_i32_e32", 0) or c.get("v_add3_u32", 0) > 60:
-                bad.append("%s: %d v_add_u32_sdwa, %d v_max3_i32, %d v_bfe_i32, %d v_add3_u32 (one SDWA add and 3.5 maxima per row, no unpacking)"
-                           % (k, rows, c.get("v_max3_i32", 0), c.get("v_bfe_i32", 0), c.get("v_add3_u32", 0)))
-            if c.get("ds_read_b64", 0) < 100 or c.get("ds_read_b128", 0):
-                bad.append("%s reads its profile with %d ds_read_b64, %d ds_read_b128" % (k, c.get("ds_read_b64", 0), c.get("ds_read_b128", 0)))
-        elif c.get("v_max3_i32", 0) < 100 or c.get("v_add3_u32", 0) < 40:
-            bad.append("%s: %d v_max3_i32, %d v_add3_u32 (the frame formulation has three and one per row)" % (k, c.get("v_max3_i32", 0), c.get("v_add3_u32", 0)))
+        rows = c.get("v_add_u32_sdwa", 0)
+        if rows < min_rows or c.get("v_max3_i32", 0) < 3.4 * rows or c.get("v_bfe_i32", 0) or c.get("v_ashrrev_i32_e32", 0) or c.get("v_add3_u32", 0) > 60:
+            bad.append("%s: %d v_add_u32_sdwa, %d v_max3_i32, %d v_bfe_i32, %d v_add3_u32 (one SDWA add and 3.5 maxima per row, no unpacking)"
+                       % (k, rows, c.get("v_max3_i32", 0), c.get("v_bfe_i32", 0), c.get("v_add3_u32", 0)))
+        if c.get("ds_read_b64", 0) < min_rows // 4 or c.get("ds_read_b128", 0):
+            bad.append("%s reads its profile with %d ds_read_b64, %d ds_read_b128" % (k, c.get("ds_read_b64", 0), c.get("ds_read_b128", 0)))
     return bad
 
 
@@ -229,7 +229,7 @@ def check(isa=None):
         assert not bad, "compiler-scheduled instructions touch in-flight registers: %r" % bad[:8]
         budget = check_register_budget(isa, group)
         assert not budget, "; ".join(budget)
-        vm = check_vmem_windows(isa, group)
+        vm = check_vmem_windows(isa, group) if group.get("windows", True) else []
         assert not vm, "compiler-issued vector memory inside an asm load window: %r" % vm[:8]
     return isa
 
@@ -261,7 +261,7 @@ def stamp():
                        "; ".join("%s: <= %d VGPRs, <= %d B of scratch outside the column loops" % ("/".join(g["kernels"]), g["budget"], g["scratch"]) for g in GROUPS),
                        "no compiler-issued vector memory (spill traffic included) inside the asm load windows",
                        "single-query int16 kernels: one v_pk_mad_i16 per row, no v_perm_b32; profile reads are ds_read_b128",
-                       "osw_sw_i32: hand-scheduled rows (v_add_u32_sdwa + 3.5 v_max3_i32, ds_read_b64), 168 VGPRs, no scratch; osw_sw_i32r: no scratch, <= 256 VGPRs, v_max3_i32 / v_add3_u32 of the column-frame int32 cell"]}
+                       "osw_sw_i32 / osw_sw_i32r: hand-scheduled int32 rows (v_add_u32_sdwa + 3.5 v_max3_i32, ds_read_b64), <= 168 VGPRs, no scratch"]}
     with open(STAMP, "w") as f:
         json.dump(info, f, indent=1)
     return info
