@@ -61,15 +61,16 @@ N_CU = 256
 SIMD_PER_CU = 4
 # VALU instructions per wave per query row (= per 128 cells) of the DP kernels: {first-pass arithmetic: (one query per
 # lane: two sequences per lane, their scores paired and added by one v_pk_mad_i16; query pairs)}
-PK_OPS_PER_ROW = {16: (6.5, 6.5), 32: (24.0, 24.0), 8: (20.0, 20.0)}  # 8: 39 SWAR instructions + 1 v_perm_b32 per row of a 2 x 2 tile = 256 cells (q8_cell.h, CellQ8F)
+PK_OPS_PER_ROW = {16: (6.5, 6.5), 32: (13.0, 13.0), 8: (20.0, 20.0)}  # 8: 39 SWAR instructions + 1 v_perm_b32 per row of a 2 x 2 tile = 256 cells (q8_cell.h, CellQ8F)
 # ... and what such a row costs in core-clock cycles per SIMD at 4 waves per SIMD.  int16: MEASURED on the cell's own
 # instruction mix (tools/oprate2.hip, profiles/r02_oprate2_valu_mix.txt: 3.5 VOP3P + 3 VOP2 = 25.3 cycles for the query-pair
 # row; the sequence-pair row -- since the third session of round 4 one v_pk_mad_i16 pairs the two sequences' scores and adds them, where a
 # v_perm_b32 and a packed add did (7.5 instructions, 30.5 cycles) -- is the same row with a VOP3P instead of the 32-bit add: 27.3 cycles
 # without its loads, tools/oprate8.hip "none", profiles/r04_oprate8_pk_mad.txt); int8: MEASURED on the cell's own column
 # step at the six waves per SIMD osw_sw_q8 runs at (tools/oprate_q8.hip, profiles/r04_oprate_q8.txt: the hand-scheduled cell of
-# round 4 takes 90.9 cycles per row of a 2 x 2 tile = 256 cells; round 3's compiler-scheduled one took 129.5); int32: instructions x 4.25, an estimate.
-ROW_CYCLES = {16: (27.3, 25.3), 32: (102.0, 102.0), 8: (45.45, 45.45)}
+# round 4 takes 90.9 cycles per row of a 2 x 2 tile = 256 cells; round 3's compiler-scheduled one took 129.5); int32 (hand-scheduled since
+# round 5: 6.5 instructions per row of 64 cells): MEASURED, tools/oprate9.hip "none" at three waves per SIMD, 26.37 cycles per 64 cells (profiles/r05_oprate9_int32_row.txt).
+ROW_CYCLES = {16: (27.3, 25.3), 32: (52.74, 52.74), 8: (45.45, 45.45)}
 DTYPE = {16: "int16", 32: "int32", 8: "int8"}
 CELL_LABEL = {16: "int16 cells (packed, column frames, exact < 22256), int32 re-run above", 32: "int32 cells",
               8: "int8 cells (four 7-bit SWAR cells per register) with int16 re-run of what leaves their range, int32 above"}
@@ -384,7 +385,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launches_per_step": round(nlaunch / max(1, args.steps), 2),
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
                                   "instr_per_128_cells": ops_row, "cycles_per_128_cells": row_cycles,
-                                  "note": "the DP is VALU-issue bound: instr_per_128_cells VALU instructions per wave per query row (query-pair cell for a multi-query search) issue in cycles_per_128_cells core-clock cycles per SIMD (measured on the cell's instruction mix: profiles/r02_oprate2_valu_mix.txt for the int16 cells, profiles/r04_oprate_q8.txt for the 8-bit cell); ceiling = 1024 SIMDs x 2.4 GHz / that x 128"}},
+                                  "note": "the DP is VALU-issue bound: instr_per_128_cells VALU instructions per wave per query row (query-pair cell for a multi-query search) issue in cycles_per_128_cells core-clock cycles per SIMD (measured on the cell's instruction mix: profiles/r02_oprate2_valu_mix.txt for the int16 cells, profiles/r04_oprate_q8.txt for the 8-bit cell, profiles/r05_oprate9_int32_row.txt for the int32 cell); ceiling = 1024 SIMDs x 2.4 GHz / that x 128"}},
             # the north star's ">= 0.5 x HBM roofline" is only well posed under the reference's own traffic
             # model, 1 B of substitution score per cell streamed from device DRAM (sw.cl:57): 8 TB/s = 8000 GCUPS
             "reference_traffic_model": {"bytes_per_cell": 1.0, "roofline_gcups": HBM_PEAK_GBS, "frac": round(gcups / world / HBM_PEAK_GBS, 4)},

@@ -69,6 +69,7 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     bool no_direct_table = false;      // OSWALD_HIP_NO_DIRECT_TABLE=1 (A/B and test hook): score tables leave by DMA on the download stream even when the kernels could write them
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
+    double warm_ms = 0.0;              // OSWALD_HIP_WARM_MS=ms: oswald_hip_reserve_chunks ends with every CU of the device busy for that long (experiment: clock ramp before a first search)
     size_t split_bytes = 32u << 20;    // OSWALD_HIP_SPLIT_BYTES=bytes: from this size on an asynchronous upload that finds its device idle is cut into head + rest (0: never; a small value: test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 0.95, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5, entries_per_wg = 4.0;
@@ -98,6 +99,7 @@ void Tunables::refresh()
     no_direct_table = flag("OSWALD_HIP_NO_DIRECT_TABLE");
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     split_bytes = (size_t)num("OSWALD_HIP_SPLIT_BYTES", (double)(32u << 20));
+    warm_ms = num("OSWALD_HIP_WARM_MS", 0.0);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
 #ifdef OSW_DIAG
     pair_margin = num("OSWALD_HIP_PAIR_MARGIN", pair_margin);
@@ -1243,6 +1245,10 @@ int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes
             if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
             if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
             if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
+        }
+        if (ctx->tun.warm_ms > 0) {
+            HIP_TRY(osw_launch_spin((uint32_t *)d.counters.p, d.grid, std::min(ctx->tun.warm_ms, 50.0), d.stream));
+            HIP_TRY(hipStreamSynchronize(d.stream));
         }
     }
     return 0;

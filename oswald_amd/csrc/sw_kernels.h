@@ -8,11 +8,10 @@
 
 #define OSW_WG_THREADS 256   // 4 waves per workgroup, each wave independent
 #define OSW_RMAX16 48        // query rows per strip, packed int16 kernels (2 state registers per row; 168 VGPRs = three waves per SIMD)
-#define OSW_RMAX32 16        // query rows per strip, int32 kernel
 #define OSW_LDS_ROWS16 192   // profile rows a wave keeps in LDS per round (12 KB; three workgroups of four waves per CU), packed int16 kernels
 #define OSW_SEQ_CODES 24     // residue codes per row-block of the single-query int16 kernels' profile (16 B each: 96 B per query row)
 #define OSW_LDS_ROWS16_SEQ 128 // ... of which a wave's 12 KB hold 128 rows (the query-pair profile: 32 codes x 16 B, OSW_LDS_ROWS16 / 2 rows)
-#define OSW_LDS_ROWS32 256   // same, int32 kernel (16 KB)
+#define OSW_LDS_ROWS32 256   // profile rows of a wave of the int32 re-run pipeline (osw_sw_i32r: 64 lane groups x 4 rows, 16 KB)
 #define OSW_RMAX32F 48       // query rows per strip of the hand-scheduled int32 cell (whole searches with cell_bits = 32: the int16 kernels' register budget)
 #define OSW_LDS_ROWS32F 192   // ... and its profile rows per wave (64 B per row: 12 KB, three workgroups per CU)
 #define OSW_RMAX8 12         // query rows per strip, SWAR 8-bit kernel (compiler-scheduled; 12 rows keep it within the 80 VGPRs of six waves per SIMD)
@@ -193,6 +192,7 @@ hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s); 
 // the int32 cell's floor table, built on the device: t[k] = {k * ge, k * ge}, k < n
 hipError_t osw_launch_floor_i32(uint2 *t, uint32_t n, uint32_t ge, hipStream_t s);
 hipError_t osw_launch_copy16(const void *src_host_pinned, void *dst, size_t bytes, hipStream_t s); // page-locked host -> device by a kernel that reads the host buffer in place
+hipError_t osw_launch_spin(uint32_t *sink, uint32_t grid, double ms, hipStream_t s); // every CU busy for `ms` (clock ramp before a first search)
 hipError_t osw_warm_aux_kernels(hipStream_t s); // first launches of the profile / top-list kernels (bring-up)
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);

@@ -637,66 +637,6 @@ typedef CellQueryPair<ArithI16B> CellPK16BQ;
 typedef CellSeqPair<ArithI16S<false>> CellPK16S;
 typedef CellQueryPair<ArithI16S<true>> CellPK16SQ;
 
-// Plain int32 cell: one sequence per lane (the `half` of the lane's pair), exact.  Compiler-scheduled (rare path: the re-run of
-// what reached the int16 cells' ceiling; whole searches with cell_bits = 32), but since round 5 in the COLUMN-FRAME formulation
-// of the int16 cell (see ArithI16S): every value of database column j is stored as  true + (j + G) * ge,  so the horizontal gap
-// needs no decay and the vertical one comes out of its maximum, and the zero floors are the third operand of a v_max3_i32:
-//   x = D + S + ge (one frame on: v_add3_u32);  H = max3(x, E, F);  u = H - go;  E = max3(E, u, fl1);  F = max3(F, u, fl1) - ge;
-//   cm = max(cm, H)                                   -- 7 instructions + the unpacking of S per row of 64 cells (12.4 before)
-// fl1 = "zero" in the frame of column j + 1; the round turns the column's maximum cm back into a true score (cm - fl).  int32
-// has room for any frame: 65535 columns x ge <= 32767 < 2^31.  `goe` carries the gap OPEN penalty for this cell.
-template <int RMAX, int LDSROWS>
-struct CellI32T {
-    typedef int T;
-    typedef int GapT;
-    static constexpr bool kFast = false;
-    static constexpr uint32_t kFloorBits = 0;
-    static constexpr bool kShifted = true; // (framed values travel between strips: run_item's pad columns hold the frame's zero)
-    static constexpr int kRows = RMAX;
-    static constexpr int kLdsRows = LDSROWS;
-    static constexpr int kCodes = 32;
-    static constexpr int kRowBytes = 64;
-    typedef uint2 Entry;
-    static __device__ __forceinline__ T zero() { return 0; }
-    static __device__ __forceinline__ T from_bits(uint32_t x) { return (int)x; }
-    static __device__ __forceinline__ uint32_t to_bits(T x) { return (uint32_t)x; }
-    static __device__ __forceinline__ T vmax(T a, T b) { return a > b ? a : b; }
-    static __device__ __forceinline__ T score_init(GapT) { return 0; }
-
-    // The profile slice of a round is INTERLEAVED over the G lane groups (round 5): entry (row-block rb, code, group g) at
-    // ((rb * 32 + code) * G + g) * 8 bytes.  These kernels run at wide geometries -- the re-run at G = 64: every lane a strip of
-    // its own, i.e. a table of its own -- and with the tables one behind the other 32 lanes read 32 different tables at
-    // code-dependent places: ~4 lanes per 8-byte slot, every ds_read_b64 several times its two LDS cycles.  Interleaved, a lane's
-    // slot is (code * G + g) mod 32 = g mod 32 for G >= 32: the 32 lanes of a hardware half never collide, whatever their residues.
-    static constexpr bool kInterleaved = true;
-    // fl1: zero in the frame of the NEXT column; cm: the column's maximum in this column's frame (written by row 0);
-    // base: LDS address of the lane group's first entry (region + 8 g); G: lane groups of the geometry
-    template <int R>
-    static __device__ __forceinline__ void column(uint32_t base, uint32_t G, uint32_t codes, int half, T (&D)[R], T (&E)[R],
-                                                  T top_prev, T &f, T &hl, GapT go, GapT ge, T fl1, T &cm)
-    {
-        const lds_cp lp = (lds_cp)(uintptr_t)(base + ((codes >> (half * 8)) & 0xffu) * G); // (`tiled` holds 8 * code)
-        T diag = top_prev;
-#pragma unroll
-        for (int rb = 0; rb < R / 4; ++rb) {
-            const u32x2 p = *(lds_u2p)(lp + rb * 256 * G);
-            const int s[4] = {(int)(short)(p.x & 0xffffu), (int)p.x >> 16, (int)(short)(p.y & 0xffffu), (int)p.y >> 16};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = rb * 4 + k;
-                const T x = diag + s[k] + ge; // the diagonal sits one frame back
-                const T h = vmax(vmax(x, E[r]), f);
-                const T u = h - go;
-                E[r] = vmax(vmax(E[r], u), fl1);
-                f = vmax(vmax(f, u), fl1) - ge;
-                cm = r == 0 ? h : vmax(cm, h);
-                if (r + 1 < R) { diag = D[r + 1]; D[r + 1] = h; } else { hl = h; }
-            }
-        }
-    }
-};
-typedef CellI32T<OSW_RMAX32, OSW_LDS_ROWS32> CellI32;    // the re-run pipeline (osw_sw_i32r)
-
 // The hand-scheduled int32 cell (ArithI32F) for whole searches with cell_bits = 32: 48-row strips and the packed-int16 kernels'
 // column loop (sw_round_fast: fixed registers, loads two columns ahead, three waves per SIMD).  go = gap OPEN, ge = gap extend,
 // plain 32-bit values (wave-uniform); floors / frames as in ArithI16S without the fp16 bias; a first round reads the row above
@@ -771,10 +711,6 @@ struct CellI32FP : CellI32F {
     static constexpr int kRows = 4;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
 };
-
-// cells whose profile slice is interleaved over the lane groups (CellI32::kInterleaved)
-template <class C, class = void> struct osw_interleaved : std::false_type {};
-template <class C> struct osw_interleaved<C, std::enable_if_t<C::kInterleaved>> : std::true_type {};
 
 static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
 {
@@ -1093,74 +1029,6 @@ static __device__ __forceinline__ void sw_round_q8f(const uint16_t *tcol, uint32
     score = (sc & gp.L) | (fl & gp.G);
 }
 
-// Compiler-scheduled version of the same round (int32 cell, column frames: see CellI32).  The inputs of a step -- the
-// column's residues and, behind a first round, the boundary entry of the round before -- are loaded OSW_PLAIN_AHEAD steps
-// ahead (round 5; the loads used to be issued in the step that needs them).
-#ifndef OSW_PLAIN_AHEAD
-#define OSW_PLAIN_AHEAD 4u
-#endif
-template <class C, int R>
-static __device__ __forceinline__ void sw_round_plain(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
-                                                      const uint2 * /*top_pages*/, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
-                                                      typename C::GapT goe, typename C::GapT ge, typename C::T &score)
-{
-    typedef typename C::T T;
-    const uint32_t g = (uint32_t)lane / gl;
-    const T go = goe - ge; // (the cell wants the gap OPEN penalty)
-    // "zero" in the frame of this lane's current column: the lane starts at column -g, whose frame offset is (G - g) * ge
-    T fl = (T)((G - g) * (uint32_t)ge), fl_prev = fl - ge;
-    T D[R], E[R], top_prev = fl_prev;
-#pragma unroll
-    for (int r = 0; r < R; ++r) { D[r] = fl_prev; E[r] = fl; }
-    const bool g0 = (uint32_t)lane < gl;
-    const bool glast = (uint32_t)lane >= 64u - gl;
-    const int src = ((lane - (int)gl) & 63) << 2;
-    const uint16_t *tb = tcol + u;
-    uint2 *col = bnd + OSW_SCRATCH_DATA + u;
-    const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
-    uint32_t hand_h = (uint32_t)fl, hand_f = (uint32_t)fl, hand_c = dummy;
-    const uint32_t nsteps = ncols + G - 1;
-    uint32_t cq[OSW_PLAIN_AHEAD];
-    uint2 bq[OSW_PLAIN_AHEAD];
-    uint32_t bv[OSW_PLAIN_AHEAD]; // the boundary entry was read (else: the frame's zero)
-    auto load_step = [&](uint32_t t, uint32_t &c, uint2 &bb, uint32_t &valid) {
-        c = dummy;
-        bb = make_uint2(0u, 0u);
-        valid = 0;
-        if (t < ncols) {
-            c = tb[(size_t)t * 64];
-            if (!first) { bb = col[(size_t)t * gl]; valid = 1; }
-        }
-    };
-#pragma unroll
-    for (uint32_t k = 0; k < OSW_PLAIN_AHEAD; ++k) load_step(k, cq[k], bq[k], bv[k]);
-#pragma unroll 1
-    for (uint32_t tg = 0; tg < nsteps; tg += OSW_PLAIN_AHEAD) {
-#pragma unroll
-        for (uint32_t k = 0; k < OSW_PLAIN_AHEAD; ++k) {
-            const uint32_t t = tg + k;
-            if (t < nsteps) {
-                // the row above: the round before's boundary entry, or -- a first round, a column past the block -- zero in this column's frame
-                uint32_t codes = cq[k], topb = bv[k] ? bq[k].x : (uint32_t)fl, fb = bv[k] ? bq[k].y : (uint32_t)fl;
-                load_step(t + OSW_PLAIN_AHEAD, cq[k], bq[k], bv[k]);
-                if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
-                T f = C::from_bits(fb), hl, cm;
-                const T fl1 = fl + ge;
-                C::template column<R>(base, G, codes, half, D, E, top_prev, f, hl, go, ge, fl1, cm);
-                score = C::vmax(score, cm - fl);
-                fl = fl1;
-                top_prev = C::from_bits(topb);
-                if (!last && t + 1 >= G && glast) col[(size_t)(t + 1 - G) * gl] = make_uint2(C::to_bits(hl), C::to_bits(f));
-                if (G > 1) {
-                    hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(hl));
-                    hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)C::to_bits(f));
-                    hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
-                }
-            }
-        }
-    }
-}
-
 template <class C>
 static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
                                                          const uint2 *top_pages, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
@@ -1170,8 +1038,7 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
     case RR:                                                                                                                    \
         if constexpr (RR > C::kRows) break; /* taller than the cell's strips: never planned, not compiled */                    \
         else if constexpr (std::is_same<C, CellQ8F>::value) sw_round_q8f<RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, goe, score); \
-        else if constexpr (C::kFast) sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score); \
-        else sw_round_plain<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);                  \
+        else sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);          \
         break
     switch (R) {
         OSW_ROUND_CASE(4);
@@ -1180,8 +1047,7 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
     default:
         if constexpr (C::kRows >= 16) {
             if (R == 16) {
-                if constexpr (C::kFast) sw_round_fast<C, 16>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);
-                else sw_round_plain<C, 16>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);
+                sw_round_fast<C, 16>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);
                 break;
             }
         }
@@ -1221,20 +1087,6 @@ static __device__ __forceinline__ void fill_profile_slice(const E *prof_q, uint3
         const E *src = prof_q + (size_t)rbs * NC;
         E *d = dst + (size_t)g * (per_group + 1u);
         for (uint32_t e = tid; e < per_group; e += nthr) d[e] = e < valid ? src[e] : E{};
-    }
-}
-
-// The same slice INTERLEAVED over the lane groups (CellI32): entry (row-block rb, code, group g) at (rb * NC + code) * G + g.
-template <class E, uint32_t NC = 32u>
-static __device__ __forceinline__ void fill_profile_slice_interleaved(const E *prof_q, uint32_t rb0, uint32_t rbg, uint32_t G, uint32_t rb_end, E *dst,
-                                                                      uint32_t tid, uint32_t nthr)
-{
-    const uint32_t per_group = rbg * NC, total = per_group * G;
-    for (uint32_t i = tid; i < total; i += nthr) {
-        const uint32_t g = i & (G - 1), e = i / G; // (G is a power of two; consecutive threads fill consecutive 8-byte slots)
-        const uint32_t rbs = rb0 + g * rbg;
-        const uint32_t valid = rb_end > rbs ? ((rb_end - rbs) < rbg ? (rb_end - rbs) : rbg) * NC : 0u;
-        dst[i] = e < valid ? prof_q[(size_t)rbs * NC + e] : E{};
     }
 }
 
@@ -1299,7 +1151,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         }
     }
     T score;
-    if constexpr (!C::kFast || std::is_same<C, CellQ8F>::value) score = C::score_init(goe);   // "zero" may depend on the scoring system (8-bit cell)
+    if constexpr (std::is_same<C, CellQ8F>::value) score = C::score_init(goe);   // "zero" may depend on the scoring system (8-bit cell)
     else if constexpr (C::kShifted) score = C::from_bits(0u); // the column-frame cell keeps a true (unbiased) running score
     else score = C::zero();
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
@@ -1312,8 +1164,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             __syncthreads(); // every wave is done with the previous slice
             uint32_t tid = threadIdx.x;
             asm volatile("" : "+v"(tid)); // keep the per-thread source address out of the registers that live across the rounds
-            if constexpr (osw_interleaved<C>::value) fill_profile_slice_interleaved<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
-            else fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
+            fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, tid, OSW_WG_THREADS);
             __syncthreads();
 #ifdef OSW_DIAG
             if (p.wg_times && lane == 0) atomicAdd(&p.counters_ovf[4], (uint32_t)((__builtin_readcyclecounter() - tb) >> 10));
@@ -1322,13 +1173,11 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             // only this wave touches its region; LDS operations of one wave execute in order, the wave barriers
             // only pin the compiler's order
             __builtin_amdgcn_wave_barrier();
-            if constexpr (osw_interleaved<C>::value) fill_profile_slice_interleaved<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
-            else fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
+            fill_profile_slice<Entry, (uint32_t)C::kCodes>(prof_q, rb0, R / 4, G, rb_end, (Entry *)lds_region, (uint32_t)lane, 64u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t base = osw_interleaved<C>::value ? (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (uint32_t)sizeof(Entry))
-                                                        : (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
+        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
         sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, osw_top_pages<C>(p), rho == 0 || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score);
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
@@ -1536,155 +1385,23 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
 
 // ---------------------------------------------------------------------------
-// The int32 re-run of ONE (query, sequence) on the FOUR waves of a workgroup (round 4).  A sequence that reaches the
-// int16 cells' ceiling is a near-copy of a long query: thousands of rows against thousands of columns, 20+ rounds of 256
-// rows at geometry 64, which one wave ran one after the other -- 30-60 ms per item, with a hundred such items on a
-// device of 4096 wave slots the re-run took a quarter of the whole search although it is 0.2 % of its cells
-// (bench.py --workload hi).  Here wave w of the workgroup runs rounds w, w+4, w+8, ... of the item, each behind the
-// round before it by a few dozen columns: the boundary row {H, F} of round rho goes through the spill scratch of the
-// wave that ran it (a region per wave, as always) to the wave that runs round rho+1, column by column.  The producer
-// publishes, in LDS, how many columns of its round are stored (a workgroup-scope release fence in front: the stores
-// have been performed; the waves of a workgroup share the CU's L1); the consumer waits for the columns of its next
-// batch of 32 steps (acquire fence behind the wait).  No wave ever waits for a later round, the first round waits for
-// nothing, and the four waves of a workgroup are resident together: the waits cannot deadlock.  A region is overwritten
-// by its owner's NEXT round (rho+4), which depends -- through rounds rho+3, rho+2, rho+1 -- on the reader of this
-// round's row having been there already.
+// The int32 re-run of ONE (query, sequence) on the EIGHT waves of a workgroup.  A sequence that reaches the int16 cells'
+// ceiling is a near-copy of a long query: thousands of rows against thousands of columns, 20+ rounds of 256 rows at
+// geometry 64 (every lane a 4-row strip), which one wave ran one after the other until round 4 -- 30-60 ms per item; with
+// a hundred such items on a device of 4096 wave slots the re-run took a quarter of the whole search although it is 0.2 %
+// of its cells (bench.py --workload hi).  Here wave w of the workgroup runs rounds w, w+8, w+16, ... of the item, each
+// behind the round before it by a few dozen columns: the boundary row {H, F} of round rho goes through the spill scratch
+// of the wave that ran it (a region per wave, as always) to the wave that runs round rho+1, column by column
+// (sw_round_fast<.., PIPE>).  The producer publishes, in LDS, how many columns of its round are stored (its stores have
+// been performed; the waves of a workgroup share the CU's L1); the consumer waits for the columns of its next batch of 32
+// steps.  No wave ever waits for a later round, the first round waits for nothing, and the waves of a workgroup are
+// resident together: the waits cannot deadlock.  A region is overwritten by its owner's NEXT round (rho+8), which depends
+// -- through rounds rho+7 ... rho+1 -- on the reader of this round's row having been there already.
+//   Round 5, second session: the hand-scheduled cell (CellI32FP) in the packed-int16 kernels' column loop.  The compiler-
+// scheduled round before it handed the residues from lane to lane together with the row, so the profile read of a step
+// waited for the hand-off of the step before (~1 050 cycles per step); here every lane loads its own residues two columns
+// ahead, from a compact copy of the sequence (560 cycles per step: hi's 133 items 8.75 -> 4.67 ms).  `lane` is the logical lane.
 // ---------------------------------------------------------------------------
-template <int R>
-static __device__ __forceinline__ void sw_round_pipe_i32(const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, const uint2 *src_region,
-                                                         uint2 *dst_region, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half, int goe,
-                                                         int ge, int &score, volatile uint32_t *prog_src, volatile uint32_t *prog_mine, uint32_t rho)
-{
-    typedef CellI32 C;
-    // column frames (see CellI32): "zero" in the frame of this lane's current column; the lane starts at column -g
-    const uint32_t g = (uint32_t)lane / gl;
-    const int go = goe - ge;
-    int fl = (int)((G - g) * (uint32_t)ge), fl_prev = fl - ge;
-    int D[R], E[R], top_prev = fl_prev;
-#pragma unroll
-    for (int r = 0; r < R; ++r) { D[r] = fl_prev; E[r] = fl; }
-    const bool g0 = (uint32_t)lane < gl;
-    const bool glast = (uint32_t)lane >= 64u - gl;
-    const int src = ((lane - (int)gl) & 63) << 2;
-    const uint16_t *tb = tcol + u;
-    const uint2 *colr = src_region + OSW_SCRATCH_DATA + u;
-    uint2 *colw = dst_region + OSW_SCRATCH_DATA + u;
-    const uint32_t dummy = OSW_DUMMY_CODE8 | (OSW_DUMMY_CODE8 << 8);
-    uint32_t hand_h = (uint32_t)fl, hand_f = (uint32_t)fl, hand_c = dummy;
-    const uint32_t nsteps = ncols + G - 1;
-    // The inputs of a step -- the column's residues and, behind a first round, the boundary entry of the round before --
-    // are loaded OSW_PIPE_AHEAD steps ahead: a re-run item has one wave per SIMD (its workgroup is alone on its CU more
-    // often than not), so nothing else hides the latency of a load issued in the step that needs it (20 ms for the 133
-    // items of bench.py --workload hi, four times what the instructions take).
-    constexpr uint32_t AHEAD = 4;
-    static_assert(OSW_PIPE_BATCH % AHEAD == 0, "a batch is whole groups of prefetched steps");
-    uint32_t cq[AHEAD];
-    uint2 bq[AHEAD];
-    uint32_t bv[AHEAD]; // the boundary entry was read (else: the frame's zero)
-    auto wait_for = [&](uint32_t cols) { // columns 0 .. cols-1 of round rho - 1 (published under the tag rho) are stored and visible
-        const uint32_t need = (rho << 20) | (cols < ncols ? cols : ncols);
-        while (*prog_src < need) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    auto load_step = [&](uint32_t t, uint32_t &c, uint2 &bb, uint32_t &valid) {
-        c = dummy;
-        bb = make_uint2(0u, 0u);
-        valid = 0;
-        if (t < ncols) {
-            c = tb[(size_t)t * 64];
-            if (!first) { bb = colr[(size_t)t * gl]; valid = 1; }
-        }
-    };
-    if (!first) wait_for(AHEAD);
-#pragma unroll
-    for (uint32_t k = 0; k < AHEAD; ++k) load_step(k, cq[k], bq[k], bv[k]);
-#pragma unroll 1
-    for (uint32_t t0 = 0; t0 < nsteps; t0 += OSW_PIPE_BATCH) {
-        const uint32_t t1 = t0 + OSW_PIPE_BATCH < nsteps ? t0 + OSW_PIPE_BATCH : nsteps;
-        if (!first) wait_for(t1 + AHEAD); // the batch consumes columns < t1 and loads ahead up to column t1 + AHEAD - 1
-#pragma unroll 1
-        for (uint32_t tg = t0; tg < t1; tg += AHEAD) {
-#pragma unroll
-            for (uint32_t k = 0; k < AHEAD; ++k) {
-                const uint32_t t = tg + k;
-                if (t < t1) {
-                    uint32_t codes = cq[k], topb = bv[k] ? bq[k].x : (uint32_t)fl, fb = bv[k] ? bq[k].y : (uint32_t)fl;
-                    load_step(t + AHEAD, cq[k], bq[k], bv[k]);
-                    if (G > 1 && !g0) { codes = hand_c; topb = hand_h; fb = hand_f; }
-                    int f = (int)fb, hl, cm;
-                    const int fl1 = fl + ge;
-                    C::template column<R>(base, G, codes, half, D, E, top_prev, f, hl, go, ge, fl1, cm);
-                    score = cm - fl > score ? cm - fl : score;
-                    fl = fl1;
-                    top_prev = (int)topb;
-                    if (!last && t + 1 >= G && glast) colw[(size_t)(t + 1 - G) * gl] = make_uint2((uint32_t)hl, (uint32_t)f);
-                    if (G > 1) {
-                        hand_h = (uint32_t)__builtin_amdgcn_ds_bpermute(src, hl);
-                        hand_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, f);
-                        hand_c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)codes);
-                    }
-                }
-            }
-        }
-        if (!last) {
-            // columns 0 .. t1 - G of this round are stored; make them visible, then say so
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 63) *prog_mine = ((rho + 1u) << 20) | (t1 >= G ? t1 + 1u - G : 0u);
-        }
-    }
-}
-
-// one (query, sequence half) on the workgroup: -> the score, valid in the lanes of group 0 of EVERY wave
-template <int NW> // waves of the workgroup = depth of the pipeline
-static __device__ __forceinline__ int run_item_i32_pipe(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma, uint32_t lg,
-                                                        int lane, int wv, int half, uint2 *lds_wave, uint2 *bnd_wg, volatile uint32_t *prog, int *red)
-{
-    typedef CellI32 C;
-    const uint32_t G = 1u << lg, gl = 64u >> lg;
-    const uint32_t u = (uint32_t)lane & (gl - 1), g = (uint32_t)lane >> (6 - lg);
-    const uint32_t ncols = __builtin_amdgcn_readfirstlane((uint32_t)p.sub_cols[(size_t)B * 128 + (G - 1u) + sigma]);
-    const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
-    const OswPlan plan = osw_plan(p.qlen[q], G, C::kLdsRows, C::kRows);
-    const uint2 *prof_q = p.prof + (size_t)p.prof_off[q] * 32u;
-    uint2 *mine = (uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)wv * p.bnd_stride));
-    const uint2 *prev = (const uint2 *)osw_uniform64((uint64_t)(bnd_wg + (size_t)((wv + NW - 1) % NW) * p.bnd_stride));
-    if (lane == 0) prog[wv] = 0;
-    __syncthreads();
-    int score = 0;
-    for (uint32_t rho = (uint32_t)wv; rho < plan.rounds; rho += NW) {
-        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
-        __builtin_amdgcn_wave_barrier();
-        fill_profile_slice_interleaved<uint2>(prof_q, rb0, R / 4, G, rb_end, lds_wave, (uint32_t)lane, 64u);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_wave + g * (uint32_t)sizeof(uint2));
-        const bool first = rho == 0, last = rho + 1 == plan.rounds;
-        volatile uint32_t *ps = prog + ((wv + NW - 1) % NW), *pm = prog + wv;
-        switch (R) {
-        case 4: sw_round_pipe_i32<4>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
-        case 8: sw_round_pipe_i32<8>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
-        case 12: sw_round_pipe_i32<12>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
-        default: sw_round_pipe_i32<16>(tcol, u, ncols, base, prev, mine, first, last, G, gl, lane, half, p.goe, p.ge, score, ps, pm, rho); break;
-        }
-    }
-    // best over the strips = best over the lane groups, then over the waves
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    for (uint32_t off = gl; off < 64; off <<= 1) {
-        const int o = __builtin_amdgcn_ds_bpermute((ln ^ (int)off) << 2, score);
-        score = o > score ? o : score;
-    }
-    red[wv * 64 + lane] = score;
-    __syncthreads();
-    int best = red[lane];
-    for (int w = 1; w < NW; ++w) best = red[w * 64 + lane] > best ? red[w * 64 + lane] : best;
-    __syncthreads(); // (red and prog are free for the next item)
-    return best;
-}
-
-// The same pipeline on the hand-scheduled cell (round 5, second session): every lane loads its own residues two columns ahead (the
-// compiler-scheduled round handed them from lane to lane with the row: the profile read of a step waited for the hand-off of the
-// step before), rows as in CellI32F, the row above through sw_round_fast<.., PIPE>.  `lane` is the logical lane.
 template <int NW>
 static __device__ __forceinline__ int run_item_i32f_pipe(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma, uint32_t lg,
                                                          int lane, int wv, int half, uint2 *lds_wave, uint2 *bnd_wg, volatile uint32_t *prog, int *red)
@@ -1777,7 +1494,7 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 }
 
 // The re-run queue of a search (what reached the int16 cells' ceiling): few, long items -- a workgroup of EIGHT waves per
-// item, a pipeline over the item's rounds (sw_round_pipe_i32); two waves per SIMD hide each other's latencies.  The queue
+// item, a pipeline over the item's rounds (run_item_i32f_pipe); two waves per SIMD hide each other's latencies.  The queue
 // length was produced by the kernels before it on this stream.  Wave w of workgroup b uses spill region 8 b + w: the grid
 // is at most an eighth of the regions (osw_launch_i32r).
 #define OSW_I32R_WAVES 8
@@ -1921,6 +1638,19 @@ extern "C" __global__ __launch_bounds__(256) void osw_floor_i32(uint2 *__restric
 {
     OSW_SEARCH_SHAPED_VGPRS();
     for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) t[k] = make_uint2(k * ge, k * ge);
+}
+
+// keeps every CU issuing vector instructions for `ticks` of the 100-MHz clock (oswald_hip_reserve_chunks: see osw_launch_spin)
+extern "C" __global__ __launch_bounds__(256) void osw_spin(uint32_t *sink, uint64_t ticks)
+{
+    OSW_SEARCH_SHAPED_VGPRS();
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t x = threadIdx.x, y = blockIdx.x;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { x = x * 1664525u + y; y = (y ^ x) + 1013904223u; }
+    }
+    if (x == 0x12345678u && y == 0x9abcdef0u) *sink = x; // (never: keeps the loop)
 }
 
 // the pad columns of `tiled` (and everything else a chunk's re-tile does not write): dummy residues; instead of the runtime's fill
@@ -2395,6 +2125,13 @@ hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s)
     const size_t n16 = bytes / 16;
     const uint32_t grid = (uint32_t)std::min<size_t>((n16 + 255) / 256, 768u * 4u);
     hipLaunchKernelGGL(osw_fill16, dim3(grid), dim3(256), osw_shape_lds((const void *)osw_fill16), s, (uint4 *)p, (uint32_t)byte * 0x01010101u, n16);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_spin(uint32_t *sink, uint32_t grid, double ms, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_spin, dim3(grid), dim3(256), osw_shape_lds((const void *)osw_spin), s, sink, (uint64_t)(ms * 1.0e5));
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -13,7 +13,7 @@ for f in sorted(os.listdir(src)):
             with open(os.path.join(dst, f"r{rnd}_{f}"), "w") as o:
                 json.dump(json.loads(lines[-1]), o, indent=1)
 for a, b in (("shard_balance.txt", f"r{rnd}_shard_balance_1gpu.txt"), ("cli_1m.txt", f"r{rnd}_cli_1m_phases.txt"), ("oprate_q8.txt", f"r{rnd}_oprate_q8.txt"),
-             ("oprate4.txt", f"r{rnd}_oprate4_valu_issue.txt"), ("oprate5.txt", f"r{rnd}_oprate5_pause_placement.txt"), ("oprate6.txt", f"r{rnd}_oprate6_lds_pairing.txt"), ("oprate7.txt", f"r{rnd}_oprate7_sdwa_bytemax.txt"), ("oprate8.txt", f"r{rnd}_oprate8_pk_mad.txt"), ("q1_tail.txt", f"r{rnd}_q1_c5_tail.txt"), ("startup.txt", f"r{rnd}_cli_startup.txt"),
+             ("oprate4.txt", f"r{rnd}_oprate4_valu_issue.txt"), ("oprate5.txt", f"r{rnd}_oprate5_pause_placement.txt"), ("oprate6.txt", f"r{rnd}_oprate6_lds_pairing.txt"), ("oprate7.txt", f"r{rnd}_oprate7_sdwa_bytemax.txt"), ("oprate8.txt", f"r{rnd}_oprate8_pk_mad.txt"), ("oprate9.txt", f"r{rnd}_oprate9_int32_row.txt"), ("q1_tail.txt", f"r{rnd}_q1_c5_tail.txt"), ("startup.txt", f"r{rnd}_cli_startup.txt"),
              ("cli_q1_1m.txt", f"r{rnd}_cli_q1_1m_phases.txt"), ("cli_hybrid.txt", f"r{rnd}_cli_hybrid.txt"), ("inclusive_probe_q1.txt", f"r{rnd}_inclusive_probe_q1.txt"),
              ("inclusive_probe_c4.txt", f"r{rnd}_inclusive_probe_c4.txt"), ("pin_probe.txt", f"r{rnd}_pin_probe.txt")):
     if os.path.exists(os.path.join(src, a)):

@@ -36,7 +36,8 @@ b q1_10m --workload q1 --nseq 10000000 --steps 5 --warmup 1 --cpu-seconds 0
 b 10m --nseq 10000000 --steps 3 --warmup 1 --cpu-seconds 0
 b hi --workload hi --steps 5 --warmup 1 --cpu-seconds 10
 b hi8 --workload hi8 --steps 8 --warmup 2 --cpu-seconds 10
-b c2_int32 --nseq 100000 --cell-bits 32 --steps 3 --warmup 1 --cpu-seconds 0
+b c2_int32 --nseq 100000 --cell-bits 32 --steps 5 --warmup 1 --cpu-seconds 0
+b c4_int32 --nseq 1000000 --cell-bits 32 --steps 3 --warmup 1 --cpu-seconds 0
 OSWALD_BENCH_BACKEND=gloo MASTER_PORT=29641 python bench.py --gpus 4 --steps 5 --warmup 1 --cpu-seconds 0 > $OUT/bench_gloo4.json 2> $OUT/bench_gloo4.err; echo "gloo4 rc=$?"
 OSWALD_BENCH_BACKEND=gloo MASTER_PORT=29642 python bench.py --gpus 4 --shard-rule reference --steps 5 --warmup 1 --cpu-seconds 0 > $OUT/bench_gloo4_reference_rule.json 2> $OUT/bench_gloo4_reference_rule.err; echo "gloo4 reference rule rc=$?"
 python tests/shard_balance_gpu.py 2 4 8 > $OUT/shard_balance.txt 2>&1; echo "shard balance rc=$?"; cat $OUT/shard_balance.txt
@@ -47,6 +48,7 @@ timeout -k 10 100 ./tools/oprate5 > $OUT/oprate5.txt 2>&1
 timeout -k 10 100 ./tools/oprate6 > $OUT/oprate6.txt 2>&1
 timeout -k 10 100 ./tools/oprate7 > $OUT/oprate7.txt 2>&1
 timeout -k 10 100 ./tools/oprate8 > $OUT/oprate8.txt 2>&1
+timeout -k 10 100 ./tools/oprate9 > $OUT/oprate9.txt 2>&1
 fi
 if [ "$PART" = bench ]; then exit 0; fi
 python tools/cli_e2e.py 1000000 /tmp/osw_e2e_1000000 > $OUT/cli_1m.txt 2>&1; echo "cli e2e rc=$?"; tail -5 $OUT/cli_1m.txt
