@@ -763,7 +763,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
             if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_i32(a, 1, d.stream);
-            if (r == hipSuccess) r = osw_launch_i32r(a, 8, d.stream);
+            if (r == hipSuccess) r = osw_launch_i32r(a, 16, d.stream); // (regions: one workgroup of the pipeline)
             if (r == hipSuccess) r = osw_launch_q8(a, 1, d.stream);
             if (r == hipSuccess) r = osw_warm_aux_kernels(d.stream);
             if (r == hipSuccess) r = osw_launch_copy16(nullptr, nullptr, 0, d.stream_up);

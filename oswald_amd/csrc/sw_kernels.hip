@@ -706,10 +706,14 @@ static __device__ __forceinline__ int osw_physical_lane(int l)
     return (l & 32) | (b << 2) | (l & 3);
 }
 
-// the same cell in the re-run pipeline (osw_sw_i32r): geometry 64, 4-row strips (a wave's 17 KB slice holds 64 tables of 4 rows)
+// the same cell in the re-run pipeline (osw_sw_i32r): geometry 64, 4-row strips -- one 4-row block per column, so a lane group's table is
+// a single row-block and may be COMPACT: the 24 residue codes the re-tiled database can hold (OSW_SEQ_CODES), 8 B each = 200 B per lane
+// group with its skew entry, 12.5 KB per wave: twelve waves of a workgroup fit the CU's LDS (with 32 codes: nine)
 struct CellI32FP : CellI32F {
     static constexpr int kRows = 4;
     static constexpr int kLdsRows = OSW_LDS_ROWS32;
+    static constexpr int kCodes = OSW_SEQ_CODES;
+    static constexpr int kRowBytes = 2 * OSW_SEQ_CODES;
 };
 
 static __device__ __forceinline__ uint64_t osw_uniform64(uint64_t x)
@@ -1090,6 +1094,16 @@ static __device__ __forceinline__ void fill_profile_slice(const E *prof_q, uint3
     }
 }
 
+// The same for ONE row-block per lane group, keeping the first NCD of the source's NCS codes per row-block (the re-run pipeline's compact tables)
+template <class E, uint32_t NCS, uint32_t NCD>
+static __device__ __forceinline__ void fill_profile_slice_compact(const E *prof_q, uint32_t rb0, uint32_t G, uint32_t rb_end, E *dst, uint32_t tid, uint32_t nthr)
+{
+    for (uint32_t i = tid; i < G * NCD; i += nthr) {
+        const uint32_t g = i / NCD, code = i - g * NCD, rb = rb0 + g; // group g: row-block rb0 + g of the query
+        dst[(size_t)g * (NCD + 1u) + code] = rb < rb_end ? prof_q[(size_t)rb * NCS + code] : E{};
+    }
+}
+
 // Diagnostics that exist only in the -DOSW_DIAG build of the library (liboswald_hip_diag.so, tools/): per-workgroup
 // time stamps, and a timing experiment that makes every round read the constant top row and store to the trash page
 // (WRONG scores, same instruction stream, no spill traffic).  The shipped library contains neither.
@@ -1385,22 +1399,24 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
 
 // ---------------------------------------------------------------------------
-// The int32 re-run of ONE (query, sequence) on the EIGHT waves of a workgroup.  A sequence that reaches the int16 cells'
+// The int32 re-run of ONE (query, sequence) on the TWELVE waves of a workgroup.  A sequence that reaches the int16 cells'
 // ceiling is a near-copy of a long query: thousands of rows against thousands of columns, 20+ rounds of 256 rows at
 // geometry 64 (every lane a 4-row strip), which one wave ran one after the other until round 4 -- 30-60 ms per item; with
 // a hundred such items on a device of 4096 wave slots the re-run took a quarter of the whole search although it is 0.2 %
-// of its cells (bench.py --workload hi).  Here wave w of the workgroup runs rounds w, w+8, w+16, ... of the item, each
+// of its cells (bench.py --workload hi).  Here wave w of the workgroup runs rounds w, w+12, w+24, ... of the item, each
 // behind the round before it by a few dozen columns: the boundary row {H, F} of round rho goes through the spill scratch
 // of the wave that ran it (a region per wave, as always) to the wave that runs round rho+1, column by column
 // (sw_round_fast<.., PIPE>).  The producer publishes, in LDS, how many columns of its round are stored (its stores have
 // been performed; the waves of a workgroup share the CU's L1); the consumer waits for the columns of its next batch of 32
 // steps.  No wave ever waits for a later round, the first round waits for nothing, and the waves of a workgroup are
-// resident together: the waits cannot deadlock.  A region is overwritten by its owner's NEXT round (rho+8), which depends
-// -- through rounds rho+7 ... rho+1 -- on the reader of this round's row having been there already.
+// resident together: the waits cannot deadlock.  A region is overwritten by its owner's NEXT round (rho+12), which depends
+// -- through rounds rho+11 ... rho+1 -- on the reader of this round's row having been there already.
 //   Round 5, second session: the hand-scheduled cell (CellI32FP) in the packed-int16 kernels' column loop.  The compiler-
 // scheduled round before it handed the residues from lane to lane together with the row, so the profile read of a step
 // waited for the hand-off of the step before (~1 050 cycles per step); here every lane loads its own residues two columns
-// ahead, from a compact copy of the sequence (560 cycles per step: hi's 133 items 8.75 -> 4.67 ms).  `lane` is the logical lane.
+// ahead, from a compact copy of the sequence (560 cycles per step: hi's 133 items 8.75 -> 4.67 ms), and the lane groups' tables hold the
+// 24 residue codes the database can contain instead of 32, which makes room in LDS for twelve waves where there were eight (a 5 000-row
+// query: two rounds per wave instead of three; 4.07 ms).  `lane` is the logical lane.
 // ---------------------------------------------------------------------------
 template <int NW>
 static __device__ __forceinline__ int run_item_i32f_pipe(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma, uint32_t lg,
@@ -1436,7 +1452,7 @@ static __device__ __forceinline__ int run_item_i32f_pipe(const OswSearchArgs &p,
     for (uint32_t rho = (uint32_t)wv; rho < plan.rounds; rho += NW) {
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
         __builtin_amdgcn_wave_barrier();
-        fill_profile_slice<uint2, 32u>(prof_q, rb0, R / 4, G, rb_end, lds_wave, (uint32_t)lane, 64u);
+        fill_profile_slice_compact<uint2, 32u, (uint32_t)C::kCodes>(prof_q, rb0, G, rb_end, lds_wave, (uint32_t)lane, 64u); // (R == 4: one row-block per group)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_wave + g * (R * C::kRowBytes + (uint32_t)sizeof(uint2)));
@@ -1493,20 +1509,21 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
     }
 }
 
-// The re-run queue of a search (what reached the int16 cells' ceiling): few, long items -- a workgroup of EIGHT waves per
-// item, a pipeline over the item's rounds (run_item_i32f_pipe); two waves per SIMD hide each other's latencies.  The queue
-// length was produced by the kernels before it on this stream.  Wave w of workgroup b uses spill region 8 b + w: the grid
-// is at most an eighth of the regions (osw_launch_i32r).
-#define OSW_I32R_WAVES 8
+// The re-run queue of a search (what reached the int16 cells' ceiling): few, long items -- a workgroup of TWELVE waves per
+// item, a pipeline over the item's rounds (run_item_i32f_pipe); three waves per SIMD hide each other's latencies.  The queue
+// length was produced by the kernels before it on this stream.  Wave w of workgroup b uses spill region 12 b + w: the grid
+// is at most a twelfth of the regions (osw_launch_i32r).
+#define OSW_I32R_WAVES 12
+#define OSW_I32R_SLICE (64u * (OSW_SEQ_CODES + 1u)) // uint2 entries of a wave's profile slice: 64 lane groups x (24 codes + the skew entry)
 extern "C" __global__ __launch_bounds__(OSW_I32R_WAVES * 64) OSW_COMPILER_VGPRS void osw_sw_i32r(OswSearchArgs p)
 {
-    extern __shared__ uint2 lds_dyn[]; // OSW_I32R_WAVES profile slices of OSW_LDS_ROWS32 rows (139 KB: above the static limit)
+    extern __shared__ uint2 lds_dyn[]; // OSW_I32R_WAVES profile slices of OSW_I32R_SLICE entries (154 KB: above the static limit)
     __shared__ uint32_t prog[OSW_I32R_WAVES];
     __shared__ uint32_t wg_it;
     __shared__ int red[OSW_I32R_WAVES * 64];
     const int lane = osw_logical_lane(threadIdx.x & 63); // (the hand-scheduled cell's lane numbering; lane 0 is lane 0)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint2 *lds_wave = lds_dyn + (size_t)wv * (OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8);
+    uint2 *lds_wave = lds_dyn + (size_t)wv * OSW_I32R_SLICE;
     uint2 *bnd_wg = p.bnd + (size_t)blockIdx.x * OSW_I32R_WAVES * p.bnd_stride;
     const uint32_t nitems = p.counters_ovf[0];
     const uint2 *items = p.ovf_items;
@@ -2095,7 +2112,7 @@ hipError_t osw_launch_i32(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 // the re-run of the int32 queue: `regions` spill regions exist on the device (one per wave of a DP launch, two launches)
 hipError_t osw_launch_i32r(const OswSearchArgs &a, uint32_t regions, hipStream_t s)
 {
-    const size_t lds = (size_t)OSW_I32R_WAVES * (OSW_LDS_ROWS32 * 8 + OSW_LDS_SKEW8) * sizeof(uint2);
+    const size_t lds = (size_t)OSW_I32R_WAVES * OSW_I32R_SLICE * sizeof(uint2);
     // (per launch: the attribute belongs to the function ON THE CURRENT DEVICE; a context may drive several)
     const hipError_t attr = hipFuncSetAttribute((const void *)osw_sw_i32r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return attr;

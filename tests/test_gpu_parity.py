@@ -654,6 +654,51 @@ def test_context_level_topr_over_chunks_and_devices(oracle, dealt, two_devices):
     assert len(np.unique(whole[0, :NSEQ])) < NSEQ // 4   # ties are present
 
 
+@pytest.mark.parametrize("seq_len,qlen,ge", [(30000, 150, 2), (65520, 120, 1)])
+def test_very_long_sequences_on_the_int32_cells(hip_ctx, oracle, seq_len, qlen, ge):
+    """cell_bits = 32 on blocks far longer than the int16 frame cell's floor table (8 448 columns): the hand-scheduled int32 cell
+    has a floor table of its own for every column the formats allow (OSW_I32F_TABLE), read by the first round of every item;
+    the planner must still pick a geometry whose boundary row fits the spill region."""
+    q = synth.random_residues(15, 0, qlen)
+    long_seq = synth.random_residues(16, 0, seq_len)
+    hom = synth.mutate(q, 0.1, 3)[:qlen]
+    long_seq[seq_len // 2:seq_len // 2 + len(hom)] = hom
+    long_seq[8600:8600 + len(hom) - 20] = hom[20:]
+    other = synth.random_residues(17, 0, seq_len - 17)
+    other[seq_len - 17 - len(hom):] = hom                     # one that ends with the sequence
+    seqs = [synth.random_residues(300 + i, 0, 40 + i) for i in range(20)] + [long_seq, other]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    qs = [q, q[:77], synth.random_residues(18, 0, 700)]       # (700 rows: several rounds at any geometry)
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, ge, cell_bits=32)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, ge)
+    np.testing.assert_array_equal(got, want)
+    assert want.max() > 300
+
+
+def test_int32_rerun_of_a_copy_inside_a_very_long_sequence(hip_ctx, oracle):
+    """A re-run item whose sequence is far longer than the query: a near-copy of a 6 600-row query in the middle of a 22 600-column
+    sequence, and one at the very end of another.  Blocks that long run on the plain biased int16 cell (their frame offsets would
+    not fit the column-frame cell), whose ceiling is 30 576: the copies score beyond it.  The pipeline's waves then hand
+    22 000-column boundary rows to each other, the compact copy of the residues (behind the columns of the workgroup's first spill
+    region) is as long as it gets in practice, and the first round reads the int32 floor table far beyond the int16 one's 8 448
+    entries."""
+    q = synth.make_queries([6600], seed=311)[0]
+    rng = np.random.default_rng(313)
+    mid = np.concatenate([synth.random_residues(41, 0, 8000), synth.mutate(np.asarray(q, np.uint8), 0.01, 5), synth.random_residues(42, 0, 8000)])
+    end = np.concatenate([synth.random_residues(43, 0, 15000), synth.mutate(np.asarray(q, np.uint8), 0.02, 6)])
+    seqs = [synth.random_residues(9100 + i, 0, int(l)) for i, l in enumerate(rng.integers(30, 900, size=40))] + [mid, end]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    qs = [q, q[:333]]
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want.max() > 30576 and hip_ctx.rerun_counts()[1] >= 1   # (the two sequences are a lane pair: one item, both halves)
+
+
 @pytest.mark.parametrize("qlens", [[4300], [6100, 1500], [2990, 5000, 3700]])
 def test_int32_rerun_pipeline_over_many_long_items(hip_ctx, oracle, qlens):
     """The int32 re-run as a workgroup pipeline (osw_sw_i32, round 4): wave w of a workgroup runs rounds w, w+4, ... of ONE
