@@ -68,6 +68,31 @@ def test_host_kernel_int16_ceiling(tmp_path, oracle):
     assert sorted(got[0][got[0] > 0].tolist())[-4:] == [11 * 2977, 11 * 2978, 11 * 2979, 11 * 3100]
 
 
+@pytest.mark.parametrize("v", [16, 32])
+def test_host_kernel_int8_ceiling(tmp_path, oracle, monkeypatch, v):
+    """The 8-bit first stage of the host kernels (round 5; reference HybridSearch.c:1618-1680): self-scores of 126, 127 and 128
+    -- ten W (11 each) + C P / C H / C C -- sit on both sides of its ceiling; a lane at 127 sends its group to the int16 kernel,
+    everything below is kept.  Both vector lengths, an odd number of groups (the AVX2 stage takes them two at a time), against the
+    scalar oracle and against the same search started in int16 (OSWALD_HOST_NO_INT8, the kernel of rounds 1-4)."""
+    A = synth.ALPHABET
+    w, c, p_, h = A.index("W"), A.index("C"), A.index("P"), A.index("H")
+    qs = [np.array([w] * 10 + tail, np.uint8) for tail in ([c, p_], [c, h], [c, c])]
+    seqs = [q.copy() for q in qs] + [synth.random_residues(50 + i, 0, 12 + i % 7) for i in range(30)] + [synth.random_residues(99, 0, 300)]
+    synth.write_fasta(str(tmp_path / "db.fasta"), seqs)
+    synth.write_fasta(str(tmp_path / "q.fasta"), qs)
+    hostlib.preprocess(str(tmp_path / "db.fasta"), str(tmp_path / "db"), 1)
+    q = hostlib.load_queries(str(tmp_path / "q.fasta"))
+    r = hostlib.assemble(str(tmp_path / "db"), 16, 134217728, 1)
+    ch = r["chunks"][0]
+    assert ch["groups"] == 3
+    got = hostlib.host_search_chunk(0, 3, ch["groups"], "blosum62", 10, 2, vector_length=v)
+    want = oracle.search_chunk_scalar(q["a"], q["m"], q["disp"][:-1].astype(np.uint32), ch["b"], ch["n"], ch["disp"], 16, submat.load("blosum62"), 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert sorted(np.unique(got.max(axis=1)).tolist()) == [126, 127, 128]
+    monkeypatch.setenv("OSWALD_HOST_NO_INT8", "1")
+    np.testing.assert_array_equal(hostlib.host_search_chunk(0, 3, ch["groups"], "blosum62", 10, 2, vector_length=v), got)
+
+
 def test_cli_host_only_mode_report(tmp_path):
     """`oswald -O search -m 2`: BASELINE configs[0] end to end on the CPU -- the report's scores are the reference's
     (sw_host goldens), in the reference's order (descending score, ties by descending database index)."""

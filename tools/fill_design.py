@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""tools/fill_design.py ROUND -- put the round's measured figures into DESIGN.md: every @@NAME@@ placeholder is replaced by the
-figure of that name taken from profiles/r<ROUND>_* (the files tools/collect_final.py copied there).  Placeholders it has no
-figure for are left in place and listed; run it again after the missing part of the validation."""
+"""tools/fill_design.py ROUND [TEMPLATE] -- put the round's measured figures into DESIGN.md: every @@NAME@@ placeholder is replaced
+by the figure of that name taken from profiles/r<ROUND>_* (the files tools/collect_final.py copied there).  TEMPLATE: the text with
+the placeholders (default: DESIGN.md itself, i.e. a first fill; the template is a working file of the writing session, not tracked --
+a later validation run is filled in from the same template again).  Placeholders without a figure are left in place and listed."""
 import json, os, re, sys
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+template = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "DESIGN.md")
 P = os.path.join(root, "profiles")
 
 
@@ -44,6 +46,9 @@ for key, label, r4 in rows:
     inc_s = "—"
     if inc.get("value"):
         inc_s = f"{sp(inc['value'])}, {inc['ms_per_step']:.2f} ms, {100 * (inc.get('vs_resident') or 0):+.1f} %"
+    if key == "gloo4":  # (ranks that share the GPU: kernel times inflated by their contention, rank 0's inclusive pass is its shard's)
+        table.append(f"| {label}; kernel times inflated by the ranks' contention | **{sp(d['value'])}** ({r4}) | {d['ms_per_step']:.2f} | — | — | — | — |")
+        continue
     table.append(f"| {label} | **{sp(d['value'])}** ({r4}) | {d['ms_per_step']:.2f} | {rf.get('kernel_ms', 0):.2f} | {valu if valu is not None else '—'} | {inc_s} | {ref if ref is not None else '—'} |")
 if table:
     vals["TABLE5"] = "\n".join(table)
@@ -75,6 +80,11 @@ if d:
 d = bench("hi")
 if d:
     vals["HIINT32"] = f"{d['rerun_ms_per_step']['int32']:.2f}"
+t = text("pytest_gpu_tail.txt")
+if t:
+    m = re.search(r"(\d+) passed, (\d+) skipped", t)
+    if m:
+        vals["GPUTESTS"] = f"{m.group(1)} passed / {m.group(2)} skipped"
 # ---- CLI
 t = text("cli_q1_1m_phases.txt")
 if t:
@@ -82,7 +92,7 @@ if t:
     later = re.findall(r"timed region\), total\s+([\d.]+) ms\s+\(a later pass", t)
     speed = re.findall(r"Search speed:\s+([\d.]+) GCUPS", t)
     if first and speed:
-        vals.update(CLIQ1=first[0], CLIQ1G=sp(float(speed[0])))
+        vals.update(CLIQ1=f"{float(first[0]):.1f}", CLIQ1G=sp(float(speed[0])))
     if later:
         vals["CLIQ1W"] = f"{min(map(float, later)):.1f}–{max(map(float, later)):.1f}"
 t = text("cli_1m_phases.txt")
@@ -100,7 +110,7 @@ if t:
         vals.update(M0C4=sp(float(m0[0])), HYBC4=f"{sp(min(m1))}–{sp(max(m1))}")
 
 p = os.path.join(root, "DESIGN.md")
-s = open(p).read()
+s = open(template).read()
 left = set()
 for name in set(re.findall(r"@@([A-Z0-9]+)@@", s)):
     if name in vals:
