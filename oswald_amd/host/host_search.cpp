@@ -56,7 +56,8 @@ int32_t scalar_score(const uint8_t *a, uint32_t m, const uint8_t *grp, uint32_t 
 
 struct Scratch {
     std::vector<int16_t> H, E; // 16 lanes per query row
-    std::vector<int8_t> H8, E8; // 32 (AVX2) or 16 (SSE4.1) lanes per query row
+    std::vector<int8_t> H8, E8; // 32 (AVX2) or 16 (SSE4.1) lanes per query row of a block
+    std::vector<int8_t> Hb8, Fb8; // ... and per column: the row above a block (-b)
     std::vector<int32_t> h32, e32;
 };
 
@@ -64,11 +65,8 @@ struct Scratch {
 // absent: ncolsB = 0 -- reads dummy residues, which score 0 against everything and cannot raise a score).  out: the
 // lanes' best scores, 127 = reached the ceiling.
 __attribute__((target("avx2"))) void simd_pair8(const uint8_t *a, uint32_t m, const uint8_t *grpA, uint32_t ncolsA, const uint8_t *grpB, uint32_t ncolsB,
-                                               const int8_t *submat, int goe, int ge, Scratch &s, int8_t out[32])
+                                               const int8_t *submat, int goe, int ge, uint32_t bw, Scratch &s, int8_t out[32])
 {
-    s.H8.assign((size_t)m * 32, 0);
-    s.E8.assign((size_t)m * 32, 0);
-    __m256i *H = (__m256i *)s.H8.data(), *E = (__m256i *)s.E8.data(); // unaligned accesses below
     // (penalties beyond 127 act like 127 on values that never exceed 127: the result is <= 0 either way)
     const __m256i vgoe = _mm256_set1_epi8((char)std::min(goe, 127)), vge = _mm256_set1_epi8((char)std::min(ge, 127)), zero = _mm256_setzero_si256();
     __m256i best = zero;
@@ -81,24 +79,41 @@ __attribute__((target("avx2"))) void simd_pair8(const uint8_t *a, uint32_t m, co
     const __m256i fifteen = _mm256_set1_epi8(15), mask31 = _mm256_set1_epi8(31);
     const __m128i dummy = _mm_set1_epi8(23);
     const uint32_t ncols = std::max(ncolsA, ncolsB);
-    for (uint32_t j = 0; j < ncols; ++j) {
-        const __m128i ra = j < ncolsA ? _mm_loadu_si128((const __m128i *)(grpA + (size_t)j * 16)) : dummy;
-        const __m128i rb = j < ncolsB ? _mm_loadu_si128((const __m128i *)(grpB + (size_t)j * 16)) : dummy;
-        const __m256i r = _mm256_and_si256(_mm256_inserti128_si256(_mm256_castsi128_si256(ra), rb, 1), mask31);
-        const __m256i upper = _mm256_cmpgt_epi8(r, fifteen), r15 = _mm256_and_si256(r, fifteen);
-        for (int c = 0; c < 24; ++c) P[c] = _mm256_blendv_epi8(_mm256_shuffle_epi8(lo[c], r), _mm256_shuffle_epi8(hi[c], r15), upper);
-        __m256i diag = zero, f = zero;
-        for (uint32_t i = 0; i < m; ++i) {
-            const uint32_t ai = a[i] < 24 ? a[i] : 23;
-            __m256i h = _mm256_adds_epi8(diag, P[ai]);
-            const __m256i e = _mm256_loadu_si256(E + i);
-            h = _mm256_max_epi8(_mm256_max_epi8(h, e), _mm256_max_epi8(f, zero));
-            diag = _mm256_loadu_si256(H + i);
-            _mm256_storeu_si256(H + i, h);
-            best = _mm256_max_epi8(best, h);
-            const __m256i u = _mm256_subs_epi8(h, vgoe);
-            _mm256_storeu_si256(E + i, _mm256_max_epi8(_mm256_subs_epi8(e, vge), u));
-            f = _mm256_max_epi8(_mm256_subs_epi8(f, vge), u);
+    // -b: the query is worked through in blocks of bw rows, every block over all columns (H and E of a block's rows stay in
+    // the L1 cache); the row above a block -- H and F of the block before at its last row, one vector per column -- is carried
+    // in Hb / Fb (the reference blocks the DATABASE sequence and carries a column, HybridSearch.c:1589-1600: the same idea on
+    // the other axis, which is the one this column-streamed kernel keeps arrays along)
+    if (bw == 0 || bw > m) bw = m;
+    const bool blocked = bw < m;
+    s.H8.assign((size_t)bw * 32, 0);
+    s.E8.assign((size_t)bw * 32, 0);
+    if (blocked) { s.Hb8.assign((size_t)ncols * 32, 0); s.Fb8.assign((size_t)ncols * 32, 0); }
+    __m256i *H = (__m256i *)s.H8.data(), *E = (__m256i *)s.E8.data(), *Hb = (__m256i *)s.Hb8.data(), *Fb = (__m256i *)s.Fb8.data(); // unaligned accesses below
+    for (uint32_t i0 = 0; i0 < m; i0 += bw) {
+        const uint32_t rows = std::min(bw, m - i0);
+        if (i0) { std::memset(s.H8.data(), 0, (size_t)rows * 32); std::memset(s.E8.data(), 0, (size_t)rows * 32); }
+        __m256i above_prev = zero; // H(i0 - 1, j - 1)
+        for (uint32_t j = 0; j < ncols; ++j) {
+            const __m128i ra = j < ncolsA ? _mm_loadu_si128((const __m128i *)(grpA + (size_t)j * 16)) : dummy;
+            const __m128i rb = j < ncolsB ? _mm_loadu_si128((const __m128i *)(grpB + (size_t)j * 16)) : dummy;
+            const __m256i r = _mm256_and_si256(_mm256_inserti128_si256(_mm256_castsi128_si256(ra), rb, 1), mask31);
+            const __m256i upper = _mm256_cmpgt_epi8(r, fifteen), r15 = _mm256_and_si256(r, fifteen);
+            for (int c = 0; c < 24; ++c) P[c] = _mm256_blendv_epi8(_mm256_shuffle_epi8(lo[c], r), _mm256_shuffle_epi8(hi[c], r15), upper);
+            __m256i diag = above_prev, f = zero, h = zero;
+            if (blocked && i0) { above_prev = _mm256_loadu_si256(Hb + j); f = _mm256_loadu_si256(Fb + j); }
+            for (uint32_t i = 0; i < rows; ++i) {
+                const uint32_t ai = a[i0 + i] < 24 ? a[i0 + i] : 23;
+                h = _mm256_adds_epi8(diag, P[ai]);
+                const __m256i e = _mm256_loadu_si256(E + i);
+                h = _mm256_max_epi8(_mm256_max_epi8(h, e), _mm256_max_epi8(f, zero));
+                diag = _mm256_loadu_si256(H + i);
+                _mm256_storeu_si256(H + i, h);
+                best = _mm256_max_epi8(best, h);
+                const __m256i u = _mm256_subs_epi8(h, vgoe);
+                _mm256_storeu_si256(E + i, _mm256_max_epi8(_mm256_subs_epi8(e, vge), u));
+                f = _mm256_max_epi8(_mm256_subs_epi8(f, vge), u);
+            }
+            if (blocked) { _mm256_storeu_si256(Hb + j, h); _mm256_storeu_si256(Fb + j, f); }
         }
     }
     _mm256_storeu_si256((__m256i *)out, best);
@@ -106,11 +121,8 @@ __attribute__((target("avx2"))) void simd_pair8(const uint8_t *a, uint32_t m, co
 
 // 8-bit first stage, SSE4.1: one group per register
 __attribute__((target("sse4.1"))) void simd_group8_sse41(const uint8_t *a, uint32_t m, const uint8_t *grp, uint32_t ncols, const int8_t *submat, int goe, int ge,
-                                                        Scratch &s, int8_t out[16])
+                                                        uint32_t bw, Scratch &s, int8_t out[16])
 {
-    s.H8.assign((size_t)m * 16, 0);
-    s.E8.assign((size_t)m * 16, 0);
-    __m128i *H = (__m128i *)s.H8.data(), *E = (__m128i *)s.E8.data();
     const __m128i vgoe = _mm_set1_epi8((char)std::min(goe, 127)), vge = _mm_set1_epi8((char)std::min(ge, 127)), zero = _mm_setzero_si128();
     __m128i best = zero;
     __m128i lo[24], hi[24], P[24];
@@ -119,21 +131,34 @@ __attribute__((target("sse4.1"))) void simd_group8_sse41(const uint8_t *a, uint3
         hi[c] = _mm_loadu_si128((const __m128i *)(submat + c * 32 + 16));
     }
     const __m128i fifteen = _mm_set1_epi8(15);
-    for (uint32_t j = 0; j < ncols; ++j) {
-        const __m128i r = _mm_and_si128(_mm_loadu_si128((const __m128i *)(grp + (size_t)j * 16)), _mm_set1_epi8(31));
-        const __m128i upper = _mm_cmpgt_epi8(r, fifteen), r15 = _mm_and_si128(r, fifteen);
-        for (int c = 0; c < 24; ++c) P[c] = _mm_blendv_epi8(_mm_shuffle_epi8(lo[c], r), _mm_shuffle_epi8(hi[c], r15), upper);
-        __m128i diag = zero, f = zero;
-        for (uint32_t i = 0; i < m; ++i) {
-            const uint32_t ai = a[i] < 24 ? a[i] : 23;
-            const __m128i e = _mm_loadu_si128(E + i);
-            const __m128i h = _mm_max_epi8(_mm_max_epi8(_mm_adds_epi8(diag, P[ai]), e), _mm_max_epi8(f, zero));
-            diag = _mm_loadu_si128(H + i);
-            _mm_storeu_si128(H + i, h);
-            best = _mm_max_epi8(best, h);
-            const __m128i u = _mm_subs_epi8(h, vgoe);
-            _mm_storeu_si128(E + i, _mm_max_epi8(_mm_subs_epi8(e, vge), u));
-            f = _mm_max_epi8(_mm_subs_epi8(f, vge), u);
+    if (bw == 0 || bw > m) bw = m; // (row blocks: see simd_pair8)
+    const bool blocked = bw < m;
+    s.H8.assign((size_t)bw * 16, 0);
+    s.E8.assign((size_t)bw * 16, 0);
+    if (blocked) { s.Hb8.assign((size_t)ncols * 16, 0); s.Fb8.assign((size_t)ncols * 16, 0); }
+    __m128i *H = (__m128i *)s.H8.data(), *E = (__m128i *)s.E8.data(), *Hb = (__m128i *)s.Hb8.data(), *Fb = (__m128i *)s.Fb8.data();
+    for (uint32_t i0 = 0; i0 < m; i0 += bw) {
+        const uint32_t rows = std::min(bw, m - i0);
+        if (i0) { std::memset(s.H8.data(), 0, (size_t)rows * 16); std::memset(s.E8.data(), 0, (size_t)rows * 16); }
+        __m128i above_prev = zero;
+        for (uint32_t j = 0; j < ncols; ++j) {
+            const __m128i r = _mm_and_si128(_mm_loadu_si128((const __m128i *)(grp + (size_t)j * 16)), _mm_set1_epi8(31));
+            const __m128i upper = _mm_cmpgt_epi8(r, fifteen), r15 = _mm_and_si128(r, fifteen);
+            for (int c = 0; c < 24; ++c) P[c] = _mm_blendv_epi8(_mm_shuffle_epi8(lo[c], r), _mm_shuffle_epi8(hi[c], r15), upper);
+            __m128i diag = above_prev, f = zero, h = zero;
+            if (blocked && i0) { above_prev = _mm_loadu_si128(Hb + j); f = _mm_loadu_si128(Fb + j); }
+            for (uint32_t i = 0; i < rows; ++i) {
+                const uint32_t ai = a[i0 + i] < 24 ? a[i0 + i] : 23;
+                const __m128i e = _mm_loadu_si128(E + i);
+                h = _mm_max_epi8(_mm_max_epi8(_mm_adds_epi8(diag, P[ai]), e), _mm_max_epi8(f, zero));
+                diag = _mm_loadu_si128(H + i);
+                _mm_storeu_si128(H + i, h);
+                best = _mm_max_epi8(best, h);
+                const __m128i u = _mm_subs_epi8(h, vgoe);
+                _mm_storeu_si128(E + i, _mm_max_epi8(_mm_subs_epi8(e, vge), u));
+                f = _mm_max_epi8(_mm_subs_epi8(f, vge), u);
+            }
+            if (blocked) { _mm_storeu_si128(Hb + j, h); _mm_storeu_si128(Fb + j, f); }
         }
     }
     _mm_storeu_si128((__m128i *)out, best);
@@ -230,7 +255,7 @@ __attribute__((target("sse4.1"))) void simd_group_sse41(const uint8_t *a, uint32
 
 void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int W, const int8_t *submat, int open_gap, int extend_gap,
                         int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length, const std::atomic<bool> *cancel,
-                        std::atomic<uint64_t> *cells_done)
+                        std::atomic<uint64_t> *cells_done, int block_width)
 {
     if (W != kFpgaVectorLength) throw std::runtime_error("OSWALD: the host path works on groups of 16 sequences.");
     const int goe = open_gap + extend_gap, ge = extend_gap;
@@ -242,6 +267,7 @@ void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t 
     if (threads < 1) threads = 1;
     // the 8-bit stage takes the groups two at a time on AVX2 (neighbours in the sorted database: the same length but for a few columns)
     const uint64_t ngroups = g1 > g0 ? g1 - g0 : 0, step = avx2 ? 2 : 1, nunits = (ngroups + step - 1) / step;
+    const uint32_t bw = block_width > 0 ? (uint32_t)block_width : 0u; // -b: query rows per block of the 8-bit stage (0: the whole query)
     const bool int8_stage = (avx2 || sse41) && !std::getenv("OSWALD_HOST_NO_INT8"); // (test hook: start in int16, the kernel of rounds 1-4)
 #pragma omp parallel num_threads(threads)
     {
@@ -259,8 +285,8 @@ void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t 
                 const uint32_t m = q.m[qi];
                 int8_t lane8[32];
                 bool have8 = false;
-                if (int8_stage && avx2) { simd_pair8(a, m, c.b + c.disp[gA], c.n[gA], haveB ? c.b + c.disp[gB] : nullptr, haveB ? c.n[gB] : 0, submat, goe, ge, s, lane8); have8 = true; }
-                else if (int8_stage) { simd_group8_sse41(a, m, c.b + c.disp[gA], c.n[gA], submat, goe, ge, s, lane8); have8 = true; }
+                if (int8_stage && avx2) { simd_pair8(a, m, c.b + c.disp[gA], c.n[gA], haveB ? c.b + c.disp[gB] : nullptr, haveB ? c.n[gB] : 0, submat, goe, ge, bw, s, lane8); have8 = true; }
+                else if (int8_stage) { simd_group8_sse41(a, m, c.b + c.disp[gA], c.n[gA], submat, goe, ge, bw, s, lane8); have8 = true; }
                 for (int part = 0; part < (haveB ? 2 : 1); ++part) {
                     const uint64_t g = part ? gB : gA;
                     const uint8_t *grp = c.b + c.disp[g];

@@ -626,6 +626,19 @@ int oswald_host_search_chunk_v(unsigned c, const char *submat_name, int open_gap
     } catch (const std::exception &e) { g_host_err = e.what(); return -1; }
 }
 
+// ... with the command line's -b (query rows per block of the 8-bit stage; 0: unblocked)
+int oswald_host_search_chunk_vb(unsigned c, const char *submat_name, int open_gap, int extend_gap, int threads, int cpu_vector_length, int block_width, int32_t *scores)
+{
+    try {
+        const int8_t *sm = oswald::submat_by_name(submat_name);
+        if (!sm) throw std::runtime_error("unknown substitution matrix");
+        const oswald::Chunk &ch = g_db.chunks.at(c);
+        oswald::host_search_groups(g_q, ch, 0, ch.n.size(), oswald::kFpgaVectorLength, sm, open_gap, extend_gap, threads, scores,
+                                   ch.n.size() * oswald::kFpgaVectorLength, 0, cpu_vector_length, nullptr, nullptr, block_width);
+        return 0;
+    } catch (const std::exception &e) { g_host_err = e.what(); return -1; }
+}
+
 int oswald_host_search_chunk(unsigned c, const char *submat_name, int open_gap, int extend_gap, int threads, int32_t *scores)
 {
     try {

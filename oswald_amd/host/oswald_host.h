@@ -114,7 +114,8 @@ std::vector<std::pair<const void *, size_t>> residue_ranges(const Database &db);
 // cpu_vector_length: the command line's -v -- 16 selects the SSE4.1 kernel (the reference's default host path), 32 the AVX2 one.
 void host_search_groups(const Queries &q, const Chunk &c, uint64_t g0, uint64_t g1, int vector_length, const int8_t *submat, int open_gap,
                         int extend_gap, int threads, int32_t *scores, uint64_t row_stride, uint64_t col0, int cpu_vector_length = 32,
-                        const std::atomic<bool> *cancel = nullptr, std::atomic<uint64_t> *cells_done = nullptr);
+                        const std::atomic<bool> *cancel = nullptr, std::atomic<uint64_t> *cells_done = nullptr, int block_width = 256);
+// block_width: the command line's -b -- the 8-bit stage works through a query in blocks of that many rows (0: unblocked).
 // cancel: when it becomes true the groups not yet started are skipped and a group in progress is left at its next query
 // (scores not computed stay untouched); cells_done accumulates query length x n[g] x 16 of every (group, query) finished
 // (what the hybrid mode's calibration measures the host's speed on).

@@ -307,7 +307,7 @@ int do_search_host_only(Options &o)
     const double tick = dwalltime();
     for (const oswald::Chunk &c : db.chunks)
         oswald::host_search_groups(q, c, 0, c.n.size(), (int)W, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, threads, scores.data(),
-                                   db.vect_sequences_count * W, c.accum * W, o.cpu_vector_length);
+                                   db.vect_sequences_count * W, c.accum * W, o.cpu_vector_length, nullptr, nullptr, o.cpu_block_size);
     const double work_time = dwalltime() - tick;
     std::vector<std::vector<int32_t>> top_s;
     std::vector<std::vector<uint64_t>> top_i;
@@ -400,7 +400,7 @@ int do_search_hybrid_static(Options &o)
         for (const oswald::Chunk &c : db.chunks) {
             const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
             if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, static_team, dst, dst_row, (a0 - dst_g0) * W, o.cpu_vector_length,
-                                                    cancel, done);
+                                                    cancel, done, o.cpu_block_size);
         }
     };
     // Test portion.  The host searches the first -p of the groups, as in the reference.  The accelerator's speed
@@ -568,7 +568,7 @@ int do_search_hybrid(Options &o)
         for (const oswald::Chunk &c : db.chunks) {
             const uint64_t a0 = std::max(g0, c.accum), a1 = std::min<uint64_t>(g1, c.accum + c.n.size());
             if (a0 < a1) oswald::host_search_groups(q, c, a0 - c.accum, a1 - c.accum, (int)W, sm, o.open_gap, o.extend_gap, host_threads, dst, dst_row, (a0 - dst_g0) * W, o.cpu_vector_length,
-                                                    cancel, done);
+                                                    cancel, done, o.cpu_block_size);
         }
     };
     // Test portion: the host on the first -p of the groups, called off when the accelerator's rating is over (as in
@@ -1060,7 +1060,7 @@ int main(int argc, char *argv[])
         {"execution_mode", 'm', "<integer>", 0, "0 for accelerator mode, 1 for hybrid mode (host + accelerator), 2 or host-only for host mode (default: 1).", 3},
         {"cpu_threads", 'c', "<integer>", 0, "Number of CPU threads (default: 4).", 3},
         {"vector_length", 'v', "<integer>", 0, "Vector length in host: 16 (SSE4.1 kernel) or 32 (AVX2 kernel) (default: 16).", 3},
-        {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (default: 256).  Accepted and printed for compatibility with the reference's command line and report; it has NO effect in this build: the host kernel here streams the database column by column and blocks nothing.", 3},
+        {"cpu_block_width", 'b', "<integer>", 0, "CPU block width (default: 256): the 8-bit stage of the host kernel works through a query in blocks of that many rows (0: the whole query at once).  The reference blocks the database sequence by it; this kernel streams the database column by column and blocks the other axis.  Scores do not depend on it.", 3},
         {"num_fpgas", 'f', "<integer>", 0, "Number of GPUs (the reference's number of FPGAs) (default: 1).", 3},
         {"max_chunk_size", 'k', "<integer>", 0, "Maximum chunk size on the accelerator (bytes, default: 134217728).", 3},
         {"db_percentage", 'p', "<integer>", 0, "Database percentage for testing computational power (hybrid mode only) (default: 0.01).  An upper bound in this build: the host's test is called off once the GPU's is over, and the host is rated on what it finished; the ratings then only size the pieces -- host and GPU take work from the two ends of the database until they meet.", 3},

@@ -73,11 +73,12 @@ def assemble(dbname, W=16, max_chunk=134217728, ndev=1):
     return r
 
 
-def host_search_chunk(chunk, nq, groups, matrix, go, ge, threads=4, vector_length=32):
+def host_search_chunk(chunk, nq, groups, matrix, go, ge, threads=4, vector_length=32, block_width=256):
     """oswald::host_search_groups (the `-m 2` / hybrid host kernel) on a chunk of the database assembled last, for
-    the queries loaded last: int32 [nq][groups*16].  vector_length: the command line's -v (16: SSE4.1 kernel, 32: AVX2)."""
+    the queries loaded last: int32 [nq][groups*16].  vector_length: the command line's -v (16: SSE4.1 kernel, 32: AVX2);
+    block_width: its -b (query rows per block of the 8-bit stage; 0: unblocked)."""
     out = np.zeros((nq, groups * 16), np.int32)
-    if load().oswald_host_search_chunk_v(chunk, matrix.encode(), go, ge, threads, vector_length, out.ctypes.data_as(C.c_void_p)):
+    if load().oswald_host_search_chunk_vb(chunk, matrix.encode(), go, ge, threads, vector_length, block_width, out.ctypes.data_as(C.c_void_p)):
         raise RuntimeError(load().oswald_host_last_error().decode())
     return out
 

@@ -53,6 +53,21 @@ def test_host_kernel_equals_oracle(tmp_path, oracle, matrix, go, ge):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("b", [0, 7, 64, 256])
+def test_host_kernel_block_width(tmp_path, oracle, b):
+    """`-b` (round 5): the 8-bit stage works through the query in blocks of b rows, the row above a block carried per column;
+    homologs whose alignments cross the block boundaries, both kernels, every score against the scalar oracle."""
+    qs = synth.make_queries([300, 77], seed=21)
+    L, R, O = _write_db(tmp_path, qs, 200, seed=23, homologs_per_query=6)
+    q = hostlib.load_queries(str(tmp_path / "q.fasta"))
+    r = hostlib.assemble(str(tmp_path / "db"), 16, 134217728, 1)
+    ch = r["chunks"][0]
+    want = oracle.search_chunk_scalar(q["a"], q["m"], q["disp"][:-1].astype(np.uint32), ch["b"], ch["n"], ch["disp"], 16, submat.load("blosum62"), 10, 2)
+    for v in (16, 32):
+        np.testing.assert_array_equal(hostlib.host_search_chunk(0, 2, ch["groups"], "blosum62", 10, 2, vector_length=v, block_width=b), want)
+    assert want.max() > 127   # (some groups went on to the int16 kernel)
+
+
 def test_host_kernel_int16_ceiling(tmp_path, oracle):
     """Scores at and beyond 32767 (all-W sequences: 11 per cell): the int16 lanes saturate and are redone in int32."""
     w = synth.ALPHABET.index("W")
@@ -89,6 +104,8 @@ def test_host_kernel_int8_ceiling(tmp_path, oracle, monkeypatch, v):
     want = oracle.search_chunk_scalar(q["a"], q["m"], q["disp"][:-1].astype(np.uint32), ch["b"], ch["n"], ch["disp"], 16, submat.load("blosum62"), 10, 2)
     np.testing.assert_array_equal(got, want)
     assert sorted(np.unique(got.max(axis=1)).tolist()) == [126, 127, 128]
+    for b in (0, 1, 5, 12, 13):   # -b: rows per block of the 8-bit stage (a 12-row query: every way to cut it)
+        np.testing.assert_array_equal(hostlib.host_search_chunk(0, 3, ch["groups"], "blosum62", 10, 2, vector_length=v, block_width=b), got)
     monkeypatch.setenv("OSWALD_HOST_NO_INT8", "1")
     np.testing.assert_array_equal(hostlib.host_search_chunk(0, 3, ch["groups"], "blosum62", 10, 2, vector_length=v), got)
 
