@@ -69,6 +69,8 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     bool no_direct_table = false;      // OSWALD_HIP_NO_DIRECT_TABLE=1 (A/B and test hook): score tables leave by DMA on the download stream even when the kernels could write them
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
+    int pair_tails = 16;               // OSWALD_HIP_PAIR_TAILS=n: query sets of up to n pairs may run the rows a pair's longer query has beyond the shorter one's as tail items (0: always pad the shorter query, rounds 1-5)
+    double tail_items_per_wave = 6.0;  // OSWALD_HIP_TAIL_ITEMS=x: ... on chunks that give every wave of the grid at least x tail items (smaller chunks: the extra launch costs more than the padding)
     double warm_ms = 0.0;              // OSWALD_HIP_WARM_MS=ms: oswald_hip_reserve_chunks ends with every CU of the device busy for that long (experiment: clock ramp before a first search)
     size_t split_bytes = 32u << 20;    // OSWALD_HIP_SPLIT_BYTES=bytes: from this size on an asynchronous upload that finds its device idle is cut into head + rest (0: never; a small value: test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
@@ -100,6 +102,8 @@ void Tunables::refresh()
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     split_bytes = (size_t)num("OSWALD_HIP_SPLIT_BYTES", (double)(32u << 20));
     warm_ms = num("OSWALD_HIP_WARM_MS", 0.0);
+    pair_tails = (int)num("OSWALD_HIP_PAIR_TAILS", 16);
+    tail_items_per_wave = num("OSWALD_HIP_TAIL_ITEMS", 6.0);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
 #ifdef OSW_DIAG
     pair_margin = num("OSWALD_HIP_PAIR_MARGIN", pair_margin);
@@ -227,6 +231,7 @@ struct Chunk {
     uint2 *items_pin[2] = {nullptr, nullptr};
     size_t items_pin_cap[2] = {0, 0};   // entries (both queues, one behind the other)
     size_t items_q_off[2] = {0, 0};     // where the query-pair kernel's queue starts in the set
+    size_t items_t_off[2] = {0, 0};     // ... and the tail items' (single-query kernel, a launch of its own behind the pairs')
     int items_cur = 0;
     // ... and who read a set last: recorded on the search stream behind the launches that pull from it.  A plan that is about to
     // overwrite a set waits for its last reader on the host (with one plan per residency that reader is long gone, but
@@ -237,6 +242,7 @@ struct Chunk {
     bool set_read_pending[2] = {false, false};
     const uint2 *items_ptr() const { return items_pin[items_cur]; }
     const uint2 *items_q_ptr() const { return items_pin[items_cur] + items_q_off[items_cur]; }
+    const uint2 *items_t_ptr() const { return items_pin[items_cur] + items_t_off[items_cur]; }
     const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     // host copy of the live extents (see osw_retile16 / osw_block_extent), for the planner: PAGE-LOCKED, so that the copy
@@ -262,6 +268,8 @@ struct Chunk {
     bool down_pending = false;          // ... which the next search that writes the slot's table must wait for
     uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
     uint32_t nitems_q = 0, nitems_q_wg = 0; // the same for the query-pair kernel's queue
+    uint32_t nitems_t = 0;                  // tail items (wave items)
+    uint64_t tiled_cols = 0;                // columns of `tiled` (a hand-over plane has 64 entries per column)
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
     int items_bits = 0;                 // cell width it was planned for
     uint32_t max_lg = 0;                // widest geometry in the item list
@@ -313,7 +321,7 @@ struct Device {
     uint32_t grid = 0;               // persistent workgroups per launch
     uint32_t grid_q8 = 0;            // ... of the 8-bit kernel (more workgroups per CU; at most 2 x grid: it runs alone and may use both halves of the spill scratch)
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_seq, prof_seq_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters;
-    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8, floor_i32;
+    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8, floor_i32, pair_tail, pair_rows, tail_pair, tail_query, hand;
     Arena qset;                           // what the buffers of the current query set (queries ... top_pages, prof_pair8) are slices of
     uint8_t *qstage = nullptr;            // page-locked: the small inputs of the query set as the arena holds them, read in place by the copy kernel
     size_t qstage_cap = 0;
@@ -359,6 +367,14 @@ struct oswald_hip_ctx {
     std::vector<uint32_t> pair_q, pair_off, singles;
     std::vector<uint16_t> pair_len;
     uint32_t pair_rowblocks = 0, pair_max_rowblocks = 0;
+    // Tails (sw_kernels.h, OswSearchArgs::hand): pair i keeps the SHORTER query's rows; the rest of its longer query is entity
+    // nq + k of the single-query arrays (m_ext / prof_off_ext: the real queries first, then the tails)
+    struct Tail { uint32_t query, pair, row0, rows; }; // (row0 / rows at geometry 1; entity nq + 7 t + lg: the tail behind pair items of geometry 2^lg)
+    std::vector<Tail> tails;
+    std::vector<uint8_t> pair_tail;                 // [pair] has a tail
+    std::vector<uint16_t> pair_rows;                // [pair] rows of a SHORT pair item (the shorter query's, rounded up to 4; = pair_len without a tail)
+    std::vector<uint16_t> m_ext, tail_pair, tail_query; // [nq + tails]
+    std::vector<uint32_t> prof_off_ext;
     uint64_t queries_version = 0;
     bool profiling = false;
     uint32_t topr_r = 0;             // oswald_hip_topr_begin: every search also selects the chunk's top r (0: off)
@@ -422,25 +438,29 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     // six little hipMemcpyAsync from the context's std::vectors holding the caller for 8.6 ms of a 25-ms search (the runtime
     // stages a pageable copy on the caller's thread, and the copy engine was busy with the chunk coming in).
     const bool alt_ = first_pass_is_frame(ctx), q8_ = first_pass_is_q8(ctx);
-    const uint32_t np_ = (uint32_t)ctx->pair_len.size();
+    const uint32_t np_ = (uint32_t)ctx->pair_len.size(), ne_ = (uint32_t)ctx->m_ext.size(); // (entities of the single-query arrays: the queries, then the tails)
     const size_t prof8 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096, prof16 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096;
     const size_t pair16 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096, pair8 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint2) + 4096;
     const size_t pages_bytes = (size_t)(128 + OSW_I16S_TABLE + 64) * 2 * sizeof(uint32_t);
     struct Slice { DevBuf *buf; size_t bytes; const void *src; size_t src_bytes; };
     const Slice slices[] = {// inputs (src: what the staging buffer holds at the slice's offset; top_pages is generated in place below)
                             {&d.queries, ctx->a.size() + 16, ctx->a.data(), ctx->a.size()},
-                            {&d.qlen, nq * sizeof(uint16_t) + 16, ctx->m.data(), nq * sizeof(uint16_t)},
+                            {&d.qlen, ne_ * sizeof(uint16_t) + 16, ctx->m_ext.data(), ne_ * sizeof(uint16_t)},
                             {&d.a_disp, (nq + 1) * sizeof(uint32_t), ctx->a_disp.data(), nq * sizeof(uint32_t)},
-                            {&d.prof_off, (nq + 1) * sizeof(uint32_t), ctx->prof_off.data(), nq * sizeof(uint32_t)},
+                            {&d.prof_off, (ne_ + 1) * sizeof(uint32_t), ctx->prof_off_ext.data(), ne_ * sizeof(uint32_t)},
                             {&d.submat, 24 * 32, ctx->submat, 24 * 32},
                             {&d.pair_q, np_ ? 2 * np_ * sizeof(uint32_t) : 0, ctx->pair_q.data(), 2 * np_ * sizeof(uint32_t)},
                             {&d.pair_off, np_ ? np_ * sizeof(uint32_t) : 0, ctx->pair_off.data(), np_ * sizeof(uint32_t)},
                             {&d.pair_len, np_ ? np_ * sizeof(uint16_t) + 16 : 0, ctx->pair_len.data(), np_ * sizeof(uint16_t)},
+                            {&d.pair_tail, np_ ? np_ + 16 : 0, ctx->pair_tail.data(), np_},
+                            {&d.pair_rows, np_ ? np_ * sizeof(uint16_t) + 16 : 0, ctx->pair_rows.data(), np_ * sizeof(uint16_t)},
+                            {&d.tail_pair, ne_ * sizeof(uint16_t) + 16, ctx->tail_pair.data(), ne_ * sizeof(uint16_t)},
+                            {&d.tail_query, ne_ * sizeof(uint16_t) + 16, ctx->tail_query.data(), ne_ * sizeof(uint16_t)},
                             {&d.top_pages, pages_bytes, nullptr, 0},
                             // built on the device
                             {&d.prof, prof8, nullptr, 0}, {&d.prof_seq, prof16, nullptr, 0}, {&d.prof_alt, prof8, nullptr, 0}, {&d.prof_seq_alt, alt_ ? prof16 : 0, nullptr, 0}, {&d.floor_i32, (size_t)OSW_I32F_TABLE * sizeof(uint2), nullptr, 0},
                             {&d.prof_pair, np_ ? pair16 : 0, nullptr, 0}, {&d.prof_pair8, np_ && q8_ ? pair8 : 0, nullptr, 0}, {&d.prof_pair_i16, np_ && alt_ ? pair16 : 0, nullptr, 0}};
-    constexpr size_t kInputs = 9;
+    constexpr size_t kInputs = 13;
     size_t total = 0, inputs_bytes = 0;
     for (size_t i = 0; i < sizeof slices / sizeof slices[0]; ++i) { total += Arena::up(slices[i].bytes); if (i + 1 == kInputs) inputs_bytes = total; }
     if (total > d.qset.slab.cap) {
@@ -826,7 +846,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; } }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_seq, &d.prof_seq_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
-                          &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8, &d.floor_i32,
+                          &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8, &d.floor_i32, &d.pair_tail, &d.pair_rows, &d.tail_pair, &d.tail_query, &d.hand,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
             b->release();
         d.qset.slab.release();
@@ -1276,7 +1296,11 @@ int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_
     uint64_t usable = (uint64_t)(0.8 * (double)free_b);
     if (stride > d.bnd_stride || !d.bnd.p) usable = usable > scratch ? usable - scratch : 0;
     // (four chunks' worth: slots are kept, and after a first chunk cut in two -- head and rest fit no full chunk -- three more are opened)
-    const double per_byte = 4.1 * (1.0 + 1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
+    // ... and ONE set of hand-over planes per device for the tails of a small query set's pairs (OswSearchArgs::hand): two planes per pair,
+    // 64 entries of 8 B per re-tiled column = 4 x the re-tiled residues and their dummy columns each
+    const uint32_t np = nq / 2;
+    const double hand_per_byte = ctx->tun.pair_tails > 0 && np >= 1 && np <= (uint32_t)ctx->tun.pair_tails ? 2.0 * np * 4.0 * (1.25 + 2.6) : 0.0;
+    const double per_byte = 4.1 * (1.0 + 1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0) + hand_per_byte;
     const uint64_t fit = (uint64_t)((double)usable / per_byte);
     *bytes = std::min<uint64_t>(fit, 0xfff00000ull); // (column offsets inside a chunk are 32-bit)
     return 0;
@@ -1332,6 +1356,22 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
     a.prof_i32 = (const uint2 *)d.prof_alt.p; // S + ge: the int32 cell (re-run and cell_bits = 32)
     a.floor_i32 = (const uint2 *)d.floor_i32.p;
+    if (c.nitems_t > 0) {
+        // tails: two hand-over planes per pair, 64 entries of 8 B per column of the re-tiled chunk; one set per device (the searches
+        // of a device run one after the other on its stream)
+        const uint64_t plane = c.total_col4 * 256ull, entries = plane * 2ull * ctx->pair_len.size();
+        if (entries >= (1ull << 32)) return fail(OSWALD_HIP_EINVAL, "the hand-over planes of %zu query pairs on a chunk of %llu columns would take %llu GB; search in smaller chunks or set OSWALD_HIP_PAIR_TAILS=0",
+                                                 ctx->pair_len.size(), (unsigned long long)(c.total_col4 * 4), (unsigned long long)(entries >> 27));
+        HIP_TRY(d.hand.reserve(entries * sizeof(uint2) + 4096));
+        a.hand = (uint2 *)d.hand.p;
+        a.hand_plane = (uint32_t)plane;
+    }
+    if (!ctx->tails.empty()) { // (also for a chunk without tail items: a pair with a tail holds the shorter query's rows only)
+        a.pair_tail = (const uint8_t *)d.pair_tail.p;
+        a.pair_rows = (const uint16_t *)d.pair_rows.p;
+        a.tail_pair = (const uint16_t *)d.tail_pair.p;
+        a.tail_query = (const uint16_t *)d.tail_query.p;
+    }
     a.debug_nospill = ctx->tun.debug_nospill ? 1u : 0u; // -DOSW_DIAG builds only (timing experiment: results are wrong); always 0 otherwise
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;
@@ -1453,6 +1493,15 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
         }
     } else if (ctx->cell_bits != 32 && c.nitems + c.nitems_wg > 0) {
         HIP_TRY(launch_single(as, grid, d.stream));
+    }
+    if (c.nitems_t > 0 && !first_pass_is_q8(ctx) && ctx->cell_bits != 32) {
+        // the tails of the pairs' longer queries: single-query wave items that start from what the pair launch handed over
+        OswSearchArgs at = as;
+        at.items = c.items_t_ptr();
+        at.nitems = c.nitems_t;
+        at.nitems_wg = 0;
+        at.counters = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
+        HIP_TRY(launch_single(at, std::min<uint32_t>(grid_cap, (c.nitems_t + 3) / 4), d.stream));
     }
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.d, d.stream));
     // cell_bits 32: the whole plan on the int32 kernel; else: the re-run of what reached the int16 cells' ceiling (queue on the device)
@@ -2011,7 +2060,7 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
         out8[1] += alloc;
         out8[2] += live;
         out8[3] += live * 64 * sizeof(uint2);
-        out8[4] += c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg; // wave-level work items (a phase-1 entry is four)
+        out8[4] += c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg + c.nitems_t; // wave-level work items (a phase-1 entry is four)
         out8[5] = std::max<uint64_t>(out8[5], c.max_lg);
         out8[6] += c.planned_spill_bytes;
     }

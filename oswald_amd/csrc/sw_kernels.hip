@@ -789,7 +789,7 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
                                                      const uint2 *top_pages, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
                                                      typename C::GapT goe, typename C::GapT ge, typename C::T &score,
                                                      const uint2 *src_region = nullptr, lds_flagp prog_src = nullptr,
-                                                     lds_flagp prog_mine = nullptr, uint32_t rho = 0)
+                                                     lds_flagp prog_mine = nullptr, uint32_t rho = 0, uint2 *hand_store = nullptr)
 {
     typedef typename C::T T;
     // (`lane` is the LOGICAL lane, see osw_logical_lane: the masks are over physical lanes)
@@ -820,21 +820,26 @@ static __device__ __forceinline__ void sw_round_fast(const uint16_t *tcol, uint3
     // a last round stores into the trash page; so do the G-1 warm-up steps in which the last group is
     // still before column 0 (the store pointer starts G-1 columns before the data: inside the trash page)
     const uint64_t data = (uint64_t)(bnd + OSW_SCRATCH_DATA);
-    const uint32_t sstep = last ? 0u : gl * 8u;
+    // (hand_store: a LAST round whose bottom row is wanted all the same -- a pair's longer query goes on as a tail item -- stores it
+    // there, column 0 at hand_store, instead of into the trash page)
+    const uint64_t hs = osw_uniform64((uint64_t)hand_store);
+    const bool keep = last && hs != 0;
+    const uint32_t sstep = last && !keep ? 0u : gl * 8u;
     // A first round reads the row above it -- "zero" in the cell's representation -- from constant memory: one
     // entry for every column (zero stride), or, for the column-frame cell, the table of per-column floors
     // (entry k = 1024 + k * ge; column 0 is entry G), 8 B per column, the same entry for every lane.
     const uint32_t lstep = !first ? gl * 8u : C::kShifted ? 8u : 0u;
     const uint32_t voffl = first && C::kShifted ? 0u : voff;
-    uint64_t lptr = !first ? (PIPE ? (uint64_t)(src_region + OSW_SCRATCH_DATA) : data)
-                  : C::kShifted ? (uint64_t)(top_pages + C::kTopTable + G) : (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0));
+    // (wave-uniform by construction; said so explicitly: the asm statements take them in scalar registers)
+    uint64_t lptr = osw_uniform64(!first ? (PIPE ? (uint64_t)(src_region + OSW_SCRATCH_DATA) : data)
+                                         : C::kShifted ? (uint64_t)(top_pages + C::kTopTable + G) : (uint64_t)(top_pages + (C::kFloorBits ? 64 : 0)));
     [[maybe_unused]] auto wait_for = [&](uint32_t cols) { // columns 0 .. cols-1 of round rho - 1 (published under the tag rho) are stored and visible
         const uint32_t need = (rho << 20) | (cols < ncols ? cols : ncols);
         while (*prog_src < need) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     if constexpr (PIPE) { if (!first) wait_for(2); }
-    uint64_t sptr = last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u;
+    uint64_t sptr = osw_uniform64(keep ? hs - (uint64_t)(G - 1u) * gl * 8u : last ? (uint64_t)(bnd + OSW_SCRATCH_TRASH) : data - (uint64_t)(G - 1u) * gl * 8u);
     uint64_t tptr = (uint64_t)tcol - (uint64_t)(G - 1u) * CS;
     uint64_t sv;
     // nothing has been handed over yet: zeros; columns 0 and 1 of the stream
@@ -1036,13 +1041,13 @@ static __device__ __forceinline__ void sw_round_q8f(const uint16_t *tcol, uint32
 template <class C>
 static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint16_t *tcol, uint32_t u, uint32_t ncols, uint32_t base, uint2 *bnd,
                                                          const uint2 *top_pages, bool first, bool last, uint32_t G, uint32_t gl, int lane, int half,
-                                                         typename C::GapT goe, typename C::GapT ge, typename C::T &score)
+                                                         typename C::GapT goe, typename C::GapT ge, typename C::T &score, uint2 *hand_store = nullptr)
 {
 #define OSW_ROUND_CASE(RR)                                                                                                      \
     case RR:                                                                                                                    \
         if constexpr (RR > C::kRows) break; /* taller than the cell's strips: never planned, not compiled */                    \
         else if constexpr (std::is_same<C, CellQ8F>::value) sw_round_q8f<RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, goe, score); \
-        else sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);          \
+        else sw_round_fast<C, RR>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score, nullptr, nullptr, nullptr, 0u, hand_store); \
         break
     switch (R) {
         OSW_ROUND_CASE(4);
@@ -1051,7 +1056,7 @@ static __device__ __forceinline__ void sw_round_dispatch(uint32_t R, const uint1
     default:
         if constexpr (C::kRows >= 16) {
             if (R == 16) {
-                sw_round_fast<C, 16>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score);
+                sw_round_fast<C, 16>(tcol, u, ncols, base, bnd, top_pages, first, last, G, gl, lane, half, goe, ge, score, nullptr, nullptr, nullptr, 0u, hand_store);
                 break;
             }
         }
@@ -1137,10 +1142,28 @@ static __device__ __forceinline__ const uint2 *osw_top_pages(const OswSearchArgs
 //               is a pair of workgroup barriers around the slice reload.
 // (wg is a run-time, workgroup-uniform flag: both kinds run the same round code.)
 // HWL: `lane` is a logical lane number (osw_logical_lane; the packed-int16 kernels), else the physical one
-template <class C, bool HWL = false>
+// A pair's longer query goes on as a tail item (OswSearchArgs::hand).  store: where the LAST round of this item leaves its bottom row
+// (null: nowhere).  A tail item's row above is the HIGH halves (the pair's second = longer query) of the entries the two passes of the
+// pair items left there, written at geometry 2^lgp (the tail runs at geometry 1: the frames differ by (2^lgp - 1) * ge).
+struct OswHand {
+    bool store;        // HMODE 1: the last round's bottom row goes to the pair's plane of this pass (computed where it is used: no live pointer)
+    uint32_t pair1;    // HMODE 2: the pair whose tail this item is, + 1 (0: an ordinary item)
+    uint32_t lgp;      // ... and the geometry of the pair items that wrote
+    bool framed;       // ... in the column-frame representation (else: plain biased values, no conversion)
+};
+// where sub-block sigma of block blk starts in a hand-over plane, for items of geometry 2^lg
+// (entry indices are 32-bit: the library gives the planes at most 2^32 entries in all, 32 GB)
+static __device__ __forceinline__ uint32_t osw_hand_sub(const OswBlock &blk, uint32_t sigma, uint32_t lg)
+{
+    return blk.col4_off * 256u + sigma * (blk.ncols4 * 4u + 64u) * (64u >> lg);
+}
+
+// HMODE: 0 = no hand-over code at all, 1 = the item may leave its last bottom row in hand.store (pair kernels), 2 = the item may be a
+// tail (single-query kernels); the other fields of `hand` are then ignored / null
+template <class C, bool HWL = false, int HMODE = 0>
 static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, const uint2 *prof, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
                                                          uint32_t lg, int lane, int half, bool wg, uint2 *lds_region, uint2 *bnd_wave,
-                                                         typename C::GapT goe, typename C::GapT ge)
+                                                         typename C::GapT goe, typename C::GapT ge, OswHand hand = OswHand{false, 0u, 0u, false})
 {
     typedef typename C::T T;
     const uint32_t kLds = wg ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
@@ -1150,10 +1173,54 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     const uint32_t ncols = __builtin_amdgcn_readfirstlane((uint32_t)p.sub_cols[(size_t)B * 128 + (G - 1u) + sigma]);
     const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
     uint2 *bnd = (uint2 *)osw_uniform64((uint64_t)bnd_wave);
-    const OswPlan plan = osw_plan(p.qlen[q], G, kLds, C::kRows);
+    uint32_t mlen = p.qlen[q];
+    if constexpr (HMODE == 1) { if (hand.store) mlen = p.pair_rows[q]; } // (a SHORT pair item: the shorter query's rows, the rest is a tail item's)
+    const OswPlan plan = osw_plan(mlen, G, kLds, C::kRows);
     typedef typename C::Entry Entry; // the profile scores of one residue code for 4 rows
     const Entry *prof_q = (const Entry *)prof + (size_t)p.prof_off[q] * (uint32_t)C::kCodes;
-    if (plan.rounds > 1) {
+    bool tail = false;
+    if constexpr (HMODE == 2) tail = __builtin_amdgcn_readfirstlane(hand.pair1 ? 1 : 0) != 0; // (wave-uniform, and known to be)
+    if constexpr (HMODE == 2) {
+        if (tail) {
+            // The row above this item: what the pair items of the block's sub-blocks -- at THEIR geometry 2^lgp -- handed over, pass 0
+            // for a lane's first sequence, pass 1 for its second, brought into this item's geometry: entry (column, lane of the first
+            // group); beyond a sub-block's own last column (its sequences are through: dummy residues) and up to this item's: zero in
+            // the column's frame.  The frames of the two geometries differ by (2^lgp - G) * ge.
+            const uint32_t glp = 64u >> hand.lgp, gep = (uint32_t)ge;
+            // (gl divides 64: a lane keeps its lane of the block -- its place with the writers -- through the loop; only the column moves)
+            const uint32_t bl = sigma * gl + ((uint32_t)lane & (gl - 1u)), sg = bl / glp, up = bl % glp;
+            const uint32_t nsub = p.sub_cols[(size_t)B * 128 + ((1u << hand.lgp) - 1u) + sg];
+            const uint2 *l0 = p.hand + (2u * (hand.pair1 - 1u) * p.hand_plane + osw_hand_sub(blk, sg, hand.lgp) + up);
+            const uint32_t fix = hand.framed ? G * gep - (1u << hand.lgp) * gep : 0u; // (mod 2^32: the halves do not borrow from each other, see above)
+            uint2 *row = bnd + OSW_SCRATCH_DATA + ((uint32_t)lane & (gl - 1u));
+            const uint32_t c0 = (uint32_t)lane / gl, cstep = 64u / gl;
+            // eight columns a turn: sixteen independent loads in flight (one after the other they cost a memory latency per column)
+            for (uint32_t cb = c0; cb < ncols; cb += 8u * cstep) {
+                uint2 e0[8], e1[8];
+#pragma unroll
+                for (uint32_t t = 0; t < 8; ++t) {
+                    const uint32_t c = cb + t * cstep;
+                    const bool live = c < nsub; // (beyond: nothing was handed over -- and nothing is read)
+                    e0[t] = live ? l0[(size_t)c * glp] : make_uint2(0u, 0u);
+                    e1[t] = live ? l0[(size_t)c * glp + p.hand_plane] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < 8; ++t) {
+                    const uint32_t c = cb + t * cstep;
+                    if (c >= ncols) break;
+                    uint32_t z = C::kFloorBits;
+                    if constexpr (C::kShifted) z += (c + G) * gep;
+                    uint2 e = make_uint2(z, z);
+                    if (c < nsub) {
+                        e.x = ((e0[t].x >> 16) | (e1[t].x & 0xffff0000u)) + fix;
+                        e.y = ((e0[t].y >> 16) | (e1[t].y & 0xffff0000u)) + fix;
+                    }
+                    row[(size_t)c * gl] = e;
+                }
+            }
+        }
+    }
+    if (plan.rounds > 1 || tail) {
         // the scratch columns the prefetch and the drain steps read past the block's last one are the
         // row above of dummy columns: "zero" in the cell's representation (other items have written here)
         uint2 *pad = bnd + OSW_SCRATCH_DATA + (size_t)ncols * gl;
@@ -1170,7 +1237,9 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     else score = C::zero();
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
-        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4, rb_end = plan.m4 / 4;
+        uint32_t rb_end = plan.m4 / 4;
+        if constexpr (HMODE == 1) { if (hand.store) rb_end = (p.qlen[q] + 3u) / 4u; } // (a SHORT pair item: its strips run on into the longer query's own rows)
+        const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4;
         if (wg) {
 #ifdef OSW_DIAG // (OSWALD_HIP_DEBUG_TIMES: core-clock cycles this wave spends in the slice reload incl. both barriers)
             const unsigned long long tb = p.wg_times ? __builtin_readcyclecounter() : 0ull;
@@ -1192,7 +1261,8 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
             __builtin_amdgcn_wave_barrier();
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
-        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, osw_top_pages<C>(p), rho == 0 || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score);
+        sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, osw_top_pages<C>(p), (rho == 0 && !tail) || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score,
+                             HMODE == 1 && hand.store && p.hand && rho + 1 == plan.rounds ? p.hand + ((2u * q + (uint32_t)half) * p.hand_plane + osw_hand_sub(blk, sigma, lg)) : nullptr);
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
     // addresses are computed here instead of being kept in registers across all the rounds)
@@ -1237,9 +1307,10 @@ static __device__ __forceinline__ void osw_store_score2(const OswSearchArgs &p, 
 
 // Scores of one packed 16-bit item: written for the lanes of group 0; lanes at
 // the ceiling of the cell arithmetic are queued for the exact int32 kernel.
+// (tail: the rows of a pair's longer query beyond the pair's own: the pair item has stored the best score of the rows before)
 template <class A>
 static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
-                                                   uint32_t lg, int lane, v2s score)
+                                                   uint32_t lg, int lane, v2s score, bool tail = false)
 {
     const uint32_t gl = 64u >> lg;
     if ((uint32_t)lane < gl) {
@@ -1247,6 +1318,11 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
         int2 out;
         out.x = A::to_int(score.x);
         out.y = A::to_int(score.y);
+        if (tail) {
+            const int2 before = *(const int2 *)(p.scores + (size_t)q * p.score_stride + (size_t)blk.seq0 + 2 * lam);
+            out.x = out.x > before.x ? out.x : before.x;
+            out.y = out.y > before.y ? out.y : before.y;
+        }
         osw_store_score2(p, q, (size_t)blk.seq0 + 2 * lam, out);
         const uint32_t hm = (A::over(score.x) ? 1u : 0u) | (A::over(score.y) ? 2u : 0u);
         if (hm) {
@@ -1365,21 +1441,39 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
             if (it >= nitems) break;
             item = wave_items[it];
         }
-        const uint32_t q = OSW_ITEM_Q(item.x), sigma = OSW_ITEM_SIGMA(item.x), lg = OSW_ITEM_LG(item.x), B = item.y & ~OSW_ITEM_WG_FLAG;
-        const OswBlock blk = p.blocks[B];
+        const uint32_t q = OSW_ITEM_Q(item.x), lg = OSW_ITEM_LG(item.x), sigma = OSW_ITEM_SIGMA(item.x);
+        uint32_t B = item.y & ~OSW_ITEM_WG_FLAG;
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         uint2 *lds_region = shared ? &lds_prof[0][0] : lds_prof[wv];
+        // Tails (OswSearchArgs::hand).  A pair item whose pair has one hands the longer query's bottom row over, pass by pass; a tail
+        // item (single-query launch; it carries the geometry of the pair items that wrote beside its block index)
+        // starts from there, and what decides its cell is the PAIR items' geometry: both must have spoken the same representation.
+        OswHand hand = {false, 0u, 0u, false};
+        uint32_t lg_cell = lg;
+        if constexpr (PAIR) {
+            hand.store = OSW_ITEM_HALVES(item.x) == OSW_ITEM_SHORT; // (the planner's choice, chunk by chunk: tails pay on large chunks only)
+        } else {
+            if (p.hand && p.tail_pair[q]) {
+                hand.pair1 = p.tail_pair[q];
+                hand.lgp = lg_cell = B >> OSW_ITEM_TAIL_LG_SHIFT; // (a tail item carries the geometry of the pair items that wrote above its block index)
+                B &= (1u << OSW_ITEM_TAIL_LG_SHIFT) - 1u;
+            }
+        }
+        const bool tail = !PAIR && hand.pair1 != 0;
+        const OswBlock blk = p.blocks[B];
         // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest run on CF
-        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge, p.goe_pk & 0xffffu);
+        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg_cell, (uint32_t)p.ge, p.goe_pk & 0xffffu);
+        hand.framed = C::kShifted && !cf_only;
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
+            constexpr int HM = PAIR ? 1 : 2;
             if (cf_only) {
-                const v2s score = run_item<CF, true>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
+                const v2s score = run_item<CF, true, HM>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, hand);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
-                else pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
+                else pk16_finish<typename CF::Arith>(p, tail ? p.tail_query[q] : q, B, blk, sigma, lg, lane, score, tail);
             } else {
-                const v2s score = run_item<C, true>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
+                const v2s score = run_item<C, true, HM>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, hand);
                 if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
-                else pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
+                else pk16_finish<typename C::Arith>(p, tail ? p.tail_query[q] : q, B, blk, sigma, lg, lane, score, tail);
             }
         }
         set_wave_prio(0);

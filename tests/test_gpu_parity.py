@@ -323,6 +323,48 @@ def test_query_pairs(hip_ctx, oracle, lg, wg, monkeypatch):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("lg,wg", [(-1, -1), (0, 0), (1, 0), (3, 0), (2, 1), (4, 1), (6, 1)])
+@pytest.mark.parametrize("go,ge", [(10, 2), (3, 0)])
+def test_pair_tails(hip_ctx, oracle, lg, wg, go, ge, monkeypatch):
+    """Tails (round 5): a pair item marked SHORT runs the shorter query's rows; its last strips end on a row of the longer query
+    -- which row depends on the geometry -- and hand the bottom row over; the rest of the longer query is a single-query item that
+    starts from it.  Forced on (the planner takes tails on large chunks only), at every geometry of the pair items, for pairs whose
+    lengths differ by less than a strip, by several strips (a tail of several rounds) and not at all, with homologs of the longer
+    queries (alignments that cross the hand-over row) and with gap extend 0 (the plain cell on long blocks: no frames to convert)."""
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
+    monkeypatch.setenv("OSWALD_HIP_TAIL_ITEMS", "0")
+    if lg >= 0:
+        monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
+    if wg >= 0:
+        monkeypatch.setenv("OSWALD_HIP_FORCE_WG", str(wg))
+    qs = synth.make_queries([5, 40, 64, 111, 200, 207, 300, 300, 350, 900, 33], seed=500 + lg)   # 5 pairs + one single
+    L, R, O = random_db(300, seed=510 + lg, max_len=140, queries=[qs[3], qs[5], qs[9], qs[9][500:]], homologs=3)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge)
+    want = expect(oracle, qs, b, n, disp, 16, sm, go, ge)
+    np.testing.assert_array_equal(got, want)
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "0")            # ... and the same table with padded pairs
+    np.testing.assert_array_equal(run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge), want)
+
+
+def test_pair_tails_over_the_int16_ceiling(hip_ctx, oracle, monkeypatch):
+    """The longer query of a pair reaches the int16 cells' ceiling in its TAIL rows only (all-W: 11 per cell; 2 000 rows of the pair
+    + 1 000 of the tail): the tail item queues the sequence for the int32 re-run like any other item."""
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
+    monkeypatch.setenv("OSWALD_HIP_TAIL_ITEMS", "0")
+    w = synth.ALPHABET.index("W")
+    qa, qb = np.full(2000, w, np.uint8), np.full(3000, w, np.uint8)
+    seqs = [np.full(k, w, np.uint8) for k in (5, 1990, 2500, 3000)] + [synth.random_residues(3, 0, 300)]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, [qa, qb], b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, [qa, qb], b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want[1].max() == 33000 and hip_ctx.rerun_counts()[1] >= 1
+
+
 def test_query_pairs_overflow_rerun(hip_ctx, oracle, monkeypatch):
     """Either query of a pair can hit the int16 ceiling on its own."""
     monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")

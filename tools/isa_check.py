@@ -33,7 +33,7 @@ STAMP = os.path.join(ROOT, "oswald_amd", "liboswald_hip.isa.json")
 GROUPS = (
     dict(kernels=("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q"), define="OSW_INFLIGHT", file="sw_kernels.hip",
          budget=168,   # three waves per SIMD; the compiler gets 140, the asm statements 27 fixed ones (v158 is spare; v148, v149 unused)
-         scratch=32, min_asm_uses=1000, nfixed=27),
+         scratch=48, min_asm_uses=1000, nfixed=27),   # (spills of item-level values around the rounds: never inside a column loop, check_vmem_windows)
     dict(kernels=("osw_sw_i32",), define="OSW_INFLIGHT", file="sw_kernels.hip",
          budget=168,   # the hand-scheduled int32 cell (cell_bits = 32): the int16 kernels' column loop and register budget
          scratch=0, min_asm_uses=500, nfixed=27),
@@ -126,14 +126,18 @@ def check_register_budget(isa, group=GROUPS[0]):
 
 
 def check_vmem_windows(isa, group=GROUPS[0]):
-    """Inside the column loops (between the prologue's asm loads and the final `s_waitcnt vmcnt(0)` of a round) every
-    vector-memory instruction must come from the asm blocks: a compiler-issued one would shift the hand-counted waits."""
+    """Inside the column loops every vector-memory instruction must come from the asm blocks: a compiler-issued one would shift
+    the hand-counted waits.  A column loop, in the text of a kernel: from the first step's opening wait (the asm
+    `s_waitcnt vmcnt(5) lgkmcnt(0)`) to the last asm vector-memory instruction in front of the round's closing wait (the asm
+    `s_waitcnt vmcnt(0) lgkmcnt(0)`).  A spill of a loop-invariant value between a round's prologue -- which ends in
+    `s_waitcnt vmcnt(0)` -- and its first step, or its reload behind the last step, is outside (counted by check_register_budget)."""
     KERNELS = group["kernels"]
-    fn, inasm, window, bad = None, False, False, []
+    fn, inasm, bad = None, False, []
+    first_begin, last_asm_vm, pending = None, None, []   # of the loop being scanned; compiler VM ops seen since first_begin
     for i, line in enumerate(isa):
         m = re.match(r'^(osw_\w+):', line)
         if m:
-            fn, window = m.group(1), False
+            fn, first_begin, last_asm_vm, pending = m.group(1), None, None, []
         if "#ASMSTART" in line:
             inasm = True
             continue
@@ -143,12 +147,17 @@ def check_vmem_windows(isa, group=GROUPS[0]):
         if fn not in KERNELS or not line.startswith("\t"):
             continue
         code = line.split(";")[0].strip()
-        if inasm and code.startswith("global_load_ushort"):
-            window = True
-        if inasm and code.startswith("s_waitcnt vmcnt(0) lgkmcnt(0)"):
-            window = False
-        if window and not inasm and re.match(r'(global_|buffer_|flat_|scratch_)', code):
-            bad.append((i + 1, code))
+        vm = re.match(r'(global_|buffer_|flat_|scratch_)', code) is not None
+        if inasm and code.startswith("s_waitcnt vmcnt(5) lgkmcnt(0)") and first_begin is None:
+            first_begin, pending = i, []
+        elif inasm and code.startswith("s_waitcnt vmcnt(0) lgkmcnt(0)"):
+            if first_begin is not None and last_asm_vm is not None:
+                bad += [(k + 1, c) for k, c in pending if k < last_asm_vm]
+            first_begin, last_asm_vm, pending = None, None, []
+        elif inasm and vm and first_begin is not None:
+            last_asm_vm = i
+        elif not inasm and vm and first_begin is not None:
+            pending.append((i, code))
     return bad
 
 
