@@ -58,6 +58,9 @@ if d:
     vals.update(INCLC4=f"{inc['ms_per_step']:.1f}", RESC4=f"{d['ms_per_step']:.1f}", INCLC4P=f"{100 * inc['vs_resident']:.2f}".lstrip("+"), INCLC4G=sp(inc["value"]))
     if d.get("cpu_baseline"):
         vals["CPUGCUPS"] = sp(d["cpu_baseline"]["value"])
+dn = bench("c4_1gpu_notails")
+if d and dn:
+    vals.update(C4TAILS=sp(d["value"]), C4NOTAILS=sp(dn["value"]), TAILGAIN=f"{100 * (d['value'] / dn['value'] - 1):.1f}")
 d = bench("q1_1m")
 if d:
     vals.update(INCLQ1=f"{d['inclusive']['ms_per_step']:.2f}", RESQ1=f"{d['ms_per_step']:.2f}")

@@ -25,6 +25,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "
 b() { name=$1; shift; python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "bench $name rc=$? $(python -c "import json;l=[x for x in open('$OUT/bench_$name.json').read().split(chr(10)) if x.startswith('{')];d=json.loads(l[-1]);print(d['value'],d['ms_per_step'],d['roofline']['kernel_ms'],d['roofline']['traffic'],d.get('top_equals_single_gpu_golden'))" 2>/dev/null)"; }
 b c4_1gpu --steps 20 --warmup 5
 b c4_1gpu_comm --steps 20 --warmup 5 --comm --cpu-seconds 0
+OSWALD_HIP_PAIR_TAILS=0 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $OUT/bench_c4_1gpu_notails.json 2> $OUT/bench_c4_1gpu_notails.err; echo "bench c4 without tails rc=$?"
 b c2 --nseq 100000 --steps 20 --warmup 5
 b c3_int8 --workload c3 --steps 10 --warmup 2
 b c3_int16 --workload c3 --cell-bits 16 --steps 20 --warmup 5 --cpu-seconds 0
