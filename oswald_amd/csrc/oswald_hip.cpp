@@ -1266,6 +1266,17 @@ int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes
             if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
             if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
         }
+        // the hand-over planes of the tails (OswSearchArgs::hand; one set per device): if a query set of nq queries would get them on
+        // chunks of this size (the planner's rule, osw_planner.inc), they are made here -- 3.6 GB for the BASELINE set on 128-MiB chunks:
+        // tens of milliseconds that would otherwise fall into the first search that takes tails (the hybrid mode rates the device on
+        // its first searches)
+        {
+            const uint32_t np = nq / 2;
+            const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
+            if (ctx->tun.pair_tails > 0 && np >= 1 && np <= (uint32_t)ctx->tun.pair_tails &&
+                (double)nblocks * (double)np >= ctx->tun.tail_items_per_wave * (double)d.grid * (OSW_WG_THREADS / 64) && col4 * 256ull * 2ull * np < (1ull << 32))
+                HIP_TRY(d.hand.reserve(col4 * 256ull * 2ull * np * sizeof(uint2) + 4096));
+        }
         if (ctx->tun.warm_ms > 0) {
             HIP_TRY(osw_launch_spin((uint32_t *)d.counters.p, d.grid, std::min(ctx->tun.warm_ms, 50.0), d.stream));
             HIP_TRY(hipStreamSynchronize(d.stream));

@@ -1262,7 +1262,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
         sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, osw_top_pages<C>(p), (rho == 0 && !tail) || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score,
-                             HMODE == 1 && hand.store && p.hand && rho + 1 == plan.rounds ? p.hand + ((2u * q + (uint32_t)half) * p.hand_plane + osw_hand_sub(blk, sigma, lg)) : nullptr);
+                             HMODE == 1 && hand.store && p.hand && rho + 1 == plan.rounds ? p.hand + ((2u * q + (uint32_t)half) * p.hand_plane + osw_hand_sub(p.blocks[B], sigma, lg)) : nullptr); // (the block's entry read again: nothing of it is kept through the rounds for this)
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
     // addresses are computed here instead of being kept in registers across all the rounds)
@@ -1464,14 +1464,21 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest run on CF
         const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg_cell, (uint32_t)p.ge, p.goe_pk & 0xffffu);
         hand.framed = C::kShifted && !cf_only;
+        // (two instantiations of the item code: the ordinary items run the one without any hand-over state -- kept through the rounds, that
+        // state costs the query-pair kernel 3 % on many-round items: registers it does not have -- the SHORT pair items / the tail items
+        // the other)
+        const bool special = PAIR ? hand.store : tail;
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             constexpr int HM = PAIR ? 1 : 2;
+            v2s score;
             if (cf_only) {
-                const v2s score = run_item<CF, true, HM>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, hand);
+                if (special) score = run_item<CF, true, HM>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, hand);
+                else score = run_item<CF, true, 0>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
                 if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename CF::Arith>(p, tail ? p.tail_query[q] : q, B, blk, sigma, lg, lane, score, tail);
             } else {
-                const v2s score = run_item<C, true, HM>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, hand);
+                if (special) score = run_item<C, true, HM>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, hand);
+                else score = run_item<C, true, 0>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
                 if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 else pk16_finish<typename C::Arith>(p, tail ? p.tail_query[q] : q, B, blk, sigma, lg, lane, score, tail);
             }
