@@ -1267,14 +1267,14 @@ int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes
             if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
         }
         // the hand-over planes of the tails (OswSearchArgs::hand; one set per device): if a query set of nq queries would get them on
-        // chunks of this size (the planner's rule, osw_planner.inc), they are made here -- 3.6 GB for the BASELINE set on 128-MiB chunks:
+        // chunks of this size (the planner's rule, osw_planner.inc), they are made here -- 11.7 GB for the BASELINE set on the 128-MiB chunks of the C4 database:
         // tens of milliseconds that would otherwise fall into the first search that takes tails (the hybrid mode rates the device on
         // its first searches)
         {
             const uint32_t np = nq / 2;
             const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
             if (ctx->tun.pair_tails > 0 && np >= 1 && np <= (uint32_t)ctx->tun.pair_tails &&
-                (double)nblocks * (double)np >= ctx->tun.tail_items_per_wave * (double)d.grid * (OSW_WG_THREADS / 64) && col4 * 256ull * 2ull * np * sizeof(uint2) <= (8ull << 30))
+                (double)nblocks * (double)np >= ctx->tun.tail_items_per_wave * (double)d.grid * (OSW_WG_THREADS / 64) && col4 * 256ull * 2ull * np * sizeof(uint2) <= OSW_HAND_MAX_BYTES)
                 HIP_TRY(d.hand.reserve(col4 * 256ull * 2ull * np * sizeof(uint2) + 4096));
         }
         if (ctx->tun.warm_ms > 0) {
@@ -1310,9 +1310,9 @@ int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_
     // ... and ONE set of hand-over planes per device for the tails of a small query set's pairs (OswSearchArgs::hand): two planes per pair,
     // 64 entries of 8 B per re-tiled column = 4 x the re-tiled residues and their dummy columns each
     const uint32_t np = nq / 2;
-    // (at most 8 GB: the planner takes no tails on chunks whose planes would be larger)
+    // (at most OSW_HAND_MAX_BYTES: the planner takes no tails on chunks whose planes would be larger)
     const bool hand_possible = ctx->tun.pair_tails > 0 && np >= 1 && np <= (uint32_t)ctx->tun.pair_tails;
-    if (hand_possible) usable = usable > (8ull << 30) + (1ull << 30) ? usable - (8ull << 30) : usable / 2;
+    if (hand_possible) usable = usable > OSW_HAND_MAX_BYTES + (1ull << 30) ? usable - OSW_HAND_MAX_BYTES : usable / 2;
     const double per_byte = 4.1 * (1.0 + 1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
     const uint64_t fit = (uint64_t)((double)usable / per_byte);
     *bytes = std::min<uint64_t>(fit, 0xfff00000ull); // (column offsets inside a chunk are 32-bit)

@@ -69,6 +69,7 @@
 #define OSW_ITEM_PRIO(x) (((x) >> 30) & 3u)
 #define OSW_ITEM_WG_FLAG 0x80000000u  // in y of a phase-1 slot: workgroup item (shared profile slice, waves in step)
 #define OSW_ITEM_NONE 0x7fffffffu     // y of an empty slot
+#define OSW_HAND_MAX_BYTES (16ull << 30) // the hand-over planes of a device at most (the BASELINE set's ten pairs on a 128-MiB chunk of the C4 database: 11.7 GB; entry indices are 32-bit: 34 GB would be the end)
 #define OSW_ITEM_SHORT 1u             // `halves` field of a pair item: the pair's register holds the shorter query's rows only; the last round hands over
 #define OSW_ITEM_TAIL_LG_SHIFT 24      // y of a tail item (wave items only): block | (log2 geometry of the pair items that handed over) << 24
 
