@@ -696,8 +696,11 @@ int do_search_hybrid(Options &o)
         g1 = back;
         g0 = back;
         while (g0 > front && (g1 - g0 < host_min_groups || cells(g0, g1) < target)) --g0;
-        // ... unless the accelerator would be through with everything else before the host is through with this batch
-        if (!force_split && gpu_gcups > 0 && cells(front, g0) / gpu_gcups < cells(g0, g1) / cpu_live) return false;
+        // ... unless the accelerator would be through with everything else before the host is through with this batch -- with a margin
+        // of 2.5 on the host's time: since its kernel starts in int8 (round 5) a batch of the longest sequences may take twice what the
+        // rating says (groups that reach 127 are redone in int16), and a batch that overruns the end by 5 ms costs a 100 000-sequence
+        // search 13 % (seen twice in 25 runs; the host's whole share is 1 %)
+        if (!force_split && gpu_gcups > 0 && cells(front, g0) / gpu_gcups < 2.5 * cells(g0, g1) / cpu_live) return false;
         back = g0;
         return true;
     };
