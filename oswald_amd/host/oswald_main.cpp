@@ -183,6 +183,10 @@ struct PinnedResidues {
 // devices 0 .. num_devices-1, or the list in OSWALD_DEVICE_IDS ("0,0": two context devices on one GPU; test hook)
 int bring_up(const Options &o, oswald_hip_ctx **ctx)
 {
+    // Tails (the library's way to spare a query pair its padding on large chunks: DESIGN 4) need hand-over planes -- 11.7 GB for twenty
+    // queries on 128-MiB chunks -- and making them costs 150 - 500 ms: a long-lived context gets that back at 1.7 ms per chunk search, a
+    // tool that searches a database once and leaves does not.  Off, unless the caller's environment says otherwise.
+    if (!getenv("OSWALD_HIP_PAIR_TAILS")) setenv("OSWALD_HIP_PAIR_TAILS", "0", 1);
     std::vector<int> ids;
     if (const char *e = getenv("OSWALD_DEVICE_IDS"))
         for (const char *p = e; *p;) { ids.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
