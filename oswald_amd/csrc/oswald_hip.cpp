@@ -70,7 +70,8 @@ struct Tunables {
     bool no_direct_table = false;      // OSWALD_HIP_NO_DIRECT_TABLE=1 (A/B and test hook): score tables leave by DMA on the download stream even when the kernels could write them
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
     int pair_tails = 16;               // OSWALD_HIP_PAIR_TAILS=n: query sets of up to n pairs may run the rows a pair's longer query has beyond the shorter one's as tail items (0: always pad the shorter query, rounds 1-5)
-    double tail_items_per_wave = 6.0;  // OSWALD_HIP_TAIL_ITEMS=x: ... on chunks that give every wave of the grid at least x tail items (smaller chunks: the extra launch costs more than the padding)
+    int tail_lg = -1;                  // OSWALD_HIP_TAIL_LG=k: tail items of geometry 2^k (test hook; -1: whole blocks on large chunks, quarters on medium ones)
+    double tail_items_per_wave = 2.5;  // OSWALD_HIP_TAIL_ITEMS=x: ... on chunks with at least x (pair, block) tails per wave of the grid (smaller chunks: the extra launch costs more than the padding)
     double warm_ms = 0.0;              // OSWALD_HIP_WARM_MS=ms: oswald_hip_reserve_chunks ends with every CU of the device busy for that long (experiment: clock ramp before a first search)
     size_t split_bytes = 32u << 20;    // OSWALD_HIP_SPLIT_BYTES=bytes: from this size on an asynchronous upload that finds its device idle is cut into head + rest (0: never; a small value: test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
@@ -103,7 +104,8 @@ void Tunables::refresh()
     split_bytes = (size_t)num("OSWALD_HIP_SPLIT_BYTES", (double)(32u << 20));
     warm_ms = num("OSWALD_HIP_WARM_MS", 0.0);
     pair_tails = (int)num("OSWALD_HIP_PAIR_TAILS", 16);
-    tail_items_per_wave = num("OSWALD_HIP_TAIL_ITEMS", 6.0);
+    tail_items_per_wave = num("OSWALD_HIP_TAIL_ITEMS", 2.5);
+    tail_lg = (int)num("OSWALD_HIP_TAIL_LG", -1);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
 #ifdef OSW_DIAG
     pair_margin = num("OSWALD_HIP_PAIR_MARGIN", pair_margin);

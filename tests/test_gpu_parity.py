@@ -333,6 +333,8 @@ def test_pair_tails(hip_ctx, oracle, lg, wg, go, ge, monkeypatch):
     queries (alignments that cross the hand-over row) and with gap extend 0 (the plain cell on long blocks: no frames to convert)."""
     monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
     monkeypatch.setenv("OSWALD_HIP_TAIL_ITEMS", "0")
+    if ge == 0:
+        monkeypatch.setenv("OSWALD_HIP_TAIL_LG", "0" if lg < 3 else "1")   # tail items over whole / half blocks (default on a chunk this small: quarters)
     if lg >= 0:
         monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
     if wg >= 0:
