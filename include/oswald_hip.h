@@ -156,7 +156,9 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
  * and -- with nq > 0 -- score table, re-run queue and work queues for a set of nq queries) for chunks of up to chunk_bytes
  * bytes in ngroups groups of lane_width sequences, on device dev (dev < 0: all), allocated NOW instead of by the first
  * uploads and searches: mapping device memory costs ~20 ms per GB, which a short search would otherwise pay inside its
- * timed region.  A hint only: a chunk that needs more grows its slot as before.  The reference creates its six device
+ * timed region.  With nq > 0 this includes the hand-over planes of the tails a query set of nq queries would get on chunks of
+ * that size (DESIGN 4 "Tails": up to 16 GB per device; OSWALD_HIP_PAIR_TAILS=0 in the environment: none).  A hint only: a
+ * chunk that needs more grows its slot as before.  The reference creates its six device
  * buffers, sized for the largest chunk, once per search and re-uses them for every chunk (FPGAsearch.c:85-96). */
 int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t lane_width,
                               uint32_t nq, uint32_t slots);
