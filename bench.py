@@ -31,8 +31,10 @@ Workload (default, every N): BASELINE.json configs[3] (C4), the configuration th
                ndev (host/src/FPGAsearch.c:132-138) -- the longest sequences all
                land in the last shard.
   Database indices are positions in the globally sorted database, so the merged
-  top-10 is the same list for every N and rule (tests/golden/bench_top_*.json
-  holds the single-GPU result; a mismatch fails the run).
+  top-10 is the same list for every N and rule (tests/reference_runs/bench_top_*.json
+  holds a single-GPU run's list -- written by the HIP path, its scores pinned to
+  the oracle by tests/test_reference_runs.py; a mismatch fails the run).  At N = 1
+  the list of THIS run is checked against the oracle itself: `top10_equals_oracle`.
   --nseq overrides the TOTAL number of database sequences (--nseq 100000 =
   BASELINE.json configs[1], C2); --workload c3 / c5 / q1 default to 100 000;
   --weak restores round 1's mode (an independent --nseq database per GPU).
@@ -101,7 +103,7 @@ def parse():
                          "made by oswald_hip_comm_init_rank; torch.distributed only hands the id round and keeps time), torch = torch.distributed.all_gather "
                          "of the ranks' lists; auto = lib over RCCL, torch for the gloo rehearsal")
     ap.add_argument("--comm", action="store_true", help="N = 1: give the one rank a process-level RCCL communicator all the same (the gather path of N > 1 at world size 1)")
-    ap.add_argument("--write-top-golden", action="store_true", help="N = 1 only: write tests/golden/bench_top_<workload>_<nseq>.json")
+    ap.add_argument("--write-top-reference-run", action="store_true", help="N = 1 only: write tests/reference_runs/bench_top_<workload>_<nseq>.json (this run's merged top list)")
     return ap.parse_args()
 
 
@@ -406,7 +408,7 @@ def main():
         else:
             result["ranks"] = [{"rank": 0, "device": gpu, "device_count": ngpu_visible, "pci_bus_id": pci_bus_id(ctx), "shard_sequences": int(sum(c["nseq"] for c in chunks)),
                                 "shard_residues": int(d_local), "chunks": len(chunks), "ms_per_step": round(elapsed_rank / args.steps * 1e3, 3)}]
-        result["top_equals_single_gpu_golden"] = check_top_golden(args, nseq_total, strong, world, top)
+        result["top_equals_single_gpu_reference_run"] = check_top_reference_run(args, nseq_total, strong, world, top)
         # not `value`: the same pass when the boundary hands over host buffers -- the reference's timed region
         # (FPGAsearch.c:80 -> :276: uploads + kernels + download of the score table).  The host buffers are pinned
         # (the reference allocates its own 64-byte aligned "for DMA", sequences.h:15, FPGAsearch.c:69-74), and the
@@ -418,6 +420,11 @@ def main():
         result["pcie_inclusive_pageable"] = pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned=False, steps=2)["value"]
         if args.cpu_seconds > 0 and world == 1 and chunks:  # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args, a, m, a_disp, chunks, ctx, sm, wl, sum_m)
+            # the metric's own clause, "top-10 score bit-exact", against the ORACLE (its scalar restatement) on the list the timed steps
+            # produced: the nq x top listed pairs, every planted homolog (score in the downloaded tables, presence in the list)
+            if strong:
+                result["top10_oracle"] = top_oracle_pin(plan, shard, queries, sm, wl, top, chunks)
+                result["top10_equals_oracle"] = result["top10_oracle"]["ok"]
     for c in chunks:
         ctx.chunk_release(c["h"])
     ctx.close()
@@ -426,8 +433,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
-        if result.get("top_equals_single_gpu_golden") is False:
-            raise SystemExit("bench.py: the merged top list differs from the single-GPU golden result (tests/golden/bench_top_*.json)")
+        if result.get("top_equals_single_gpu_reference_run") is False:
+            raise SystemExit("bench.py: the merged top list differs from the single-GPU run's list (tests/reference_runs/bench_top_*.json)")
+        if result.get("top10_equals_oracle") is False:
+            raise SystemExit("bench.py: the top list differs from the oracle: " + json.dumps(result["top10_oracle"]))
 
 
 def pci_bus_id(ctx):
@@ -486,19 +495,20 @@ def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned, steps):
                     + ("page-locked host buffers (oswald_hip_host_alloc)" if pinned else "pageable host memory")}
 
 
-def golden_path(args, nseq_total):
-    return os.path.join(ROOT, "tests", "golden", f"bench_top_{args.workload}_{nseq_total}.json")
+def reference_run_path(args, nseq_total):
+    return os.path.join(ROOT, "tests", "reference_runs", f"bench_top_{args.workload}_{nseq_total}.json")
 
 
-def check_top_golden(args, nseq_total, strong, world, top):
+def check_top_reference_run(args, nseq_total, strong, world, top):
     """The merged top-r list (scores and positions in the globally sorted database) against the list a
-    single GPU produced for the same workload (written with --write-top-golden at N = 1): True / False,
-    or None when no golden exists for this workload (or in --weak mode, where the database differs)."""
+    single GPU produced for the same workload (written with --write-top-reference-run at N = 1; NOT an oracle
+    result -- tests/test_reference_runs.py pins its scores to the oracle): True / False, or None when no such
+    file exists for this workload (or in --weak mode, where the database differs)."""
     if not strong or top is None:
         return None
     sc, ix = top
-    path = golden_path(args, nseq_total)
-    if args.write_top_golden and world == 1:
+    path = reference_run_path(args, nseq_total)
+    if args.write_top_reference_run and world == 1:
         with open(path, "w") as f:
             json.dump({"workload": args.workload, "nseq": nseq_total, "top": args.top, "scores": sc.tolist(), "index": ix.tolist()}, f)
         return True
@@ -509,6 +519,32 @@ def check_top_golden(args, nseq_total, strong, world, top):
         return None
     r = min(args.top, g["top"])
     return bool(np.array_equal(np.array(g["scores"])[:, :r], sc[:, :r]) and np.array_equal(np.array(g["index"])[:, :r], ix[:, :r]))
+
+
+def top_oracle_pin(plan, shard, queries, sm, wl, top, chunks):
+    """oracle/toppin.py on the list of the timed steps (N = 1): the scalar restatement on the listed (query, sequence) pairs and
+    on the planted homologs, whose GPU scores come from the score tables the inclusive leg downloaded."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    import toppin
+    tables = pcie_inclusive.last_scores
+    starts = [(int(c["gpos"][0]), int(c["gpos"][-1]), k) for k, c in enumerate(chunks) if len(c["gpos"])]
+
+    def score_at(q, pos):
+        for lo, hi, k in starts:
+            if lo <= pos <= hi:
+                j = int(np.searchsorted(chunks[k]["gpos"], pos))
+                if j < len(chunks[k]["gpos"]) and int(chunks[k]["gpos"][j]) == pos:
+                    return tables[k][q, j]
+        raise KeyError(pos)
+
+    t0 = time.perf_counter()
+    pin = toppin.pin_top_list(pyoracle, plan, shard.order, queries, sm, wl["go"], wl["ge"], top[0], top[1], score_at=score_at)
+    pin["seconds"] = round(time.perf_counter() - t0, 2)
+    pin["what"] = ("oracle/sw_oracle.c scalar restatement on the nq x top (query, listed sequence) pairs and on the planted homologs "
+                   "(score in the downloaded table; a copy that outscores a list's last entry must be listed)")
+    pin["first"] = [list(map(lambda v: None if v is None else int(v) if not isinstance(v, str) else v, x)) for x in pin["first"]]
+    return pin
 
 
 def measured_traffic(workload_name, nseq, dtype=None):

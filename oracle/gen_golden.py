@@ -6,7 +6,10 @@ reference* (oracle/_ref/libosw_ref.so, built in place from /root/reference by
 `make -C oracle ref`) on inputs defined here.  Only inputs and the reference's
 outputs are stored -- no reference source text.  Run in the build container:
 
-    python oracle/gen_golden.py
+    python oracle/gen_golden.py [output directory, default tests/golden]
+
+(tests/test_golden_regenerates.py runs it into a scratch directory wherever the
+reference is present and compares the files with the committed ones.)
 
 Vectors:
   G1 alphabet.json ....... preprocess_db on every upper-case letter (+ a few
@@ -286,6 +289,9 @@ def gen_sort(lib):
 
 
 def main():
+    global OUT
+    if len(sys.argv) > 1:
+        OUT = os.path.abspath(sys.argv[1])
     os.makedirs(OUT, exist_ok=True)
     lib = ref_lib()
     with tempfile.TemporaryDirectory() as tmp:

@@ -261,7 +261,9 @@ class Context:
         n = np.ascontiguousarray(n, dtype=np.uint16)
         disp = np.ascontiguousarray(disp, dtype=np.uint32)
         assert out.dtype == np.int32 and out.flags.c_contiguous
-        self._keep.append(out)
+        # the call is asynchronous throughout: `b` is read by DMA until wait() (include/oswald_hip.h); ascontiguousarray may
+        # have made a temporary of it.  n and disp are copied by the library inside the call.
+        self._keep += [b, out]
         _chk(self.lib.oswald_hip_search_chunk_async(self.h, dev, _ptr(b), b.size, _ptr(n), _ptr(disp), n.size, lane_width, _ptr(out)))
 
     def wait(self, dev: int = -1):

@@ -163,6 +163,7 @@ class DatabasePlan:
         self.nseq, self.seed = nseq, seed
         lengths = random_lengths(seed, nseq).astype(np.int64)
         self.planted = {}
+        self.planted_query = {}   # generation-order id of a planted copy -> the query it is a copy of
         if queries is not None and nseq > 0:
             ranks = splitmix64(seed ^ 0x9A17ED, 0, len(queries) * homologs_per_query)
             k = 0
@@ -176,6 +177,7 @@ class DatabasePlan:
                     if len(mut) > 65520:
                         mut = mut[:65520]
                     self.planted[idx] = mut
+                    self.planted_query[idx] = qi
                     lengths[idx] = len(mut)
                     k += 1
         self.lengths = lengths

@@ -59,6 +59,13 @@ def oracle():
     return pyoracle
 
 
+@pytest.fixture(scope="session")
+def toppin(oracle):
+    """oracle/toppin.py: a top list pinned to the oracle's scalar scores (the metric's "top-10 score bit-exact")."""
+    import toppin as tp
+    return tp
+
+
 def _two_device_ids(kind):
     """Device ids of a two-device context: "aliased" = the one GPU of the test box twice (per-device streams, buffers
     and queues, level-1 gather on one GPU); "distinct" = GPUs 0 and 1 -- different devices, peer traffic and the RCCL

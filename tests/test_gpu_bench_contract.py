@@ -73,15 +73,15 @@ def test_bench_sharded_ranks_rehearsal(first_pass):
     assert "chunk rule" in ref["config"]["sharding"] and ref["config"]["chunks_rank0"] >= 2
 
 
-def _golden_top(nseq):
-    with open(os.path.join(ROOT, "tests", "golden", f"bench_top_c2_{nseq}.json")) as f:
+def _reference_run_top(nseq):
+    with open(os.path.join(ROOT, "tests", "reference_runs", f"bench_top_c2_{nseq}.json")) as f:
         return json.load(f)
 
 
 def test_bench_library_gather_at_world_size_one(first_pass):
     """`bench.py --gpus 1 --comm`: the one rank joins a process-level RCCL communicator made through the C ABI, and every
     step's oswald_hip_topr runs the all-gather + fold of N > 1 (at world size 1).  The line says who carried the gather
-    and how many ranks RCCL itself reported; the merged top-10 is the committed single-GPU golden."""
+    and how many ranks RCCL itself reported; the merged top-10 is the committed single-GPU run's list (pinned to the oracle by tests/test_reference_runs.py)."""
     if first_pass != "i16":
         pytest.skip("one run is enough")
     env = dict(os.environ)
@@ -90,15 +90,15 @@ def test_bench_library_gather_at_world_size_one(first_pass):
     c = d["config"]
     assert c["collective_backend"] == "RCCL (nccl)" and c["collective_note"] is None and c["collective_ranks"] == 1
     assert "liboswald_hip.so" in c["collective_via"] and "ncclAllGather" in c["collective_via"]
-    assert d["top_equals_single_gpu_golden"] is True
-    assert d["top1_scores"] == [row[0] for row in _golden_top(100000)["scores"]]
+    assert d["top_equals_single_gpu_reference_run"] is True
+    assert d["top1_scores"] == [row[0] for row in _reference_run_top(100000)["scores"]]
 
 
 def test_bench_two_gpus_over_rccl(first_pass):
     """The N > 1 path on real hardware, wherever the box has two GPUs (the round's own test box has one: skipped
     there, runs by itself on a multi-GPU node): `bench.py --gpus 2`, one rank per GPU, RCCL -- no rehearsal backend,
     no fallback -- with the gather inside the C ABI and, second run, through torch.distributed.  RCCL must have seen
-    two ranks, and the merged top-10 must be the committed single-GPU golden under both shard rules."""
+    two ranks, and the merged top-10 must be the committed single-GPU run's list under both shard rules."""
     if first_pass != "i16":
         pytest.skip("one run is enough")
     from oswald_amd import capi
@@ -108,14 +108,14 @@ def test_bench_two_gpus_over_rccl(first_pass):
     env.pop("OSWALD_HIP_CELL_BITS", None)
     env.pop("OSWALD_BENCH_BACKEND", None)
     common = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--nseq", "100000", "--cpu-seconds", "0"]
-    gold = [row[0] for row in _golden_top(100000)["scores"]]
+    gold = [row[0] for row in _reference_run_top(100000)["scores"]]
     for k, extra in enumerate((["--gather", "lib"], ["--gather", "torch"], ["--gather", "lib", "--shard-rule", "reference"])):
         d = _bench(common + extra, dict(env, MASTER_PORT=str(29621 + k)))
         c = d["config"]
         assert d["n_gpus"] == 2 and d["scaling"] == "strong"
         assert c["collective_backend"] == "RCCL (nccl)" and c["collective_note"] is None and c["collective_ranks"] == 2, c
         assert ("liboswald_hip.so" in c["collective_via"]) == (extra[1] == "lib")
-        assert d["top_equals_single_gpu_golden"] is True and d["top1_scores"] == gold
+        assert d["top_equals_single_gpu_reference_run"] is True and d["top1_scores"] == gold
         assert d["value"] > 100
     # the library's communicator cannot be made (test hook: no rank joins it): the ranks decide TOGETHER to carry their lists
     # through torch.distributed -- still RCCL, and the line says so; asked for by name, `--gather lib` ends non-zero instead
@@ -123,13 +123,13 @@ def test_bench_two_gpus_over_rccl(first_pass):
     c = d["config"]
     assert c["collective_backend"] == "RCCL (nccl)" and c["collective_ranks"] == 2 and c["collective_via"] == "torch.distributed.all_gather"
     assert "oswald_hip_comm_init_rank failed" in c["collective_note"]
-    assert d["top_equals_single_gpu_golden"] is True and d["top1_scores"] == gold
+    assert d["top_equals_single_gpu_reference_run"] is True and d["top1_scores"] == gold
     # ... and the partial case: ONE rank reports a failure, the other holds a working communicator -- both must give it up
     # (oswald_hip_comm_destroy) before the lists go through torch, or the rank that kept it would all-gather alone inside oswald_hip_topr
     d = _bench(common, dict(env, MASTER_PORT="29628", OSWALD_BENCH_FAIL_LIB_COMM="rank:1"))
     c = d["config"]
     assert c["collective_ranks"] == 2 and c["collective_via"] == "torch.distributed.all_gather" and "another rank" in c["collective_note"]
-    assert d["top_equals_single_gpu_golden"] is True and d["top1_scores"] == gold
+    assert d["top_equals_single_gpu_reference_run"] is True and d["top1_scores"] == gold
     assert len(d["ranks"]) == 2 and d["rank_ms_per_step"]["distinct_devices"] == 2 and all(r["device_count"] >= 2 for r in d["ranks"])
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--gather", "lib"], cwd=ROOT, capture_output=True, text=True, timeout=900,
                        env=dict(env, MASTER_PORT="29627", OSWALD_BENCH_FAIL_LIB_COMM="1"))

@@ -27,6 +27,23 @@ def db100k():
     return qs, sl, sr, so, b, n, disp.astype(np.uint32)
 
 
+@pytest.fixture(scope="module")
+def plan100k():
+    """The same database as a plan (lengths + planted homologs and the query each is a copy of) and its sort order."""
+    qs = synth.make_queries(synth.default_query_lengths())
+    plan = synth.DatabasePlan(100000, qs, synth.SEED_DB, 12)
+    return plan, np.argsort(plan.lengths, kind="stable")
+
+
+def pin_to_oracle(toppin, oracle, plan, order, qs, sm, go, ge, sc, pos, score_at):
+    """The metric's clause "top-10 score bit-exact" against the ORACLE: the scalar restatement on the nq x 10 listed
+    (query, sequence) pairs and on all 12 planted homologs of every query; no planted copy that outscores a list's
+    last entry is absent from it (oracle/toppin.py)."""
+    pin = toppin.pin_top_list(oracle, plan, order, qs, sm, go, ge, sc, pos, score_at=score_at)
+    assert pin["ok"], pin
+    assert pin["list_pairs"] == len(qs) * 10 and pin["planted"] == len(qs) * 12 and pin["planted_absent"] == 0, pin
+
+
 def sample_groups(nseq, W, stride, tail):
     """Every stride-th W-lane group plus the last `tail` groups -> sequence indices."""
     ng = (nseq + W - 1) // W
@@ -57,7 +74,7 @@ def check_properties(t, sc, ix, nseq, m, sl, sm):
     assert (np.diff(sc.astype(np.int64), axis=1) <= 0).all()
 
 
-def test_c2_full_size_properties(hip_ctx, oracle, db100k):
+def test_c2_full_size_properties(hip_ctx, oracle, toppin, db100k, plan100k):
     qs, sl, sr, so, b, n, disp = db100k
     nseq = len(sl)
     a, m, ad = pack_queries(qs)
@@ -77,6 +94,7 @@ def test_c2_full_size_properties(hip_ctx, oracle, db100k):
     check_properties(t1, sc, ix, nseq, m, sl, sm)
     # the 12 planted copies of every query dominate its top-10 (well beyond the int8 range)
     assert (sc[:, 0] > 127).all() and (sc[:, 9] > 60).all()
+    pin_to_oracle(toppin, oracle, *plan100k, qs, sm, 10, 2, sc, ix, lambda q, p: t1[q, p])
     seqs = sample_groups(nseq, 32, 40, 8)
     np.testing.assert_array_equal(t1[:, seqs], cpu_port_scores(oracle, a, m, ad, sl, sr, so, seqs, sm, 10, 2))
     # chunked the reference's way (8 MiB chunks) == one chunk
@@ -92,7 +110,7 @@ def test_c2_full_size_properties(hip_ctx, oracle, db100k):
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), t1)
 
 
-def test_c3_pam250_full_size(hip_ctx, oracle, db100k):
+def test_c3_pam250_full_size(hip_ctx, oracle, toppin, db100k, plan100k):
     """BASELINE configs[2]: the same queries and database with PAM250, gap 14/2, in the named cell mode -- int8 cells
     (cell_bits = 8: SWAR 8-bit first pass, int16 re-run of what leaves its range, int32 beyond) -- and on the
     default int16 cells: both must give the reference's exact scores, i.e. identical tables."""
@@ -113,6 +131,7 @@ def test_c3_pam250_full_size(hip_ctx, oracle, db100k):
         hip_ctx.chunk_release(h)
         check_properties(t, sc, ix, nseq, m, sl, sm)
         assert (sc[:, 0] > 127).all()
+        pin_to_oracle(toppin, oracle, *plan100k, qs, sm, 14, 2, sc, ix, lambda q, p: t[q, p])
         tables[bits] = t
         if bits == 8:
             assert 0 < to16 < 0.05 * t.size      # the homologs and a few strong random hits, not the bulk
@@ -157,7 +176,7 @@ def test_c5_long_query_full_size(hip_ctx, oracle, db100k):
     np.testing.assert_array_equal(t1[:, seqs], cpu_port_scores(oracle, a, m, ad, lens, allres, off, seqs, sm, 10, 2))
 
 
-def test_c4_database_on_one_gpu_chunked(hip_ctx, oracle):
+def test_c4_database_on_one_gpu_chunked(hip_ctx, oracle, toppin):
     """BASELINE configs[3]'s database (1 000 000 sequences) on ONE GPU, cut into 128 MiB chunks by the reference's
     rule (sequences.c:505-541, the -k default) and searched chunk after chunk like `oswald -O search` does;
     per-chunk device top-r merged to the global top-10 (positions in the globally sorted database)."""
@@ -170,6 +189,11 @@ def test_c4_database_on_one_gpu_chunked(hip_ctx, oracle):
     hip_ctx.set_scoring(sm, 10, 2)
     hip_ctx.set_queries(a, m, ad)
     parts, best = [], None
+    # the planted homologs' places in the sorted database: their scores are kept from every chunk's table for the oracle pin below
+    inv = np.empty(plan.nseq, np.int64)
+    inv[shard.order] = np.arange(plan.nseq)
+    planted_at = sorted((int(inv[idx]), qi) for idx, qi in plan.planted_query.items())
+    planted_score = {}
     for k in range(len(shard.mine)):
         c = shard.chunk(k)
         h = hip_ctx.chunk_upload(c["b"], c["n"], c["disp"], 16)
@@ -187,6 +211,9 @@ def test_c4_database_on_one_gpu_chunked(hip_ctx, oracle):
         seqs = sample_groups(c["nseq"], 32, 150, 6)
         np.testing.assert_array_equal(t[:, seqs], cpu_port_scores(oracle, a, m, ad, c["ls"], c["res"], c["off"], seqs, sm, 10, 2))
         parts.append((sc, multigpu.global_index(ix, c["s0"])))
+        for pos, qi in planted_at:
+            if c["s0"] <= pos < c["s0"] + c["nseq"]:
+                planted_score[(qi, pos)] = int(t[qi, pos - c["s0"]])
         whole = (t[:, :c["nseq"]], c["s0"])
         # running global top-10 from the full tables, the slow way
         for q in range(len(qs)):
@@ -200,6 +227,9 @@ def test_c4_database_on_one_gpu_chunked(hip_ctx, oracle):
     for q in range(len(qs)):
         np.testing.assert_array_equal(gs[q], best[q][0])
         np.testing.assert_array_equal(gi[q], best[q][1])
+    # "top-10 score bit-exact" at the headline size, against the oracle: the 200 listed pairs and the 240 planted homologs
+    assert len(planted_score) == len(qs) * 12
+    pin_to_oracle(toppin, oracle, plan, shard.order, qs, sm, 10, 2, gs, gi, lambda q, p: planted_score[(q, p)])
     # the planted 5 % copies are on top, and their sorted positions hold sequences of about the query's length
     assert (gs[:, 0] > 300).all()
     assert (np.abs(shard.sorted_lengths[gi[:, 0]] - m.astype(np.int64)) <= 5).all()
