@@ -19,6 +19,7 @@
 #include <functional>
 #include <memory>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,21 @@ int fail(int code, const char *fmt, ...)
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// What stands between the implementations and the C ABI (see the exported entry points at the end of the file).
+template <class F>
+int guarded(const char *entry, F &&body) noexcept
+{
+    auto report = [entry](int code, const char *what) noexcept {
+        try { return fail(code, "%s: %s", entry, what); }
+        catch (...) { return code; } // (the message itself could not be stored: the code still says what happened)
+    };
+    try { return body(); }
+    catch (const std::bad_alloc &) { return report(OSWALD_HIP_ENOMEM, "out of host memory (std::bad_alloc)"); }
+    catch (const std::length_error &e) { return report(OSWALD_HIP_ENOMEM, e.what()); }
+    catch (const std::exception &e) { return report(OSWALD_HIP_ERUNTIME, e.what()); }
+    catch (...) { return report(OSWALD_HIP_ERUNTIME, "unknown exception"); }
 }
 
 #define HIP_TRY(expr)                                                                                         \
@@ -82,6 +98,7 @@ struct Tunables {
     void refresh();
 };
 bool g_debug_slow = false; // OSWALD_HIP_DEBUG_SLOW=1: report allocations / pinning that take > 5 ms
+size_t g_fail_alloc_above = 0; // OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE=bytes (test hook): a device allocation of more than that fails like a device that is full
 
 void Tunables::refresh()
 {
@@ -107,6 +124,7 @@ void Tunables::refresh()
     tail_items_per_wave = num("OSWALD_HIP_TAIL_ITEMS", 2.5);
     tail_lg = (int)num("OSWALD_HIP_TAIL_LG", -1);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
+    g_fail_alloc_above = (size_t)num("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE", 0);
 #ifdef OSW_DIAG
     pair_margin = num("OSWALD_HIP_PAIR_MARGIN", pair_margin);
     col_cost = num("OSWALD_HIP_COL_COST", col_cost);
@@ -170,7 +188,7 @@ struct DevBuf {
         if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) { (void)hipGetLastError(); return e; } p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
         const auto t0 = std::chrono::steady_clock::now();
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = g_fail_alloc_above && want > g_fail_alloc_above ? hipErrorOutOfMemory : hipMalloc(&p, want);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (ms > 5.0 && g_debug_slow) fprintf(stderr, "[oswald_hip] slow hipMalloc: %zu bytes took %.1f ms\n", want, ms);
         if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return e; }
@@ -642,6 +660,7 @@ int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c)
 void merge_candidates(uint32_t nq, size_t K, const int32_t *cs, const uint32_t *ci, uint32_t r, int32_t *out_s, uint32_t *out_i)
 {
     std::vector<uint64_t> keys;
+    keys.reserve(K); // (one allocation; a K no memory can hold is std::length_error / std::bad_alloc here, before anything is read)
     for (uint32_t q = 0; q < nq; ++q) {
         keys.clear();
         for (size_t k = 0; k < K; ++k)
@@ -664,7 +683,7 @@ int oswald_hip_abi_version(void) { return OSWALD_HIP_ABI_VERSION; }
 const char *oswald_hip_last_error(void) { return g_err.c_str(); }
 
 // Page-locked host memory for the caller's chunk buffers and score tables.
-int oswald_hip_host_alloc(size_t bytes, void **ptr)
+static int host_alloc_impl(size_t bytes, void **ptr)
 {
     if (!ptr) return fail(OSWALD_HIP_EINVAL, "null out-pointer");
     *ptr = nullptr;
@@ -673,14 +692,14 @@ int oswald_hip_host_alloc(size_t bytes, void **ptr)
     return 0;
 }
 
-int oswald_hip_host_free(void *ptr)
+static int host_free_impl(void *ptr)
 {
     if (ptr) HIP_TRY(hipHostFree(ptr));
     return 0;
 }
 
 // Page-locks memory the caller already has (a mapped or loaded database): uploads from it are asynchronous DMA.
-int oswald_hip_host_register(void *ptr, size_t bytes)
+static int host_register_impl(void *ptr, size_t bytes)
 {
     if (!ptr || bytes == 0) return fail(OSWALD_HIP_EINVAL, "nothing to register");
     const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
@@ -692,7 +711,7 @@ int oswald_hip_host_register(void *ptr, size_t bytes)
     return 0;
 }
 
-int oswald_hip_host_unregister(void *ptr)
+static int host_unregister_impl(void *ptr)
 {
     if (!ptr) return 0;
     const hipError_t e = hipHostUnregister(ptr);
@@ -700,7 +719,7 @@ int oswald_hip_host_unregister(void *ptr)
     return 0;
 }
 
-int oswald_hip_device_count(int *count)
+static int device_count_impl(int *count)
 {
     if (!count) return fail(OSWALD_HIP_EINVAL, "count is null");
     int n = 0;
@@ -710,7 +729,7 @@ int oswald_hip_device_count(int *count)
     return 0;
 }
 
-int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
+static int init_impl(int ndev, const int *device_ids, oswald_hip_ctx **out)
 {
     if (!out) return fail(OSWALD_HIP_EINVAL, "ctx out-pointer is null");
     *out = nullptr;
@@ -816,7 +835,7 @@ int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
     return 0;
 }
 
-int oswald_hip_finalize(oswald_hip_ctx *ctx)
+static int finalize_impl(oswald_hip_ctx *ctx)
 {
     if (!ctx) return 0;
     for (Device &d : ctx->dev) {
@@ -868,7 +887,7 @@ int oswald_hip_finalize(oswald_hip_ctx *ctx)
     return 0;
 }
 
-int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen)
+static int info_impl(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen)
 {
     if (int r = check_dev(ctx, dev)) return r;
     if (!buf || buflen == 0) return fail(OSWALD_HIP_EINVAL, "buffer is null");
@@ -891,7 +910,7 @@ int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen)
     return 0;
 }
 
-int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_gap, int extend_gap, int cell_bits)
+static int set_scoring_impl(oswald_hip_ctx *ctx, const int8_t *submat, int open_gap, int extend_gap, int cell_bits)
 {
     if (!ctx || !submat) return fail(OSWALD_HIP_EINVAL, "null argument");
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
@@ -919,7 +938,7 @@ int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_g
     return 0;
 }
 
-int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, const uint16_t *m, const uint32_t *a_disp, uint32_t nq)
+static int set_queries_impl(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, const uint16_t *m, const uint32_t *a_disp, uint32_t nq)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (nq > 0 && (!m || !a_disp || (Q > 0 && !a))) return fail(OSWALD_HIP_EINVAL, "null query arrays");
@@ -1114,8 +1133,8 @@ static bool device_is_idle(Device &d)
     return true;
 }
 
-static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
-                             uint32_t ngroups, uint32_t W, int *chunk, bool async)
+static int upload_pieces(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
+                         uint32_t ngroups, uint32_t W, int *chunk, bool async)
 {
     if (int r = check_dev(ctx, dev)) return r;
     if (!chunk) return fail(OSWALD_HIP_EINVAL, "chunk out-pointer is null");
@@ -1178,19 +1197,19 @@ static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uin
     return 0;
 }
 
-int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
+static int chunk_upload_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
                             uint32_t ngroups, uint32_t W, int *chunk)
 {
-    return chunk_upload_impl(ctx, dev, b, vD, n, disp, ngroups, W, chunk, false);
+    return upload_pieces(ctx, dev, b, vD, n, disp, ngroups, W, chunk, false);
 }
 
-int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
+static int chunk_upload_async_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp,
                                   uint32_t ngroups, uint32_t W, int *chunk)
 {
-    return chunk_upload_impl(ctx, dev, b, vD, n, disp, ngroups, W, chunk, true);
+    return upload_pieces(ctx, dev, b, vD, n, disp, ngroups, W, chunk, true);
 }
 
-int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length)
+static int reserve_impl(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (dev >= (int)ctx->dev.size()) return fail(OSWALD_HIP_ENODEV, "device index %d out of range", dev);
@@ -1208,7 +1227,7 @@ int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_lengt
 // caller's clock starts -- instead of by the first uploads and searches: mapping a few hundred MB of device memory takes
 // milliseconds (20 ms per GB on the round-5 box: 9 ms of a 27-ms one-query search at 1 M sequences went into the first
 // upload's allocations).  A hint: a chunk that needs more grows its slot as before.
-int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
+static int reserve_chunks_impl(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (dev >= (int)ctx->dev.size()) return fail(OSWALD_HIP_ENODEV, "device index %d out of range", dev);
@@ -1293,7 +1312,7 @@ int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes
 // re-tiled residues (a 128-sequence block is padded to its longest group: <= 1.25), the all-dummy columns behind every
 // block (18 x 512 B per block of >= 128 x 28 B: 2.6), and per sequence -- at most one per 28 bytes, the shortest
 // padded group length -- 4 B of score, 8 B of int32 re-run queue and 8 B of int16 re-run queue per query.
-int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_t max_sequence_length, uint64_t *bytes)
+static int max_chunk_size_impl(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_t max_sequence_length, uint64_t *bytes)
 {
     if (int r = check_dev(ctx, dev)) return r;
     if (!bytes) return fail(OSWALD_HIP_EINVAL, "null output");
@@ -1592,7 +1611,7 @@ static int check_chunk(oswald_hip_ctx *ctx, int dev, int chunk)
     return 0;
 }
 
-int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out)
+static int chunk_search_impl(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out)
 {
     if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
@@ -1643,7 +1662,7 @@ int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *sc
     return 0;
 }
 
-int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
+static int chunk_release_impl(oswald_hip_ctx *ctx, int dev, int chunk)
 {
     if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
@@ -1666,7 +1685,7 @@ int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
 // (oswald_hip_wait, or a later upload's completion on the same in-order stream) -- a following upload into it waits for this
 // search on the device.  With several devices the calls for device d+1 are made while device d's chunk is still on the link:
 // the reference's four clEnqueueWriteBuffer per device are non-blocking too (FPGAsearch.c:180-198).
-int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
+static int search_chunk_async_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                                   const uint32_t *disp, uint32_t ngroups, uint32_t W, int32_t *scores_out)
 {
     int h = -1;
@@ -1683,7 +1702,7 @@ int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b
     return r;
 }
 
-int oswald_hip_chunk_wait(oswald_hip_ctx *ctx, int dev, int chunk)
+static int chunk_wait_impl(oswald_hip_ctx *ctx, int dev, int chunk)
 {
     if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
@@ -1697,7 +1716,7 @@ int oswald_hip_chunk_wait(oswald_hip_ctx *ctx, int dev, int chunk)
     return 0;
 }
 
-int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
+static int wait_impl(oswald_hip_ctx *ctx, int dev)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (dev >= (int)ctx->dev.size()) return fail(OSWALD_HIP_ENODEV, "device index %d out of range", dev);
@@ -1714,7 +1733,7 @@ int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
     return 0;
 }
 
-int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nvalid, uint32_t r, int32_t *scores, uint32_t *index)
+static int chunk_topr_impl(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nvalid, uint32_t r, int32_t *scores, uint32_t *index)
 {
     if (int rc = check_dev(ctx, dev)) return rc;
     Device &d = ctx->dev[dev];
@@ -1798,7 +1817,7 @@ static int set_index_slot(Device &d, Chunk &c, uint32_t first_index, uint32_t nv
     return 0;
 }
 
-int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t first_index, uint32_t nvalid, const uint32_t *index_map)
+static int chunk_set_index_impl(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t first_index, uint32_t nvalid, const uint32_t *index_map)
 {
     if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
@@ -1817,7 +1836,7 @@ int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t
     return 0;
 }
 
-int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r)
+static int topr_begin_impl(oswald_hip_ctx *ctx, uint32_t r)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (r > 1024) return fail(OSWALD_HIP_EINVAL, "top-r on the device supports r <= 1024 (asked for %u): download the score table instead", r);
@@ -1849,7 +1868,7 @@ int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r)
 // between the processes and folded again, so every rank ends up with the list of the whole job.  Then ONE copy of
 // nq x r (score, index) pairs to the host.  Every fold is osw_topr_fold on tagged keys: descending score, equal
 // scores by descending database index (utils.c:3-86).
-int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *db_index)
+static int topr_impl(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *db_index)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (r == 0 || ctx->nq == 0) return 0;
@@ -1928,7 +1947,7 @@ int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *
     return 0;
 }
 
-int oswald_hip_comm_unique_id(void *id, size_t id_bytes)
+static int comm_unique_id_impl(void *id, size_t id_bytes)
 {
     if (!id || id_bytes < sizeof(ncclUniqueId)) return fail(OSWALD_HIP_EINVAL, "the id buffer must hold %zu bytes", sizeof(ncclUniqueId));
     ncclUniqueId u;
@@ -1938,7 +1957,7 @@ int oswald_hip_comm_unique_id(void *id, size_t id_bytes)
     return 0;
 }
 
-int oswald_hip_comm_init_rank(oswald_hip_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank)
+static int comm_init_rank_impl(oswald_hip_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank)
 {
     if (!ctx || !id) return fail(OSWALD_HIP_EINVAL, "null argument");
     if (id_bytes < sizeof(ncclUniqueId)) return fail(OSWALD_HIP_EINVAL, "the id must be the %zu bytes oswald_hip_comm_unique_id wrote", sizeof(ncclUniqueId));
@@ -1962,7 +1981,7 @@ int oswald_hip_comm_init_rank(oswald_hip_ctx *ctx, const void *id, size_t id_byt
     return 0;
 }
 
-int oswald_hip_comm_destroy(oswald_hip_ctx *ctx)
+static int comm_destroy_impl(oswald_hip_ctx *ctx)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (!ctx->pcomm) return 0;
@@ -1976,7 +1995,7 @@ int oswald_hip_comm_destroy(oswald_hip_ctx *ctx)
     return 0;
 }
 
-int oswald_hip_comm_info(oswald_hip_ctx *ctx, int *out4)
+static int comm_info_impl(oswald_hip_ctx *ctx, int *out4)
 {
     if (!ctx || !out4) return fail(OSWALD_HIP_EINVAL, "null argument");
     int version = 0;
@@ -1997,7 +2016,7 @@ int oswald_hip_comm_info(oswald_hip_ctx *ctx, int *out4)
     return 0;
 }
 
-int oswald_hip_merge_candidates(uint32_t nq, uint64_t ncand, const int32_t *cand_scores, const uint32_t *cand_index, uint32_t r,
+static int merge_candidates_impl(uint32_t nq, uint64_t ncand, const int32_t *cand_scores, const uint32_t *cand_index, uint32_t r,
                                 int32_t *scores, uint32_t *db_index)
 {
     if (nq == 0 || r == 0) return 0;
@@ -2006,14 +2025,14 @@ int oswald_hip_merge_candidates(uint32_t nq, uint64_t ncand, const int32_t *cand
     return 0;
 }
 
-int oswald_hip_set_profiling(oswald_hip_ctx *ctx, int enable)
+static int set_profiling_impl(oswald_hip_ctx *ctx, int enable)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     ctx->profiling = enable != 0;
     return 0;
 }
 
-int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, uint64_t *dp_launches, uint64_t *rerun_items, int reset)
+static int kernel_stats_impl(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, uint64_t *dp_launches, uint64_t *rerun_items, int reset)
 {
     if (int r = check_dev(ctx, dev)) return r;
     Device &d = ctx->dev[dev];
@@ -2029,7 +2048,7 @@ int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, 
     return 0;
 }
 
-int oswald_hip_rerun_stats(oswald_hip_ctx *ctx, int dev, double *ms2)
+static int rerun_stats_impl(oswald_hip_ctx *ctx, int dev, double *ms2)
 {
     if (int r = check_dev(ctx, dev)) return r;
     if (!ms2) return fail(OSWALD_HIP_EINVAL, "null output");
@@ -2042,7 +2061,7 @@ int oswald_hip_rerun_stats(oswald_hip_ctx *ctx, int dev, double *ms2)
     return 0;
 }
 
-int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2)
+static int rerun_counts_impl(oswald_hip_ctx *ctx, int dev, uint64_t *out2)
 {
     if (int r = check_dev(ctx, dev)) return r;
     if (!out2) return fail(OSWALD_HIP_EINVAL, "null output");
@@ -2056,7 +2075,7 @@ int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2)
     return 0;
 }
 
-int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out8)
+static int chunk_geometry_impl(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out8)
 {
     if (int r = check_chunk(ctx, dev, chunk)) return r;
     Device &d = ctx->dev[dev];
@@ -2080,6 +2099,184 @@ int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t 
         out8[6] += c.planned_spill_bytes;
     }
     return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The exported entry points.  No exception crosses the C ABI: the implementations above use the standard containers (work
+// queues, block tables, host copies of the query set), whose allocations throw; an exception that left an extern "C"
+// function would be std::terminate -- a dead caller where include/oswald_hip.h promises an error code.
+// Every entry is its implementation inside guarded(): std::bad_alloc / std::length_error -> OSWALD_HIP_ENOMEM, anything
+// else -> OSWALD_HIP_ERUNTIME, with the entry's name and what() in oswald_hip_last_error().
+// ---------------------------------------------------------------------------------------------------------------
+int oswald_hip_host_alloc(size_t bytes, void **ptr)
+{
+    return guarded("oswald_hip_host_alloc", [&] { return host_alloc_impl(bytes, ptr); });
+}
+
+int oswald_hip_host_free(void *ptr)
+{
+    return guarded("oswald_hip_host_free", [&] { return host_free_impl(ptr); });
+}
+
+int oswald_hip_host_register(void *ptr, size_t bytes)
+{
+    return guarded("oswald_hip_host_register", [&] { return host_register_impl(ptr, bytes); });
+}
+
+int oswald_hip_host_unregister(void *ptr)
+{
+    return guarded("oswald_hip_host_unregister", [&] { return host_unregister_impl(ptr); });
+}
+
+int oswald_hip_device_count(int *count)
+{
+    return guarded("oswald_hip_device_count", [&] { return device_count_impl(count); });
+}
+
+int oswald_hip_init(int ndev, const int *device_ids, oswald_hip_ctx **out)
+{
+    return guarded("oswald_hip_init", [&] { return init_impl(ndev, device_ids, out); });
+}
+
+int oswald_hip_finalize(oswald_hip_ctx *ctx)
+{
+    return guarded("oswald_hip_finalize", [&] { return finalize_impl(ctx); });
+}
+
+int oswald_hip_info(oswald_hip_ctx *ctx, int dev, char *buf, size_t buflen)
+{
+    return guarded("oswald_hip_info", [&] { return info_impl(ctx, dev, buf, buflen); });
+}
+
+int oswald_hip_set_scoring(oswald_hip_ctx *ctx, const int8_t *submat, int open_gap, int extend_gap, int cell_bits)
+{
+    return guarded("oswald_hip_set_scoring", [&] { return set_scoring_impl(ctx, submat, open_gap, extend_gap, cell_bits); });
+}
+
+int oswald_hip_set_queries(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, const uint16_t *m, const uint32_t *a_disp, uint32_t nq)
+{
+    return guarded("oswald_hip_set_queries", [&] { return set_queries_impl(ctx, a, Q, m, a_disp, nq); });
+}
+
+int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W, int *chunk)
+{
+    return guarded("oswald_hip_chunk_upload", [&] { return chunk_upload_impl(ctx, dev, b, vD, n, disp, ngroups, W, chunk); });
+}
+
+int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W, int *chunk)
+{
+    return guarded("oswald_hip_chunk_upload_async", [&] { return chunk_upload_async_impl(ctx, dev, b, vD, n, disp, ngroups, W, chunk); });
+}
+
+int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length)
+{
+    return guarded("oswald_hip_reserve", [&] { return reserve_impl(ctx, dev, max_sequence_length); });
+}
+
+int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
+{
+    return guarded("oswald_hip_reserve_chunks", [&] { return reserve_chunks_impl(ctx, dev, chunk_bytes, ngroups, W, nq, slots); });
+}
+
+int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_t max_sequence_length, uint64_t *bytes)
+{
+    return guarded("oswald_hip_max_chunk_size", [&] { return max_chunk_size_impl(ctx, dev, nq, max_sequence_length, bytes); });
+}
+
+int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out)
+{
+    return guarded("oswald_hip_chunk_search", [&] { return chunk_search_impl(ctx, dev, chunk, scores_out); });
+}
+
+int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
+{
+    return guarded("oswald_hip_chunk_release", [&] { return chunk_release_impl(ctx, dev, chunk); });
+}
+
+int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W, int32_t *scores_out)
+{
+    return guarded("oswald_hip_search_chunk_async", [&] { return search_chunk_async_impl(ctx, dev, b, vD, n, disp, ngroups, W, scores_out); });
+}
+
+int oswald_hip_chunk_wait(oswald_hip_ctx *ctx, int dev, int chunk)
+{
+    return guarded("oswald_hip_chunk_wait", [&] { return chunk_wait_impl(ctx, dev, chunk); });
+}
+
+int oswald_hip_wait(oswald_hip_ctx *ctx, int dev)
+{
+    return guarded("oswald_hip_wait", [&] { return wait_impl(ctx, dev); });
+}
+
+int oswald_hip_chunk_topr(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t nvalid, uint32_t r, int32_t *scores, uint32_t *index)
+{
+    return guarded("oswald_hip_chunk_topr", [&] { return chunk_topr_impl(ctx, dev, chunk, nvalid, r, scores, index); });
+}
+
+int oswald_hip_chunk_set_index(oswald_hip_ctx *ctx, int dev, int chunk, uint32_t first_index, uint32_t nvalid, const uint32_t *index_map)
+{
+    return guarded("oswald_hip_chunk_set_index", [&] { return chunk_set_index_impl(ctx, dev, chunk, first_index, nvalid, index_map); });
+}
+
+int oswald_hip_topr_begin(oswald_hip_ctx *ctx, uint32_t r)
+{
+    return guarded("oswald_hip_topr_begin", [&] { return topr_begin_impl(ctx, r); });
+}
+
+int oswald_hip_topr(oswald_hip_ctx *ctx, uint32_t r, int32_t *scores, uint32_t *db_index)
+{
+    return guarded("oswald_hip_topr", [&] { return topr_impl(ctx, r, scores, db_index); });
+}
+
+int oswald_hip_comm_unique_id(void *id, size_t id_bytes)
+{
+    return guarded("oswald_hip_comm_unique_id", [&] { return comm_unique_id_impl(id, id_bytes); });
+}
+
+int oswald_hip_comm_init_rank(oswald_hip_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank)
+{
+    return guarded("oswald_hip_comm_init_rank", [&] { return comm_init_rank_impl(ctx, id, id_bytes, nranks, rank); });
+}
+
+int oswald_hip_comm_destroy(oswald_hip_ctx *ctx)
+{
+    return guarded("oswald_hip_comm_destroy", [&] { return comm_destroy_impl(ctx); });
+}
+
+int oswald_hip_comm_info(oswald_hip_ctx *ctx, int *out4)
+{
+    return guarded("oswald_hip_comm_info", [&] { return comm_info_impl(ctx, out4); });
+}
+
+int oswald_hip_merge_candidates(uint32_t nq, uint64_t ncand, const int32_t *cand_scores, const uint32_t *cand_index, uint32_t r, int32_t *scores, uint32_t *db_index)
+{
+    return guarded("oswald_hip_merge_candidates", [&] { return merge_candidates_impl(nq, ncand, cand_scores, cand_index, r, scores, db_index); });
+}
+
+int oswald_hip_set_profiling(oswald_hip_ctx *ctx, int enable)
+{
+    return guarded("oswald_hip_set_profiling", [&] { return set_profiling_impl(ctx, enable); });
+}
+
+int oswald_hip_kernel_stats(oswald_hip_ctx *ctx, int dev, double *dp_kernel_ms, uint64_t *dp_launches, uint64_t *rerun_items, int reset)
+{
+    return guarded("oswald_hip_kernel_stats", [&] { return kernel_stats_impl(ctx, dev, dp_kernel_ms, dp_launches, rerun_items, reset); });
+}
+
+int oswald_hip_rerun_stats(oswald_hip_ctx *ctx, int dev, double *ms2)
+{
+    return guarded("oswald_hip_rerun_stats", [&] { return rerun_stats_impl(ctx, dev, ms2); });
+}
+
+int oswald_hip_rerun_counts(oswald_hip_ctx *ctx, int dev, uint64_t *out2)
+{
+    return guarded("oswald_hip_rerun_counts", [&] { return rerun_counts_impl(ctx, dev, out2); });
+}
+
+int oswald_hip_chunk_geometry(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t *out8)
+{
+    return guarded("oswald_hip_chunk_geometry", [&] { return chunk_geometry_impl(ctx, dev, chunk, out8); });
 }
 
 } // extern "C"

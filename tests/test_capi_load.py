@@ -83,3 +83,34 @@ def test_merge_candidates_is_the_reference_order():
         np.testing.assert_array_equal(got_s, want_s)
         np.testing.assert_array_equal(np.where(got_s < 0, -1, got_i.astype(np.int64)), want_i)
         assert ((got_i == 0xFFFFFFFF) == (got_s < 0)).all()
+
+
+def test_no_exception_crosses_the_c_abi():
+    """VERDICT r05 item 2: an allocation that throws inside the library (std::length_error / std::bad_alloc from a standard
+    container) comes back as OSWALD_HIP_ENOMEM with the entry's name in oswald_hip_last_error() -- it used to be
+    std::terminate, i.e. a dead caller.  oswald_hip_merge_candidates is host logic and reserves room for its candidates
+    before it reads any: a candidate count no memory can hold fails there, in this process, and the process lives on."""
+    import numpy as np
+    lib = capi.load()
+    cs = np.zeros(16, np.int32)
+    ci = np.zeros(16, np.uint32)
+    out_s = np.zeros(10, np.int32)
+    out_i = np.zeros(10, np.uint32)
+    for ncand in (1 << 61, (1 << 64) - 1):
+        rc = lib.oswald_hip_merge_candidates(1, ctypes.c_uint64(ncand), cs.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), 10,
+                                             out_s.ctypes.data_as(ctypes.c_void_p), out_i.ctypes.data_as(ctypes.c_void_p))
+        assert rc == -4, rc                                             # OSWALD_HIP_ENOMEM
+        assert "oswald_hip_merge_candidates" in lib.oswald_hip_last_error().decode()
+    # ... and the library still works
+    got_s, got_i = capi.merge_candidates(np.array([[5, 7, 7]], np.int32), np.array([[1, 2, 3]], np.uint32), 2)
+    assert got_s.tolist() == [[7, 7]] and got_i.tolist() == [[3, 2]]
+
+
+def test_every_exported_entry_is_guarded():
+    """Every extern "C" entry of oswald_hip.cpp that can fail is its implementation inside guarded() (the catch-all)."""
+    src = open(os.path.join(ROOT, "oswald_amd", "csrc", "oswald_hip.cpp")).read()
+    exported = re.findall(r"^int (oswald_hip_\w+)\(", src, flags=re.M)
+    guarded = re.findall(r'return guarded\("(oswald_hip_\w+)"', src)
+    assert sorted(exported) == sorted(set(guarded) | {"oswald_hip_abi_version"})
+    assert set(capi.SYMBOLS) == set(exported) | {"oswald_hip_last_error"}
+    assert "noexcept" in src[src.index("int guarded("):src.index("int guarded(") + 80]

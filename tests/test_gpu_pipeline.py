@@ -326,3 +326,77 @@ def test_one_call_search_is_asynchronous(oracle):
         assert best[0] < 0.5 * best[1], f"the two calls held the host {best[0] * 1e3:.2f} ms of the {best[1] * 1e3:.2f} ms until both devices were through"
         for x in hb + outs:
             x.close()
+
+
+def test_one_call_search_keeps_a_converted_residue_buffer_alive(oracle):
+    """oswald_hip_search_chunk_async reads `b` by DMA until the next wait.  The Python binding converts what it is
+    given (np.ascontiguousarray): a caller's int16 or strided array becomes a temporary, which must live until wait() --
+    as must the caller's own array when the caller drops it right after the call.  Several such calls in a row, each with
+    its buffer dropped and the heap churned before the wait, must still give the oracle's scores."""
+    import gc
+    from oswald_amd import capi
+    qs = synth.make_queries([60, 133], seed=41)
+    L, R, O = random_db(1500, seed=42, min_len=30, max_len=300, queries=qs, homologs=2)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    b, n, disp = dblayout.interleave(sl, sr, so, 16)
+    disp = disp.astype(np.uint32)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        outs = []
+        for form in ("int16", "strided", "dropped"):
+            out = np.full((len(qs), len(n) * 16), -3, np.int32)
+            if form == "int16":
+                src = b.astype(np.int16)                       # a dtype conversion inside the binding
+            elif form == "strided":
+                src = np.repeat(b, 2)[::2]                     # not contiguous: a copy inside the binding
+                assert not src.flags.c_contiguous
+            else:
+                src = b.copy()                                 # the caller's own array, dropped before the wait
+            ctx.search_chunk_async(src, n, disp, out, 16)
+            del src
+            gc.collect()
+            junk = [np.full(b.size, 0xEE, np.uint8) for _ in range(3)]   # whatever was freed is written over
+            del junk
+            outs.append(out)
+        ctx.wait()
+        for out in outs:
+            np.testing.assert_array_equal(out[:, :want.shape[1]], want[:, :out.shape[1]])
+
+
+def test_failures_come_back_as_error_codes_and_the_context_lives_on(oracle, monkeypatch):
+    """(a) a device allocation that fails (OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE: a device that is full -- here the
+    spill scratch the first upload needs) is OSWALD_HIP_ENOMEM, not a dead process, and the same context searches correctly once
+    memory is there; (b) a host allocation that THROWS inside the library (a query buffer no memory can hold: std::length_error
+    out of std::vector) comes back through the C ABI as OSWALD_HIP_ENOMEM too (every entry is guarded)."""
+    import ctypes
+    from oswald_amd import capi
+    qs = synth.make_queries([80, 150, 222], seed=5)
+    L, R, O = random_db(700, seed=6, min_len=30, max_len=260, queries=qs, homologs=2)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    b, n, disp = dblayout.interleave(sl, sr, so, 16)
+    disp = disp.astype(np.uint32)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    monkeypatch.setenv("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE", str(256 << 20))
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        with pytest.raises(capi.OswaldHipError, match="error -4"):
+            ctx.chunk_upload(b, n, disp, 16)                  # the spill scratch (> 1 GB) cannot be made
+        monkeypatch.delenv("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE")
+        ctx.set_scoring(sm, 10, 2)                            # (hooks are read when a context is configured)
+        # (b): Q = 2^62 bytes of queries, no query: nothing is read, the copy of the buffer cannot be allocated
+        rc = ctx.lib.oswald_hip_set_queries(ctx.h, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(1 << 62), None, None, 0)
+        assert rc == -4 and "oswald_hip_set_queries" in ctx.lib.oswald_hip_last_error().decode()
+        ctx.set_queries(a, m, ad)
+        out = np.full((len(qs), len(n) * 16), -3, np.int32)
+        h = ctx.chunk_upload(b, n, disp, 16)
+        ctx.chunk_search(h, out)
+        ctx.wait()
+        ctx.chunk_release(h)
+        np.testing.assert_array_equal(out[:, :want.shape[1]], want[:, :out.shape[1]])
