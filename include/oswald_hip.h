@@ -49,7 +49,7 @@ extern "C" {
 #define OSWALD_HIP_ESTATE (-5)   /* call sequence violated (e.g. search before set_queries) */
 #define OSWALD_HIP_ECOMM (-6)    /* an RCCL call failed (multi-GPU top-r gather) */
 
-#define OSWALD_HIP_ABI_VERSION 4
+#define OSWALD_HIP_ABI_VERSION 5
 
 typedef struct oswald_hip_ctx oswald_hip_ctx;
 
@@ -146,22 +146,24 @@ int oswald_hip_chunk_upload(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint
 int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n,
                                   const uint32_t *disp, uint32_t ngroups, uint32_t lane_width, int *chunk);
 
-/* Optional: allocate the device-side work space (per-wave spill scratch of the long-query rounds) for databases
- * whose longest sequence has max_sequence_length residues, on device dev (dev < 0: all).  Without it the first
- * upload allocates what its chunk needs.  Stands where the reference sizes its device buffers for the largest
- * chunk before the timed region starts (FPGAsearch.c:85-96). */
+/* The device's own working memory (the per-wave spill scratch of the long-query rounds) is made by oswald_hip_init since ABI
+ * version 5 -- it belongs to the kernels, not to a search: see there.  This call remains for callers of earlier versions: it makes
+ * sure the scratch holds blocks of max_sequence_length residues (it does) and returns. */
 int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length);
 
-/* Optional, in the same place: the device buffers of `slots` chunk slots (staging copy, re-tiled residues, block tables,
- * and -- with nq > 0 -- score table, re-run queue and work queues for a set of nq queries) for chunks of up to chunk_bytes
- * bytes in ngroups groups of lane_width sequences, on device dev (dev < 0: all), allocated NOW instead of by the first
- * uploads and searches: mapping device memory costs ~20 ms per GB, which a short search would otherwise pay inside its
- * timed region.  With nq > 0 this includes the hand-over planes of the tails a query set of nq queries would get on chunks of
- * that size (DESIGN 4 "Tails": up to 16 GB per device; OSWALD_HIP_PAIR_TAILS=0 in the environment: none).  A hint only: a
- * chunk that needs more grows its slot as before.  The reference creates its six device
- * buffers, sized for the largest chunk, once per search and re-uses them for every chunk (FPGAsearch.c:85-96). */
+/* Optional: the device buffers of `slots` chunk slots (staging copy, re-tiled residues, block tables, and -- with nq > 0 --
+ * score table, re-run queue and work queues for a set of nq queries) for chunks of up to chunk_bytes bytes in ngroups groups of
+ * lane_width sequences, on device dev (dev < 0: all), allocated in ONE place instead of by the first uploads and searches as
+ * they come.  This is the reference's buffer creation -- its six device buffers, sized for the largest chunk, created once per
+ * search INSIDE its timed region and re-used for every chunk (FPGAsearch.c:80, :85-96) -- and a caller that mirrors the
+ * reference's clock calls it inside its own (the command-line tool and bench.py's `inclusive` leg do).  A hint only: a chunk that
+ * needs more grows its slot as before. */
 int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t lane_width,
                               uint32_t nq, uint32_t slots);
+
+/* ... and the reverse: the buffers of every chunk slot of device dev (dev < 0: all) that holds no chunk are given back (the
+ * reference releases its buffers at the end of a search, FPGAsearch.c:361-368).  Waits for the device. */
+int oswald_hip_release_chunks(oswald_hip_ctx *ctx, int dev);
 
 /* The largest chunk -- in bytes of b, i.e. padded residues, the unit of the command line's -k -- device dev can hold for
  * a set of nq queries and sequences of up to max_sequence_length residues: 0.8 of its free memory (less the work

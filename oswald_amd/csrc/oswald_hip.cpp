@@ -85,9 +85,7 @@ struct Tunables {
     bool no_pin = false;               // OSWALD_HIP_NO_PIN=1: do not pin the caller's score table for the download
     bool no_direct_table = false;      // OSWALD_HIP_NO_DIRECT_TABLE=1 (A/B and test hook): score tables leave by DMA on the download stream even when the kernels could write them
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
-    int pair_tails = 16;               // OSWALD_HIP_PAIR_TAILS=n: query sets of up to n pairs may run the rows a pair's longer query has beyond the shorter one's as tail items (0: always pad the shorter query, rounds 1-5)
-    int tail_lg = -1;                  // OSWALD_HIP_TAIL_LG=k: tail items of geometry 2^k (test hook; -1: whole blocks on large chunks, quarters on medium ones)
-    double tail_items_per_wave = 2.5;  // OSWALD_HIP_TAIL_ITEMS=x: ... on chunks with at least x (pair, block) tails per wave of the grid (smaller chunks: the extra launch costs more than the padding)
+    int pair_tails = 1;                // OSWALD_HIP_PAIR_TAILS=0|1|2: the rows a pair's longer query has beyond the shorter one's are padded (0: rounds 1-4) / run as the pair item's TAIL on the single-query cell where the cost model says so (1) / always (2: test hook)
     double warm_ms = 0.0;              // OSWALD_HIP_WARM_MS=ms: oswald_hip_reserve_chunks ends with every CU of the device busy for that long (experiment: clock ramp before a first search)
     size_t split_bytes = 32u << 20;    // OSWALD_HIP_SPLIT_BYTES=bytes: from this size on an asynchronous upload that finds its device idle is cut into head + rest (0: never; a small value: test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
@@ -120,9 +118,7 @@ void Tunables::refresh()
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     split_bytes = (size_t)num("OSWALD_HIP_SPLIT_BYTES", (double)(32u << 20));
     warm_ms = num("OSWALD_HIP_WARM_MS", 0.0);
-    pair_tails = (int)num("OSWALD_HIP_PAIR_TAILS", 16);
-    tail_items_per_wave = num("OSWALD_HIP_TAIL_ITEMS", 2.5);
-    tail_lg = (int)num("OSWALD_HIP_TAIL_LG", -1);
+    pair_tails = (int)num("OSWALD_HIP_PAIR_TAILS", 1);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
     g_fail_alloc_above = (size_t)num("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE", 0);
 #ifdef OSW_DIAG
@@ -251,7 +247,6 @@ struct Chunk {
     uint2 *items_pin[2] = {nullptr, nullptr};
     size_t items_pin_cap[2] = {0, 0};   // entries (both queues, one behind the other)
     size_t items_q_off[2] = {0, 0};     // where the query-pair kernel's queue starts in the set
-    size_t items_t_off[2] = {0, 0};     // ... and the tail items' (single-query kernel, a launch of its own behind the pairs')
     int items_cur = 0;
     // ... and who read a set last: recorded on the search stream behind the launches that pull from it.  A plan that is about to
     // overwrite a set waits for its last reader on the host (with one plan per residency that reader is long gone, but
@@ -262,7 +257,6 @@ struct Chunk {
     bool set_read_pending[2] = {false, false};
     const uint2 *items_ptr() const { return items_pin[items_cur]; }
     const uint2 *items_q_ptr() const { return items_pin[items_cur] + items_q_off[items_cur]; }
-    const uint2 *items_t_ptr() const { return items_pin[items_cur] + items_t_off[items_cur]; }
     const uint16_t *sub_cols_dev() const { return (const uint16_t *)sub_cols_buf.p; }
     std::vector<uint32_t> ncols4_alloc; // host copy, per block
     // host copy of the live extents (see osw_retile16 / osw_block_extent), for the planner: PAGE-LOCKED, so that the copy
@@ -288,8 +282,7 @@ struct Chunk {
     bool down_pending = false;          // ... which the next search that writes the slot's table must wait for
     uint32_t nitems = 0, nitems_wg = 0;  // wave items / workgroup items of the queue
     uint32_t nitems_q = 0, nitems_q_wg = 0; // the same for the query-pair kernel's queue
-    uint32_t nitems_t = 0;                  // tail items (wave items)
-    uint64_t tiled_cols = 0;                // columns of `tiled` (a hand-over plane has 64 entries per column)
+    uint32_t nitems_short = 0;              // ... of which SHORT pair items (they run their pair's tail, OswSearchArgs::hand)
     uint64_t items_version = ~0ull;     // query-set version the item list was built for
     int items_bits = 0;                 // cell width it was planned for
     uint32_t max_lg = 0;                // widest geometry in the item list
@@ -341,7 +334,7 @@ struct Device {
     uint32_t grid = 0;               // persistent workgroups per launch
     uint32_t grid_q8 = 0;            // ... of the 8-bit kernel (more workgroups per CU; at most 2 x grid: it runs alone and may use both halves of the spill scratch)
     DevBuf queries, qlen, a_disp, prof_off, prof, prof_alt, prof_seq, prof_seq_alt, prof_pair_i16, pair_q, pair_off, pair_len, prof_pair, submat, bnd, counters;
-    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8, floor_i32, pair_tail, pair_rows, tail_pair, tail_query, hand;
+    DevBuf topr_scores, topr_index, topr_cand, wg_times, scores_packed, top_pages, prof_pair8, floor_i32, pair_rows, tail_len, tail_off;
     Arena qset;                           // what the buffers of the current query set (queries ... top_pages, prof_pair8) are slices of
     uint8_t *qstage = nullptr;            // page-locked: the small inputs of the query set as the arena holds them, read in place by the copy kernel
     size_t qstage_cap = 0;
@@ -387,14 +380,13 @@ struct oswald_hip_ctx {
     std::vector<uint32_t> pair_q, pair_off, singles;
     std::vector<uint16_t> pair_len;
     uint32_t pair_rowblocks = 0, pair_max_rowblocks = 0;
-    // Tails (sw_kernels.h, OswSearchArgs::hand): pair i keeps the SHORTER query's rows; the rest of its longer query is entity
-    // nq + k of the single-query arrays (m_ext / prof_off_ext: the real queries first, then the tails)
-    struct Tail { uint32_t query, pair, row0, rows; }; // (row0 / rows at geometry 1; entity nq + 7 t + lg: the tail behind pair items of geometry 2^lg)
-    std::vector<Tail> tails;
-    std::vector<uint8_t> pair_tail;                 // [pair] has a tail
-    std::vector<uint16_t> pair_rows;                // [pair] rows of a SHORT pair item (the shorter query's, rounded up to 4; = pair_len without a tail)
-    std::vector<uint16_t> m_ext, tail_pair, tail_query; // [nq + tails]
-    std::vector<uint32_t> prof_off_ext;
+    // Tails (sw_kernels.h, OswSearchArgs::hand): a SHORT item of pair i runs pair_rows[i] rows as a pair (the shorter query's, rounded up
+    // to 4; = pair_len where the pair has no tail) and then the rest of the longer query -- tail_len[7 i + lg] rows from row-block
+    // tail_off[7 i + lg] of that query's single-query profile on, behind a pair item of geometry 2^lg -- on the single-query cell
+    bool have_tails = false;                        // some pair of the set has a tail
+    std::vector<uint16_t> pair_rows;                // [pair]
+    std::vector<uint16_t> tail_len;                 // [pair * OSW_TAIL_GEOMS + lg]
+    std::vector<uint32_t> tail_off;
     uint64_t queries_version = 0;
     bool profiling = false;
     uint32_t topr_r = 0;             // oswald_hip_topr_begin: every search also selects the chunk's top r (0: off)
@@ -458,29 +450,28 @@ int sync_queries(oswald_hip_ctx *ctx, Device &d)
     // six little hipMemcpyAsync from the context's std::vectors holding the caller for 8.6 ms of a 25-ms search (the runtime
     // stages a pageable copy on the caller's thread, and the copy engine was busy with the chunk coming in).
     const bool alt_ = first_pass_is_frame(ctx), q8_ = first_pass_is_q8(ctx);
-    const uint32_t np_ = (uint32_t)ctx->pair_len.size(), ne_ = (uint32_t)ctx->m_ext.size(); // (entities of the single-query arrays: the queries, then the tails)
+    const uint32_t np_ = (uint32_t)ctx->pair_len.size();
     const size_t prof8 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint2) + 4096, prof16 = (size_t)ctx->total_rowblocks * 32 * sizeof(uint4) + 4096;
     const size_t pair16 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint4) + 4096, pair8 = (size_t)ctx->pair_rowblocks * 32 * sizeof(uint2) + 4096;
     const size_t pages_bytes = (size_t)(128 + OSW_I16S_TABLE + 64) * 2 * sizeof(uint32_t);
     struct Slice { DevBuf *buf; size_t bytes; const void *src; size_t src_bytes; };
     const Slice slices[] = {// inputs (src: what the staging buffer holds at the slice's offset; top_pages is generated in place below)
                             {&d.queries, ctx->a.size() + 16, ctx->a.data(), ctx->a.size()},
-                            {&d.qlen, ne_ * sizeof(uint16_t) + 16, ctx->m_ext.data(), ne_ * sizeof(uint16_t)},
+                            {&d.qlen, nq * sizeof(uint16_t) + 16, ctx->m.data(), nq * sizeof(uint16_t)},
                             {&d.a_disp, (nq + 1) * sizeof(uint32_t), ctx->a_disp.data(), nq * sizeof(uint32_t)},
-                            {&d.prof_off, (ne_ + 1) * sizeof(uint32_t), ctx->prof_off_ext.data(), ne_ * sizeof(uint32_t)},
+                            {&d.prof_off, (nq + 1) * sizeof(uint32_t), ctx->prof_off.data(), nq * sizeof(uint32_t)},
                             {&d.submat, 24 * 32, ctx->submat, 24 * 32},
                             {&d.pair_q, np_ ? 2 * np_ * sizeof(uint32_t) : 0, ctx->pair_q.data(), 2 * np_ * sizeof(uint32_t)},
                             {&d.pair_off, np_ ? np_ * sizeof(uint32_t) : 0, ctx->pair_off.data(), np_ * sizeof(uint32_t)},
                             {&d.pair_len, np_ ? np_ * sizeof(uint16_t) + 16 : 0, ctx->pair_len.data(), np_ * sizeof(uint16_t)},
-                            {&d.pair_tail, np_ ? np_ + 16 : 0, ctx->pair_tail.data(), np_},
                             {&d.pair_rows, np_ ? np_ * sizeof(uint16_t) + 16 : 0, ctx->pair_rows.data(), np_ * sizeof(uint16_t)},
-                            {&d.tail_pair, ne_ * sizeof(uint16_t) + 16, ctx->tail_pair.data(), ne_ * sizeof(uint16_t)},
-                            {&d.tail_query, ne_ * sizeof(uint16_t) + 16, ctx->tail_query.data(), ne_ * sizeof(uint16_t)},
+                            {&d.tail_len, np_ ? np_ * OSW_TAIL_GEOMS * sizeof(uint16_t) + 16 : 0, ctx->tail_len.data(), np_ * OSW_TAIL_GEOMS * sizeof(uint16_t)},
+                            {&d.tail_off, np_ ? np_ * OSW_TAIL_GEOMS * sizeof(uint32_t) + 16 : 0, ctx->tail_off.data(), np_ * OSW_TAIL_GEOMS * sizeof(uint32_t)},
                             {&d.top_pages, pages_bytes, nullptr, 0},
                             // built on the device
                             {&d.prof, prof8, nullptr, 0}, {&d.prof_seq, prof16, nullptr, 0}, {&d.prof_alt, prof8, nullptr, 0}, {&d.prof_seq_alt, alt_ ? prof16 : 0, nullptr, 0}, {&d.floor_i32, (size_t)OSW_I32F_TABLE * sizeof(uint2), nullptr, 0},
                             {&d.prof_pair, np_ ? pair16 : 0, nullptr, 0}, {&d.prof_pair8, np_ && q8_ ? pair8 : 0, nullptr, 0}, {&d.prof_pair_i16, np_ && alt_ ? pair16 : 0, nullptr, 0}};
-    constexpr size_t kInputs = 13;
+    constexpr size_t kInputs = 12;
     size_t total = 0, inputs_bytes = 0;
     for (size_t i = 0; i < sizeof slices / sizeof slices[0]; ++i) { total += Arena::up(slices[i].bytes); if (i + 1 == kInputs) inputs_bytes = total; }
     if (total > d.qset.slab.cap) {
@@ -741,6 +732,7 @@ static int init_impl(int ndev, const int *device_ids, oswald_hip_ctx **out)
     oswald_hip_ctx *ctx = new (std::nothrow) oswald_hip_ctx;
     if (!ctx) return fail(OSWALD_HIP_ENOMEM, "out of host memory");
     ctx->tun.refresh();
+    struct HookOff { size_t keep; HookOff() : keep(g_fail_alloc_above) { g_fail_alloc_above = 0; } ~HookOff() { g_fail_alloc_above = keep; } } hook_off; // (the test hook "device is full" spares bring-up)
     ctx->profiling = g_debug_slow; // (OSWALD_HIP_DEBUG_SLOW: the device's time line of every pass, see drain_events)
     ctx->dev.resize(ndev);
     for (int i = 0; i < ndev; ++i) {
@@ -780,6 +772,13 @@ static int init_impl(int ndev, const int *device_ids, oswald_hip_ctx **out)
         r = d.qset.slab.reserve(16u << 20); // the query sets' arena: the BASELINE set needs 8 MB
         if (r == hipSuccess) r = d.counters.reserve((OSW_CTR_BLOCKS * OSW_CTR_COUNT + 8) * sizeof(uint32_t));
         if (r != hipSuccess) { delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: %s", d.id, hipGetErrorString(r)); }
+        // The device's own working memory -- the spill scratch of the strip boundaries, a region per resident wave -- is part of the
+        // bring-up (round 6): it belongs to the kernels like the FPGA kernel's on-chip row buffers belong to the bitstream init() loads
+        // (utils.c:99-173), it does not depend on the inputs (sized for the longest block a region ever holds: 4 096 columns at two
+        // lane groups; longer blocks run at narrower lane groups), and nothing the reference creates inside its clock
+        // (FPGAsearch.c:85-96: queries, chunk arrays, profiles, scores) corresponds to it.  What does -- the chunk slots -- is made
+        // inside the caller's clock (oswald_hip_reserve_chunks, or the first uploads).
+        if (ensure_scratch(d, 4096) != 0) { const std::string why = g_err; delete ctx; return fail(OSWALD_HIP_ENOMEM, "device %d: spill scratch: %s", d.id, why.c_str()); }
         // Bring-up costs that would otherwise land in the first search (the reference times its searches after
         // init(), main.c:46 / FPGAsearch.c:80): the runtime's staging for copies from / to pageable memory (the first
         // copy of a process takes ~10 ms, later ones run at ~20 GB/s) and the first launch of every kernel.
@@ -867,7 +866,7 @@ static int finalize_impl(oswald_hip_ctx *ctx)
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
         for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; } }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_seq, &d.prof_seq_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
-                          &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8, &d.floor_i32, &d.pair_tail, &d.pair_rows, &d.tail_pair, &d.tail_query, &d.hand,
+                          &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8, &d.floor_i32, &d.pair_rows, &d.tail_len, &d.tail_off,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
             b->release();
         d.qset.slab.release();
@@ -1239,10 +1238,13 @@ static int reserve_chunks_impl(oswald_hip_ctx *ctx, int dev, uint64_t chunk_byte
         if (dev >= 0 && i != dev) continue;
         Device &d = ctx->dev[i];
         HIP_TRY(hipSetDevice(d.id));
-        while (d.chunks.size() < slots) d.chunks.emplace_back();
-        for (uint32_t k = 0; k < slots; ++k) {
+        // `slots` FREE slots (slots that hold a chunk -- a caller's resident chunks -- do not count)
+        uint32_t made = 0;
+        for (size_t k = 0; made < slots; ++k) {
+            if (k >= d.chunks.size()) d.chunks.emplace_back();
             Chunk &c = d.chunks[k];
             if (c.live || c.upload_pending) continue;
+            ++made;
             // re-tiled residues: a byte per residue of every block padded to its longest group (sorted databases: ~1.02 x the chunk)
             // + the all-dummy column groups around every block
             const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
@@ -1287,17 +1289,6 @@ static int reserve_chunks_impl(oswald_hip_ctx *ctx, int dev, uint64_t chunk_byte
             if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
             if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
         }
-        // the hand-over planes of the tails (OswSearchArgs::hand; one set per device): if a query set of nq queries would get them on
-        // chunks of this size (the planner's rule, osw_planner.inc), they are made here -- 11.7 GB for the BASELINE set on the 128-MiB chunks of the C4 database:
-        // tens of milliseconds that would otherwise fall into the first search that takes tails (the hybrid mode rates the device on
-        // its first searches)
-        {
-            const uint32_t np = nq / 2;
-            const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
-            if (ctx->tun.pair_tails > 0 && np >= 1 && np <= (uint32_t)ctx->tun.pair_tails &&
-                (double)nblocks * (double)np >= ctx->tun.tail_items_per_wave * (double)d.grid * (OSW_WG_THREADS / 64) && col4 * 256ull * 2ull * np * sizeof(uint2) <= OSW_HAND_MAX_BYTES)
-                HIP_TRY(d.hand.reserve(col4 * 256ull * 2ull * np * sizeof(uint2) + 4096));
-        }
         if (ctx->tun.warm_ms > 0) {
             HIP_TRY(osw_launch_spin((uint32_t *)d.counters.p, d.grid, std::min(ctx->tun.warm_ms, 50.0), d.stream));
             HIP_TRY(hipStreamSynchronize(d.stream));
@@ -1328,12 +1319,6 @@ static int max_chunk_size_impl(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32
     uint64_t usable = (uint64_t)(0.8 * (double)free_b);
     if (stride > d.bnd_stride || !d.bnd.p) usable = usable > scratch ? usable - scratch : 0;
     // (four chunks' worth: slots are kept, and after a first chunk cut in two -- head and rest fit no full chunk -- three more are opened)
-    // ... and ONE set of hand-over planes per device for the tails of a small query set's pairs (OswSearchArgs::hand): two planes per pair,
-    // 64 entries of 8 B per re-tiled column = 4 x the re-tiled residues and their dummy columns each
-    const uint32_t np = nq / 2;
-    // (at most OSW_HAND_MAX_BYTES: the planner takes no tails on chunks whose planes would be larger)
-    const bool hand_possible = ctx->tun.pair_tails > 0 && np >= 1 && np <= (uint32_t)ctx->tun.pair_tails;
-    if (hand_possible) usable = usable > OSW_HAND_MAX_BYTES + (1ull << 30) ? usable - OSW_HAND_MAX_BYTES : usable / 2;
     const double per_byte = 4.1 * (1.0 + 1.25 + 2.6 + 20.0 * (double)std::max(nq, 1u) / 28.0);
     const uint64_t fit = (uint64_t)((double)usable / per_byte);
     *bytes = std::min<uint64_t>(fit, 0xfff00000ull); // (column offsets inside a chunk are 32-bit)
@@ -1390,22 +1375,6 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     a.force_all = ctx->cell_bits == 32 ? 1u : 0u;
     a.prof_i32 = (const uint2 *)d.prof_alt.p; // S + ge: the int32 cell (re-run and cell_bits = 32)
     a.floor_i32 = (const uint2 *)d.floor_i32.p;
-    if (c.nitems_t > 0) {
-        // tails: two hand-over planes per pair, 64 entries of 8 B per column of the re-tiled chunk; one set per device (the searches
-        // of a device run one after the other on its stream)
-        const uint64_t plane = c.total_col4 * 256ull, entries = plane * 2ull * ctx->pair_len.size();
-        if (entries >= (1ull << 32)) return fail(OSWALD_HIP_EINVAL, "the hand-over planes of %zu query pairs on a chunk of %llu columns would take %llu GB; search in smaller chunks or set OSWALD_HIP_PAIR_TAILS=0",
-                                                 ctx->pair_len.size(), (unsigned long long)(c.total_col4 * 4), (unsigned long long)(entries >> 27));
-        HIP_TRY(d.hand.reserve(entries * sizeof(uint2) + 4096));
-        a.hand = (uint2 *)d.hand.p;
-        a.hand_plane = (uint32_t)plane;
-    }
-    if (!ctx->tails.empty()) { // (also for a chunk without tail items: a pair with a tail holds the shorter query's rows only)
-        a.pair_tail = (const uint8_t *)d.pair_tail.p;
-        a.pair_rows = (const uint16_t *)d.pair_rows.p;
-        a.tail_pair = (const uint16_t *)d.tail_pair.p;
-        a.tail_query = (const uint16_t *)d.tail_query.p;
-    }
     a.debug_nospill = ctx->tun.debug_nospill ? 1u : 0u; // -DOSW_DIAG builds only (timing experiment: results are wrong); always 0 otherwise
     a.prof = (const uint2 *)d.prof.p;
     a.prof_off = (const uint32_t *)d.prof_off.p;
@@ -1509,6 +1478,18 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
         aq.qlen = (const uint16_t *)d.pair_len.p;
         aq.pair_q = (const uint32_t *)d.pair_q.p;
         aq.counters = (uint32_t *)d.counters.p + OSW_CTR_COUNT;
+        if (c.nitems_short > 0) {
+            // SHORT pair items run their pair's tail on the single-query cell (OswSearchArgs::hand): the single-query profiles of the same
+            // set, and a hand region per resident wave -- the half of the spill scratch a launch of single queries beside this one
+            // would use (the planner marks items SHORT only where there is no such launch)
+            if (c.nitems + c.nitems_wg > 0) return fail(OSWALD_HIP_ERUNTIME, "planner: SHORT pair items beside a launch of single queries");
+            aq.hand = a.bnd + (size_t)d.grid * (OSW_WG_THREADS / 64) * a.bnd_stride;
+            aq.pair_rows = (const uint16_t *)d.pair_rows.p;
+            aq.tail_len = (const uint16_t *)d.tail_len.p;
+            aq.tail_off = (const uint32_t *)d.tail_off.p;
+            aq.tail_prof = as.prof;
+            aq.tail_prof_fb = as.prof_fb;
+        }
         const uint32_t gq = std::min<uint32_t>(grid_cap, (c.nitems_q + 3) / 4 + c.nitems_q_wg);
         if (c.nitems + c.nitems_wg > 0 && !ctx->tun.one_stream) {
             // the single-query launch goes to a second stream so that its workgroups fill the slots the
@@ -1527,15 +1508,6 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
         }
     } else if (ctx->cell_bits != 32 && c.nitems + c.nitems_wg > 0) {
         HIP_TRY(launch_single(as, grid, d.stream));
-    }
-    if (c.nitems_t > 0 && !first_pass_is_q8(ctx) && ctx->cell_bits != 32) {
-        // the tails of the pairs' longer queries: single-query wave items that start from what the pair launch handed over
-        OswSearchArgs at = as;
-        at.items = c.items_t_ptr();
-        at.nitems = c.nitems_t;
-        at.nitems_wg = 0;
-        at.counters = (uint32_t *)d.counters.p + 2 * OSW_CTR_COUNT;
-        HIP_TRY(launch_single(at, std::min<uint32_t>(grid_cap, (c.nitems_t + 3) / 4), d.stream));
     }
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.d, d.stream));
     // cell_bits 32: the whole plan on the int32 kernel; else: the re-run of what reached the int16 cells' ceiling (queue on the device)
@@ -1700,6 +1672,37 @@ static int search_chunk_async_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *
         c.is_cont = false;
     }
     return r;
+}
+
+// The reverse of oswald_hip_reserve_chunks: the buffers of every chunk slot that holds no chunk go back to the device and the
+// host (the reference releases its six buffers at the end of a search, FPGAsearch.c:361-368, and creates them again inside the
+// next search's clock, :85-96).  Waits for the device first: a released slot's last search may still be running.
+static int release_chunks_impl(oswald_hip_ctx *ctx, int dev)
+{
+    if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
+    if (dev >= (int)ctx->dev.size()) return fail(OSWALD_HIP_ENODEV, "device index %d out of range", dev);
+    for (int i = 0; i < (int)ctx->dev.size(); ++i) {
+        if (dev >= 0 && i != dev) continue;
+        Device &d = ctx->dev[i];
+        HIP_TRY(hipSetDevice(d.id));
+        for (hipStream_t st : {d.stream_copy, d.stream_up, d.stream, d.stream2, d.stream_down}) HIP_TRY(hipStreamSynchronize(st));
+        release_registered(d);
+        for (Chunk &c : d.chunks) {
+            c.upload_pending = c.use_pending = c.down_pending = c.map_pending = false;
+            c.set_read_pending[0] = c.set_read_pending[1] = false;
+            if (c.live) continue;
+            for (DevBuf *b : {&c.tiled, &c.blocks, &c.sub_cols_buf, &c.scores, &c.ovf, &c.ovf8, &c.st_b, &c.index_map_dev[0], &c.index_map_dev[1]}) b->release();
+            c.nd_pin.release(); c.map_pin[0].release(); c.map_pin[1].release();
+            if (c.sub_cols) (void)hipHostFree(c.sub_cols);
+            c.sub_cols = nullptr; c.sub_cols_cap = 0;
+            if (c.blocks_pin) (void)hipHostFree(c.blocks_pin);
+            c.blocks_pin = nullptr; c.blocks_pin_cap = 0;
+            for (int k = 0; k < 2; ++k) { if (c.items_pin[k]) (void)hipHostFree(c.items_pin[k]); c.items_pin[k] = nullptr; c.items_pin_cap[k] = 0; }
+            c.items_version = ~0ull;
+            c.searched = false;
+        }
+    }
+    return 0;
 }
 
 static int chunk_wait_impl(oswald_hip_ctx *ctx, int dev, int chunk)
@@ -2094,7 +2097,7 @@ static int chunk_geometry_impl(oswald_hip_ctx *ctx, int dev, int chunk, uint64_t
         out8[1] += alloc;
         out8[2] += live;
         out8[3] += live * 64 * sizeof(uint2);
-        out8[4] += c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg + c.nitems_t; // wave-level work items (a phase-1 entry is four)
+        out8[4] += c.nitems + 4ull * c.nitems_wg + c.nitems_q + 4ull * c.nitems_q_wg; // wave-level work items (a phase-1 entry is four)
         out8[5] = std::max<uint64_t>(out8[5], c.max_lg);
         out8[6] += c.planned_spill_bytes;
     }
@@ -2197,6 +2200,11 @@ int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
 int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W, int32_t *scores_out)
 {
     return guarded("oswald_hip_search_chunk_async", [&] { return search_chunk_async_impl(ctx, dev, b, vD, n, disp, ngroups, W, scores_out); });
+}
+
+int oswald_hip_release_chunks(oswald_hip_ctx *ctx, int dev)
+{
+    return guarded("oswald_hip_release_chunks", [&] { return release_chunks_impl(ctx, dev); });
 }
 
 int oswald_hip_chunk_wait(oswald_hip_ctx *ctx, int dev, int chunk)

@@ -69,9 +69,8 @@
 #define OSW_ITEM_PRIO(x) (((x) >> 30) & 3u)
 #define OSW_ITEM_WG_FLAG 0x80000000u  // in y of a phase-1 slot: workgroup item (shared profile slice, waves in step)
 #define OSW_ITEM_NONE 0x7fffffffu     // y of an empty slot
-#define OSW_HAND_MAX_BYTES (16ull << 30) // the hand-over planes of a device at most (the BASELINE set's ten pairs on a 128-MiB chunk of the C4 database: 11.7 GB; entry indices are 32-bit: 34 GB would be the end)
-#define OSW_ITEM_SHORT 1u             // `halves` field of a pair item: the pair's register holds the shorter query's rows only; the last round hands over
-#define OSW_ITEM_TAIL_LG_SHIFT 24      // y of a tail item (wave items only): block | (log2 geometry of the pair items that handed over) << 24
+#define OSW_ITEM_SHORT 1u             // `halves` field of a pair item: the item runs the shorter query's rows as a pair and the rest of the longer query as its TAIL (below)
+#define OSW_TAIL_GEOMS 7u             // a pair's tail has a length and a place in the profile for each log2 geometry 0 .. 6 of the item that runs it
 
 // Strip plan of a query of m rows at geometry G: every lane group owns
 // T = ceil4(ceil4(m) / G) rows, cut into `rounds` strips whose heights are
@@ -169,20 +168,22 @@ struct OswSearchArgs {
     uint2 *ovf8_items;         // 8-bit kernel: the queue it fills for the int16 re-run
     uint32_t bias8, go8, ge8, off8; // 8-bit kernel: profile bias, gap open, gap extend and the cell's offset c (q8_cell.h), plain values
     const uint32_t *pair_q;    // query-pair kernel: the two queries of pair i (rows of the score table)
-    // Tails (round 5, third session): a pair's register holds the SHORTER query's rows only (rounded up to 4); the rows the longer
-    // query has beyond them run afterwards as a single-query item on BOTH sequences of a lane at once instead of padding the
-    // shorter one (6.5 instead of 13 instructions per row and sequence pair).  The pair launch hands the longer query's bottom
-    // row {H, F} of its last round over in `hand`: two planes per pair (one per pass = sequence of the lane), each laid out like
-    // `tiled` in columns (64 entries of 8 B per column; a block's sub-block sigma at geometry G = 64 / gl lanes per group at
-    // (sigma * (columns of the block + 64) + column) * gl + lane of the group).  The tail launch (single-query kernel) merges
-    // the two planes into its own spill region and starts from there.
-    uint2 *hand;               // or null: no hand-over (pair launch) / no tails (single-query launch)
-    uint32_t hand_plane;       // entries per plane = columns of `tiled` x 64 (all planes together: < 2^32 entries)
-    const uint8_t *pair_tail;  // pair launch: pair i has a tail (its longer query's last round is handed over)
-    const uint16_t *pair_rows; // ... and the rows a pair item marked SHORT (OSW_ITEM_SHORT) runs: the shorter query's, rounded up to 4; its strips
-                               // end on a row of the longer query wherever the geometry puts it (the profile holds all of the longer query's rows)
-    const uint16_t *tail_pair; // single-query launch: entity q is the tail of pair tail_pair[q] - 1 (0: an ordinary query)
-    const uint16_t *tail_query;// ... and its scores belong to row tail_query[q] of the table
+    // Tails.  A query pair pads its shorter query to the longer one (two passes of the pair cell over rows that hold one query).  A pair
+    // item marked OSW_ITEM_SHORT instead runs the SHORTER query's rows as a pair (pair_rows, rounded up to 4; at geometry G its strips
+    // end on row X(G) = 4 G ceil(ceil(rows / G) / 4) of the longer query, whose profile rows are all there) and then -- the same wave,
+    // the same sub-block, the same geometry -- the rest of the longer query on the SINGLE-query cell, both sequences of a lane at once
+    // (6.5 instead of 13 instructions per row and sequence pair).  The bottom row {H, F} of the pair's last round is the tail's row
+    // above: pass 0 (a lane's first sequence) leaves it in the wave's HAND region, pass 1 in the wave's own spill region (in place,
+    // like every round boundary); the wave merges the longer query's halves of the two into its spill region and goes on from there.
+    // (Round 5 ran the tails as a launch of their own and handed over through planes as large as 8 x the chunk per pair: 11.7 GB for
+    // the BASELINE set.  Here nothing leaves the wave: the hand regions are the half of the spill scratch that a launch of single
+    // queries beside the pairs' would use -- tails are planned for query sets without such a launch.)
+    uint2 *hand;               // pair launch: a second region per resident wave, laid out like `bnd` (same stride); null: no SHORT items in the queue
+    const uint16_t *pair_rows; // [pair] rows a SHORT item runs as a pair
+    const uint16_t *tail_len;  // [pair * OSW_TAIL_GEOMS + lg] rows of the tail behind a SHORT item of geometry 2^lg (0: the strips took the whole query)
+    const uint32_t *tail_off;  // ... and its first row-block in the single-query profiles (tail_prof / tail_prof_fb)
+    const uint2 *tail_prof;    // the single-query kernels' profile of the same query set ({S, 1} entries; column-frame kernels: S + ge)
+    const uint2 *tail_prof_fb; // column-frame kernels: ... and the plain one (blocks run on the plain cell)
     uint2 *ovf_items;
     uint32_t goe_pk, ge_pk;    // (open+extend, extend) replicated in both halves; column-frame kernels: (open, extend)
     uint32_t goe_fb, ge_fb;    // column-frame kernels: (open+extend, extend) for the plain cell

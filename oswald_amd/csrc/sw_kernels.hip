@@ -1142,28 +1142,46 @@ static __device__ __forceinline__ const uint2 *osw_top_pages(const OswSearchArgs
 //               is a pair of workgroup barriers around the slice reload.
 // (wg is a run-time, workgroup-uniform flag: both kinds run the same round code.)
 // HWL: `lane` is a logical lane number (osw_logical_lane; the packed-int16 kernels), else the physical one
-// A pair's longer query goes on as a tail item (OswSearchArgs::hand).  store: where the LAST round of this item leaves its bottom row
-// (null: nowhere).  A tail item's row above is the HIGH halves (the pair's second = longer query) of the entries the two passes of the
-// pair items left there, written at geometry 2^lgp (the tail runs at geometry 1: the frames differ by (2^lgp - 1) * ge).
+// Tails (OswSearchArgs::hand): what a SHORT pair item and the tail behind it need beyond an ordinary item's arguments.
 struct OswHand {
-    bool store;        // HMODE 1: the last round's bottom row goes to the pair's plane of this pass (computed where it is used: no live pointer)
-    uint32_t pair1;    // HMODE 2: the pair whose tail this item is, + 1 (0: an ordinary item)
-    uint32_t lgp;      // ... and the geometry of the pair items that wrote
-    bool framed;       // ... in the column-frame representation (else: plain biased values, no conversion)
+    uint2 *region;     // HMODE 1: the wave's hand region; the LAST round of pass 0 leaves its bottom row there, of pass 1 in the wave's own spill region (in place)
+    uint32_t mlen;     // HMODE 1: the rows the item runs as a pair (the shorter query's, rounded up to 4); HMODE 2: the rows of the tail
+    uint32_t rb_end;   // HMODE 1: row-blocks of the pair's profile that are real (the LONGER query's: the strips run on into its own rows)
+    uint32_t prof_rb0; // HMODE 2: the tail's first row-block in the single-query profile
 };
-// where sub-block sigma of block blk starts in a hand-over plane, for items of geometry 2^lg
-// (entry indices are 32-bit: the library gives the planes at most 2^32 entries in all, 32 GB)
-static __device__ __forceinline__ uint32_t osw_hand_sub(const OswBlock &blk, uint32_t sigma, uint32_t lg)
+
+// The tail's row above: the longer query's halves (the high halves of a pair's packed {H, F}) of what pass 0 left in the hand region
+// (the lane's first sequence -> low half) and pass 1 in the spill region (second sequence -> high half), merged in place in the spill
+// region.  Same wave, same geometry, same columns: entry (column, lane of the group) stays where it is, the frames are the same.
+static __device__ __forceinline__ void osw_merge_hand(uint2 *bnd, const uint2 *hand_region, uint32_t ncols, uint32_t gl, int lane)
 {
-    return blk.col4_off * 256u + sigma * (blk.ncols4 * 4u + 64u) * (64u >> lg);
+    uint2 *row = bnd + OSW_SCRATCH_DATA;
+    const uint2 *h0 = hand_region + OSW_SCRATCH_DATA;
+    const uint32_t n = ncols * gl;
+    // eight entries a turn per lane: sixteen independent loads in flight
+    for (uint32_t i0 = (uint32_t)lane; i0 < n; i0 += 8u * 64u) {
+        uint2 e0[8], e1[8];
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+            const uint32_t i = i0 + t * 64u;
+            const bool live = i < n;
+            e0[t] = live ? h0[i] : make_uint2(0u, 0u);
+            e1[t] = live ? row[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+            const uint32_t i = i0 + t * 64u;
+            if (i < n) row[i] = make_uint2((e0[t].x >> 16) | (e1[t].x & 0xffff0000u), (e0[t].y >> 16) | (e1[t].y & 0xffff0000u));
+        }
+    }
 }
 
-// HMODE: 0 = no hand-over code at all, 1 = the item may leave its last bottom row in hand.store (pair kernels), 2 = the item may be a
-// tail (single-query kernels); the other fields of `hand` are then ignored / null
+// HMODE: 0 = an ordinary item; 1 = a SHORT pair item (hand.mlen rows, the last round's bottom row is kept); 2 = the tail behind it
+// (the single-query cell: rows hand.mlen from row-block hand.prof_rb0 of `prof` on; its row above is in the spill region already)
 template <class C, bool HWL = false, int HMODE = 0>
 static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p, const uint2 *prof, uint32_t q, uint32_t B, const OswBlock &blk, uint32_t sigma,
                                                          uint32_t lg, int lane, int half, bool wg, uint2 *lds_region, uint2 *bnd_wave,
-                                                         typename C::GapT goe, typename C::GapT ge, OswHand hand = OswHand{false, 0u, 0u, false})
+                                                         typename C::GapT goe, typename C::GapT ge, OswHand hand = OswHand{nullptr, 0u, 0u, 0u})
 {
     typedef typename C::T T;
     const uint32_t kLds = wg ? C::kLdsRows * (OSW_WG_THREADS / 64) : C::kLdsRows;
@@ -1173,53 +1191,14 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     const uint32_t ncols = __builtin_amdgcn_readfirstlane((uint32_t)p.sub_cols[(size_t)B * 128 + (G - 1u) + sigma]);
     const uint16_t *tcol = (const uint16_t *)osw_uniform64((uint64_t)(p.tiled + (size_t)blk.col4_off * 256 + sigma * gl));
     uint2 *bnd = (uint2 *)osw_uniform64((uint64_t)bnd_wave);
-    uint32_t mlen = p.qlen[q];
-    if constexpr (HMODE == 1) { if (hand.store) mlen = p.pair_rows[q]; } // (a SHORT pair item: the shorter query's rows, the rest is a tail item's)
+    uint32_t mlen, prof_rb0;
+    if constexpr (HMODE == 0) { mlen = p.qlen[q]; prof_rb0 = p.prof_off[q]; }
+    else if constexpr (HMODE == 1) { mlen = hand.mlen; prof_rb0 = p.prof_off[q]; }
+    else { mlen = hand.mlen; prof_rb0 = hand.prof_rb0; }
     const OswPlan plan = osw_plan(mlen, G, kLds, C::kRows);
     typedef typename C::Entry Entry; // the profile scores of one residue code for 4 rows
-    const Entry *prof_q = (const Entry *)prof + (size_t)p.prof_off[q] * (uint32_t)C::kCodes;
-    bool tail = false;
-    if constexpr (HMODE == 2) tail = __builtin_amdgcn_readfirstlane(hand.pair1 ? 1 : 0) != 0; // (wave-uniform, and known to be)
-    if constexpr (HMODE == 2) {
-        if (tail) {
-            // The row above this item: what the pair items of the block's sub-blocks -- at THEIR geometry 2^lgp -- handed over, pass 0
-            // for a lane's first sequence, pass 1 for its second, brought into this item's geometry: entry (column, lane of the first
-            // group); beyond a sub-block's own last column (its sequences are through: dummy residues) and up to this item's: zero in
-            // the column's frame.  The frames of the two geometries differ by (2^lgp - G) * ge.
-            const uint32_t glp = 64u >> hand.lgp, gep = (uint32_t)ge;
-            // (gl divides 64: a lane keeps its lane of the block -- its place with the writers -- through the loop; only the column moves)
-            const uint32_t bl = sigma * gl + ((uint32_t)lane & (gl - 1u)), sg = bl / glp, up = bl % glp;
-            const uint32_t nsub = p.sub_cols[(size_t)B * 128 + ((1u << hand.lgp) - 1u) + sg];
-            const uint2 *l0 = p.hand + (2u * (hand.pair1 - 1u) * p.hand_plane + osw_hand_sub(blk, sg, hand.lgp) + up);
-            const uint32_t fix = hand.framed ? G * gep - (1u << hand.lgp) * gep : 0u; // (mod 2^32: the halves do not borrow from each other, see above)
-            uint2 *row = bnd + OSW_SCRATCH_DATA + ((uint32_t)lane & (gl - 1u));
-            const uint32_t c0 = (uint32_t)lane / gl, cstep = 64u / gl;
-            // eight columns a turn: sixteen independent loads in flight (one after the other they cost a memory latency per column)
-            for (uint32_t cb = c0; cb < ncols; cb += 8u * cstep) {
-                uint2 e0[8], e1[8];
-#pragma unroll
-                for (uint32_t t = 0; t < 8; ++t) {
-                    const uint32_t c = cb + t * cstep;
-                    const bool live = c < nsub; // (beyond: nothing was handed over -- and nothing is read)
-                    e0[t] = live ? l0[(size_t)c * glp] : make_uint2(0u, 0u);
-                    e1[t] = live ? l0[(size_t)c * glp + p.hand_plane] : make_uint2(0u, 0u);
-                }
-#pragma unroll
-                for (uint32_t t = 0; t < 8; ++t) {
-                    const uint32_t c = cb + t * cstep;
-                    if (c >= ncols) break;
-                    uint32_t z = C::kFloorBits;
-                    if constexpr (C::kShifted) z += (c + G) * gep;
-                    uint2 e = make_uint2(z, z);
-                    if (c < nsub) {
-                        e.x = ((e0[t].x >> 16) | (e1[t].x & 0xffff0000u)) + fix;
-                        e.y = ((e0[t].y >> 16) | (e1[t].y & 0xffff0000u)) + fix;
-                    }
-                    row[(size_t)c * gl] = e;
-                }
-            }
-        }
-    }
+    const Entry *prof_q = (const Entry *)prof + (size_t)prof_rb0 * (uint32_t)C::kCodes;
+    constexpr bool tail = HMODE == 2;
     if (plan.rounds > 1 || tail) {
         // the scratch columns the prefetch and the drain steps read past the block's last one are the
         // row above of dummy columns: "zero" in the cell's representation (other items have written here)
@@ -1238,7 +1217,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
     for (uint32_t rho = 0; rho < plan.rounds; ++rho) {
         // round rho: group g runs rows [G*row0 + g*R, +R) of the query
         uint32_t rb_end = plan.m4 / 4;
-        if constexpr (HMODE == 1) { if (hand.store) rb_end = (p.qlen[q] + 3u) / 4u; } // (a SHORT pair item: its strips run on into the longer query's own rows)
+        if constexpr (HMODE == 1) rb_end = hand.rb_end; // (a SHORT pair item: its strips run on into the longer query's own rows)
         const uint32_t R = osw_round_rows(plan, rho), rb0 = G * osw_round_row0(plan, rho) / 4;
         if (wg) {
 #ifdef OSW_DIAG // (OSWALD_HIP_DEBUG_TIMES: core-clock cycles this wave spends in the slice reload incl. both barriers)
@@ -1262,7 +1241,7 @@ static __device__ __forceinline__ typename C::T run_item(const OswSearchArgs &p,
         }
         const uint32_t base = (uint32_t)(uintptr_t)((lds_cp)lds_region + g * (R * C::kRowBytes + (uint32_t)sizeof(Entry)));
         sw_round_dispatch<C>(R, tcol, u, ncols, base, bnd, osw_top_pages<C>(p), (rho == 0 && !tail) || OSW_DIAG_NOSPILL(p), rho + 1 == plan.rounds || OSW_DIAG_NOSPILL(p), G, gl, lane, half, goe, ge, score,
-                             HMODE == 1 && hand.store && p.hand && rho + 1 == plan.rounds ? p.hand + ((2u * q + (uint32_t)half) * p.hand_plane + osw_hand_sub(p.blocks[B], sigma, lg)) : nullptr); // (the block's entry read again: nothing of it is kept through the rounds for this)
+                             HMODE == 1 && rho + 1 == plan.rounds ? (half ? bnd : hand.region) + OSW_SCRATCH_DATA : nullptr);
     }
     // best over the strips = best over the lane groups (the lane index is laundered so that the permute
     // addresses are computed here instead of being kept in registers across all the rounds)
@@ -1372,7 +1351,8 @@ static __device__ __forceinline__ bool osw_frame_cell_takes(uint32_t cols, uint3
 // Main kernel: packed int16.
 // ---------------------------------------------------------------------------
 // C = the cell; CF = the cell for the blocks C cannot take (CF = C: none)
-template <class C, class CF, bool PAIR>
+// TC / TCF (query-pair kernels): the single-query cells that run the tails of SHORT pair items (OswSearchArgs::hand)
+template <class C, class CF, bool PAIR, class TC = C, class TCF = CF>
 static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8 + OSW_LDS_SKEW8]; // + one entry per lane group (fill_profile_slice)
@@ -1381,6 +1361,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
+    [[maybe_unused]] uint2 *hand_wave = PAIR && p.hand ? p.hand + (size_t)slot * p.bnd_stride : nullptr; // (null: the queue holds no SHORT item)
 
     // (-DOSW_DIAG: when each workgroup started, left phase 1 and finished, 100 MHz ticks)
     OSW_DIAG_STAMP(threadIdx.x == 0, blockIdx.x * 4 + 0);
@@ -1442,45 +1423,58 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
             item = wave_items[it];
         }
         const uint32_t q = OSW_ITEM_Q(item.x), lg = OSW_ITEM_LG(item.x), sigma = OSW_ITEM_SIGMA(item.x);
-        uint32_t B = item.y & ~OSW_ITEM_WG_FLAG;
+        const uint32_t B = item.y & ~OSW_ITEM_WG_FLAG;
         set_wave_prio(OSW_ITEM_PRIO(item.x));
         uint2 *lds_region = shared ? &lds_prof[0][0] : lds_prof[wv];
-        // Tails (OswSearchArgs::hand).  A pair item whose pair has one hands the longer query's bottom row over, pass by pass; a tail
-        // item (single-query launch; it carries the geometry of the pair items that wrote beside its block index)
-        // starts from there, and what decides its cell is the PAIR items' geometry: both must have spoken the same representation.
-        OswHand hand = {false, 0u, 0u, false};
-        uint32_t lg_cell = lg;
-        if constexpr (PAIR) {
-            hand.store = OSW_ITEM_HALVES(item.x) == OSW_ITEM_SHORT; // (the planner's choice, chunk by chunk: tails pay on large chunks only)
-        } else {
-            if (p.hand && p.tail_pair[q]) {
-                hand.pair1 = p.tail_pair[q];
-                hand.lgp = lg_cell = B >> OSW_ITEM_TAIL_LG_SHIFT; // (a tail item carries the geometry of the pair items that wrote above its block index)
-                B &= (1u << OSW_ITEM_TAIL_LG_SHIFT) - 1u;
-            }
-        }
-        const bool tail = !PAIR && hand.pair1 != 0;
         const OswBlock blk = p.blocks[B];
         // the column-frame cell only takes blocks whose frame offset stays small (ArithI16S); the rest run on CF
-        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg_cell, (uint32_t)p.ge, p.goe_pk & 0xffffu);
-        hand.framed = C::kShifted && !cf_only;
-        // (two instantiations of the item code: the ordinary items run the one without any hand-over state -- kept through the rounds, that
-        // state costs the query-pair kernel 3 % on many-round items: registers it does not have -- the SHORT pair items / the tail items
-        // the other)
-        const bool special = PAIR ? hand.store : tail;
+        const bool cf_only = C::kShifted && !osw_frame_cell_takes(blk.ncols4 * 4u, lg, (uint32_t)p.ge, p.goe_pk & 0xffffu);
+        // Tails (OswSearchArgs::hand): a SHORT pair item runs the shorter query's rows as a pair -- its last rounds keep their bottom rows --
+        // and then the rest of the longer query on the single-query cell (TC / TCF), same wave, same sub-block, same geometry, same
+        // representation (what decides the cell, `cf_only`, is the same for both).
+        // (separate instantiations of the item code: the ordinary items run the one without any hand-over state -- kept through the rounds, that
+        // state costs the query-pair kernel 3 % on many-round items: registers it does not have)
+        bool shorty = false;
+        if constexpr (PAIR) shorty = OSW_ITEM_HALVES(item.x) == OSW_ITEM_SHORT; // (the planner's choice, item by item)
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
-            constexpr int HM = PAIR ? 1 : 2;
             v2s score;
-            if (cf_only) {
-                if (special) score = run_item<CF, true, HM>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, hand);
-                else score = run_item<CF, true, 0>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
-                if constexpr (PAIR) pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
-                else pk16_finish<typename CF::Arith>(p, tail ? p.tail_query[q] : q, B, blk, sigma, lg, lane, score, tail);
+            if constexpr (PAIR) {
+                const OswHand hand = {hand_wave, shorty ? (uint32_t)p.pair_rows[q] : 0u, (p.qlen[q] + 3u) / 4u, 0u}; // (pair_rows: only a launch with SHORT items has it)
+                if (cf_only) {
+                    if (shorty) score = run_item<CF, true, 1>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, hand);
+                    else score = run_item<CF, true, 0>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
+                    pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
+                } else {
+                    if (shorty) score = run_item<C, true, 1>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, hand);
+                    else score = run_item<C, true, 0>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
+                    pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
+                }
             } else {
-                if (special) score = run_item<C, true, HM>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, hand);
-                else score = run_item<C, true, 0>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
-                if constexpr (PAIR) pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
-                else pk16_finish<typename C::Arith>(p, tail ? p.tail_query[q] : q, B, blk, sigma, lg, lane, score, tail);
+                if (cf_only) {
+                    score = run_item<CF, true, 0>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
+                    pk16_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, score);
+                } else {
+                    score = run_item<C, true, 0>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
+                    pk16_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, score);
+                }
+            }
+        }
+        if constexpr (PAIR) {
+            // (wave-uniform, and for a workgroup item the same in its four waves: one entity, one geometry)
+            const uint32_t mt = shorty ? __builtin_amdgcn_readfirstlane((uint32_t)p.tail_len[q * OSW_TAIL_GEOMS + lg]) : 0u;
+            if (mt) {
+                const uint32_t ncols = __builtin_amdgcn_readfirstlane((uint32_t)p.sub_cols[(size_t)B * 128 + ((1u << lg) - 1u) + sigma]);
+                osw_merge_hand(bnd_wave, hand_wave, ncols, 64u >> lg, lane);
+                const OswHand th = {nullptr, mt, 0u, p.tail_off[q * OSW_TAIL_GEOMS + lg]};
+                const uint32_t qb = p.pair_q[2 * q + 1]; // the longer query of the pair: the row of the table the tail's scores belong to
+                v2s score;
+                if (cf_only) {
+                    score = run_item<TCF, true, 2>(p, p.tail_prof_fb, q, B, blk, sigma, lg, lane, 0, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, th);
+                    pk16_finish<typename TCF::Arith>(p, qb, B, blk, sigma, lg, lane, score, true);
+                } else {
+                    score = run_item<TC, true, 2>(p, p.tail_prof, q, B, blk, sigma, lg, lane, 0, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, th);
+                    pk16_finish<typename TC::Arith>(p, qb, B, blk, sigma, lg, lane, score, true);
+                }
             }
         }
         set_wave_prio(0);
@@ -1492,12 +1486,12 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 
 // Query pairs: `items` / `qlen` / `prof` / `prof_off` describe pairs (length = the longer query,
 // profile = packed (A, B) scores); pair_q maps a pair to its two query rows of the score table.
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true, CellPK16B, CellPK16B>(p); }
 
 // Column-frame cell (6.5 instructions per row) with the plain biased cell for the blocks it cannot take:
 // `prof` holds S + ge, goe_pk the gap OPEN penalty; prof_fb / goe_fb / ge_fb serve the plain cell.
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16(OswSearchArgs p) { pk16_body<CellPK16S, CellPK16B, false>(p); }
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true, CellPK16S, CellPK16B>(p); }
 
 // ---------------------------------------------------------------------------
 // The int32 re-run of ONE (query, sequence) on the TWELVE waves of a workgroup.  A sequence that reaches the int16 cells'

@@ -183,10 +183,6 @@ struct PinnedResidues {
 // devices 0 .. num_devices-1, or the list in OSWALD_DEVICE_IDS ("0,0": two context devices on one GPU; test hook)
 int bring_up(const Options &o, oswald_hip_ctx **ctx)
 {
-    // Tails (the library's way to spare a query pair its padding on large chunks: DESIGN 4) need hand-over planes -- 11.7 GB for twenty
-    // queries on 128-MiB chunks -- and making them costs 150 - 500 ms: a long-lived context gets that back at 1.7 ms per chunk search, a
-    // tool that searches a database once and leaves does not.  Off, unless the caller's environment says otherwise.
-    if (!getenv("OSWALD_HIP_PAIR_TAILS")) setenv("OSWALD_HIP_PAIR_TAILS", "0", 1);
     std::vector<int> ids;
     if (const char *e = getenv("OSWALD_DEVICE_IDS"))
         for (const char *p = e; *p;) { ids.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
@@ -364,7 +360,6 @@ int do_search_hybrid_static(Options &o)
     if (db.sequences_count < o.top) o.top = db.sequences_count;
     const int8_t *sm = oswald::submat_by_name(o.submat);
     std::vector<int32_t> scores(nq * row, 0);
-    check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space");
     check(oswald_hip_set_scoring(ctx, sm, o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
     auto padded = [&](uint64_t g0, uint64_t g1) { // padded residues of database groups [g0, g1)
@@ -533,11 +528,11 @@ int do_search_hybrid(Options &o)
     }
     const uint64_t host_min_groups = std::max<uint64_t>(1, (2 * (uint64_t)host_threads + nq - 1) / std::max<uint64_t>(nq, 1)); // >= two (group, query) cells per host thread
     std::vector<int32_t> scores(nq * row, 0); // the host's columns only
-    check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space");
-    {   // (the chunk slots too, before the clock: a piece is a run of groups of one chunk)
+    {   // the chunk slots BEFORE the clock, where the reference's hybrid driver creates its device buffers (HybridSearch.c:79-90, its clocks start at :124 /
+        // :633; fpga_search creates them behind its tick, FPGAsearch.c:80-96, and so does `-m 0` here): a piece is a run of groups of one chunk
         uint32_t mg = 0;
         for (const oswald::Chunk &c : db.chunks) mg = std::max<uint32_t>(mg, (uint32_t)c.n.size());
-        if (db.max_chunk_vD) check(oswald_hip_reserve_chunks(ctx, -1, db.max_chunk_vD, mg, (uint32_t)W, (uint32_t)nq, 3), "device work space");
+        if (db.max_chunk_vD) check(oswald_hip_reserve_chunks(ctx, -1, db.max_chunk_vD, mg, (uint32_t)W, (uint32_t)nq, 3), "device buffers");
     }
     check(oswald_hip_set_scoring(ctx, sm, o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
@@ -933,15 +928,18 @@ int do_search(Options &o)
     std::vector<int32_t> scores;
     if (!device_top) scores.assign(nq * db.vect_sequences_count * W, 0);
     std::vector<std::vector<int32_t>> tmp(o.num_devices);
-    check(oswald_hip_reserve(ctx, -1, db.sequences_db_max_length), "device work space"); // buffers sized before the clock starts, FPGAsearch.c:85-96
-    if (device_top)
-        for (unsigned d = 0; d < pieces.size(); ++d) { // ... the chunk slots' too: the largest piece of the device, one slot more than it keeps in flight
+    // (the device's own working memory -- the kernels' spill scratch -- exists since bring-up, like the FPGA kernel's on-chip buffers since
+    // init(); the buffers the reference creates INSIDE its clock -- queries, chunk arrays, profiles, scores: FPGAsearch.c:80, :85-96 --
+    // are made inside ours: reserve_slots below)
+    auto reserve_slots = [&] {
+        if (!device_top) return;
+        for (unsigned d = 0; d < pieces.size(); ++d) { // the largest piece of the device, one slot more than it keeps in flight
             uint64_t mb = 0;
             uint32_t mg = 0;
             for (const Piece &p : pieces[d]) { mb = std::max(mb, p.bytes); mg = std::max(mg, p.ngroups); }
-            if (mb) check(oswald_hip_reserve_chunks(ctx, (int)d, mb, mg, (uint32_t)W, (uint32_t)nq, (uint32_t)std::min<size_t>(pieces[d].size() + 1, 4)), "device work space");
+            if (mb) check(oswald_hip_reserve_chunks(ctx, (int)d, mb, mg, (uint32_t)W, (uint32_t)nq, (uint32_t)std::min<size_t>(pieces[d].size() + 1, 4)), "device buffers");
         }
-    lap("device work space");
+    };
 
     // OSWALD_DEBUG_REPEAT=n (with OSWALD_DEBUG_PHASES; measurement hook): the timed region is run n times; the report is the FIRST
     // pass's -- what a user gets --, the later passes (same process: clocks, caches, the runtime's queues warm) go to stderr
@@ -950,11 +948,13 @@ int do_search(Options &o)
     std::vector<std::vector<int32_t>> top_s(nq);
     std::vector<std::vector<uint64_t>> top_i(nq);
     for (int pass = 0; pass < passes; ++pass) {
-    if (pass > 0) { check(oswald_hip_wait(ctx, -1), "wait"); for (auto &v : top_s) v.clear(); for (auto &v : top_i) v.clear(); tp = dwalltime(); }
+    if (pass > 0) { check(oswald_hip_wait(ctx, -1), "wait"); check(oswald_hip_release_chunks(ctx, -1), "buffer release"); for (auto &v : top_s) v.clear(); for (auto &v : top_i) v.clear(); tp = dwalltime(); } // (a later pass creates its buffers again, like a new run)
     const double tick = dwalltime();
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
     lap("  scoring + queries");
+    reserve_slots();
+    lap("  device buffers (chunk slots)");
     if (device_top) {
         check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");
         // Round k = piece k of every device.  The uploads of a round are queued on all devices (they overlap), every

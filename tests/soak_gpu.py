@@ -33,8 +33,7 @@ for it in range(iters):
     sm = submat.load(mats[it % len(mats)])
     go, ge = int(rng.integers(0, 20)), int(rng.integers(0, 6))
     bits = [0, 16, 32, 8][(it // 3) % 4] if it % 3 == 2 else 0   # every third search in an explicit cell mode, 8-bit included
-    os.environ["OSWALD_HIP_TAIL_ITEMS"] = "0" if it % 2 else "1000"   # every other search with tail items whatever the chunk's size, the others without (read at set_scoring)
-    os.environ["OSWALD_HIP_TAIL_LG"] = ["-1", "0", "1"][(it // 2) % 3]   # ... over quarter / whole / half blocks
+    os.environ["OSWALD_HIP_PAIR_TAILS"] = ["2", "1", "0"][it % 3]   # every eligible pair item with its tail / the cost model's choice / padded pairs (read at set_scoring)
     ctx.set_scoring(sm, go, ge, bits)
     ctx.set_queries(a, m, ad)
     if h is None:

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert capi.load().oswald_hip_abi_version() == 4
+    assert capi.load().oswald_hip_abi_version() == 5
 
 
 def test_library_links_rccl():

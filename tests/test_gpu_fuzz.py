@@ -32,7 +32,7 @@ def cases(draw):
                 matrix=draw(st.sampled_from(submat.NAMES)), go=draw(st.integers(0, 40)), ge=ge,
                 W=draw(st.sampled_from([16, 32, 64, 128])), lg=draw(st.sampled_from([-1, -1, 0, 1, 2, 3, 4, 5, 6])),
                 wg=draw(st.sampled_from([-1, -1, 0, 1])), pairs=draw(st.sampled_from([0, 1, 2])), bits=draw(st.sampled_from([0, 16, 16, 32, 8, 8])),
-                homolog=draw(st.booleans()), tails=draw(st.booleans()), tail_lg=draw(st.sampled_from([-1, 0, 1, 2, 3])))   # tails: tail items whatever the chunk's size (the planner takes them on large chunks only)
+                homolog=draw(st.booleans()), tails=draw(st.sampled_from([0, 1, 2, 2])))   # tails: OSWALD_HIP_PAIR_TAILS (2: every eligible pair item runs its pair's tail, whatever the cost model says)
 
 
 # OSWALD_FUZZ_EXAMPLES=N widens the campaign (and un-derandomises it with OSWALD_FUZZ_SEED set)
@@ -55,15 +55,12 @@ def test_random_cases(hip_ctx, oracle, case):
     b, n, disp, _, _ = layout(L, R, O, case["W"], round_to=int(rng.choice([1, 4, 28])))
     sm = submat.load(case["matrix"])
     env = {"OSWALD_HIP_PAIRS": str(case["pairs"])}
-    if case["tails"]:
-        env["OSWALD_HIP_TAIL_ITEMS"] = "0"
-        if case["tail_lg"] >= 0:
-            env["OSWALD_HIP_TAIL_LG"] = str(case["tail_lg"])
+    env["OSWALD_HIP_PAIR_TAILS"] = str(case["tails"])
     if case["lg"] >= 0:
         env["OSWALD_HIP_FORCE_LG"] = str(case["lg"])
     if case["wg"] >= 0:
         env["OSWALD_HIP_FORCE_WG"] = str(case["wg"])
-    old = {k: os.environ.get(k) for k in ("OSWALD_HIP_PAIRS", "OSWALD_HIP_FORCE_LG", "OSWALD_HIP_FORCE_WG", "OSWALD_HIP_TAIL_ITEMS", "OSWALD_HIP_TAIL_LG")}
+    old = {k: os.environ.get(k) for k in ("OSWALD_HIP_PAIRS", "OSWALD_HIP_FORCE_LG", "OSWALD_HIP_FORCE_WG", "OSWALD_HIP_PAIR_TAILS")}
     try:
         for k in old:
             os.environ.pop(k, None)

@@ -323,38 +323,43 @@ def test_query_pairs(hip_ctx, oracle, lg, wg, monkeypatch):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("lg,wg", [(-1, -1), (0, 0), (1, 0), (3, 0), (2, 1), (4, 1), (6, 1)])
+@pytest.mark.parametrize("lg,wg", [(-1, -1), (0, 0), (1, 0), (3, 0), (4, 0), (2, 1), (4, 1), (6, 1)])
 @pytest.mark.parametrize("go,ge", [(10, 2), (3, 0)])
 def test_pair_tails(hip_ctx, oracle, lg, wg, go, ge, monkeypatch):
-    """Tails (round 5): a pair item marked SHORT runs the shorter query's rows; its last strips end on a row of the longer query
-    -- which row depends on the geometry -- and hand the bottom row over; the rest of the longer query is a single-query item that
-    starts from it.  Forced on (the planner takes tails on large chunks only), at every geometry of the pair items, for pairs whose
-    lengths differ by less than a strip, by several strips (a tail of several rounds) and not at all, with homologs of the longer
-    queries (alignments that cross the hand-over row) and with gap extend 0 (the plain cell on long blocks: no frames to convert)."""
+    """Tails: a pair item marked SHORT runs the shorter query's rows as a pair -- its last strips end on a row of the longer query,
+    which row depends on the geometry -- and then, in the same wave at the same geometry, the rest of the longer query on the
+    single-query cell, starting from the bottom rows the two passes left (pass 0 in the wave's hand region, pass 1 in place).
+    Forced on (OSWALD_HIP_PAIR_TAILS=2: every eligible item, whatever the cost model says), at every geometry of the items, wave and
+    workgroup items, for pairs whose lengths differ by less than a strip, by several strips (a tail of several rounds) and not at
+    all, with homologs of the longer queries (alignments that cross the hand-over row) and with gap extend 0 (the plain cell)."""
     monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
-    monkeypatch.setenv("OSWALD_HIP_TAIL_ITEMS", "0")
-    if ge == 0:
-        monkeypatch.setenv("OSWALD_HIP_TAIL_LG", "0" if lg < 3 else "1")   # tail items over whole / half blocks (default on a chunk this small: quarters)
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "2")
     if lg >= 0:
         monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
     if wg >= 0:
         monkeypatch.setenv("OSWALD_HIP_FORCE_WG", str(wg))
-    qs = synth.make_queries([5, 40, 64, 111, 200, 207, 300, 300, 350, 900, 33], seed=500 + lg)   # 5 pairs + one single
+    qs = synth.make_queries([5, 40, 64, 111, 200, 207, 300, 300, 350, 900], seed=500 + lg)   # five pairs, no single query (tails are planned for such sets)
     L, R, O = random_db(300, seed=510 + lg, max_len=140, queries=[qs[3], qs[5], qs[9], qs[9][500:]], homologs=3)
     b, n, disp, _, _ = layout(L, R, O, 16)
     sm = submat.load("blosum62")
     got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge)
     want = expect(oracle, qs, b, n, disp, 16, sm, go, ge)
     np.testing.assert_array_equal(got, want)
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "1")            # ... the cost model's choice, item by item
+    np.testing.assert_array_equal(run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge), want)
     monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "0")            # ... and the same table with padded pairs
     np.testing.assert_array_equal(run_gpu(hip_ctx, qs, b, n, disp, 16, sm, go, ge), want)
+    # a set with a single query beside its pairs keeps its padded pairs (the hand regions are that launch's half of the scratch)
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "2")
+    qs1 = qs + synth.make_queries([33], seed=77)
+    np.testing.assert_array_equal(run_gpu(hip_ctx, qs1, b, n, disp, 16, sm, go, ge), expect(oracle, qs1, b, n, disp, 16, sm, go, ge))
 
 
 def test_pair_tails_over_the_int16_ceiling(hip_ctx, oracle, monkeypatch):
     """The longer query of a pair reaches the int16 cells' ceiling in its TAIL rows only (all-W: 11 per cell; 2 000 rows of the pair
-    + 1 000 of the tail): the tail item queues the sequence for the int32 re-run like any other item."""
+    + 1 000 of the tail): the tail queues the sequence for the int32 re-run like any other item."""
     monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
-    monkeypatch.setenv("OSWALD_HIP_TAIL_ITEMS", "0")
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "2")
     w = synth.ALPHABET.index("W")
     qa, qb = np.full(2000, w, np.uint8), np.full(3000, w, np.uint8)
     seqs = [np.full(k, w, np.uint8) for k in (5, 1990, 2500, 3000)] + [synth.random_residues(3, 0, 300)]
@@ -365,6 +370,33 @@ def test_pair_tails_over_the_int16_ceiling(hip_ctx, oracle, monkeypatch):
     want = expect(oracle, [qa, qb], b, n, disp, 16, sm, 10, 2)
     np.testing.assert_array_equal(got, want)
     assert want[1].max() == 33000 and hip_ctx.rerun_counts()[1] >= 1
+
+
+@pytest.mark.parametrize("lg", [-1, 0, 2])
+def test_pair_tails_at_the_frame_limit(hip_ctx, oracle, lg, monkeypatch):
+    """blocks whose column count lies at the column-frame cell's limit ((columns + 2 G + 2) x ge <= 8192: ~4 090 columns
+    at ge = 2), with tails and a high-scoring homolog of the longer query at the far end of such a sequence.  Pair item and tail run
+    at ONE geometry in one wave and take their cell -- column frames or plain -- from the same test, so what the pair hands over is
+    in the representation the tail goes on in, on either side of the limit."""
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "2")
+    if lg >= 0:
+        monkeypatch.setenv("OSWALD_HIP_FORCE_LG", str(lg))
+    qs = synth.make_queries([180, 260], seed=901)
+    rng = np.random.default_rng(902)
+    seqs = [synth.random_residues(9000 + i, 0, int(l)) for i, l in enumerate(rng.integers(4060, 4100, size=40))]
+    seqs += [synth.random_residues(9100 + i, 0, int(l)) for i, l in enumerate(rng.integers(3900, 4060, size=20))]
+    for k in (3, 17, 44):
+        mut = synth.mutate(qs[1], 0.03, 900 + k)                                    # near-copies of the LONGER query, at the end of the block
+        seqs[k][-len(mut):] = mut
+    seqs[29][:len(qs[0])] = qs[0]
+    L, R, O = db_from_sequences(seqs)
+    b, n, disp, _, _ = layout(L, R, O, 16)
+    sm = submat.load("blosum62")
+    got = run_gpu(hip_ctx, qs, b, n, disp, 16, sm, 10, 2)
+    want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
+    np.testing.assert_array_equal(got, want)
+    assert want[1].max() > 1000
 
 
 def test_query_pairs_overflow_rerun(hip_ctx, oracle, monkeypatch):
