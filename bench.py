@@ -483,6 +483,8 @@ def pcie_inclusive(ctx, chunks, nq, sum_m, d_local, pinned, steps):
                     hs.append(ctx.chunk_upload(*bufs[j], 16, wait=False))
             ctx.chunk_release(hs[k])                     # last: returns when the chunk's upload has landed; the slot is re-used once the device is through with it
 
+    if slot_bytes:      # host staging of the slots: before the clock, like the reference's posix_memalign (FPGAsearch.c:69-74)
+        ctx.reserve_host(slot_groups, 16, nq, min(len(bufs) + 1, 4))
     one_pass()          # untimed: first DMA through the host buffers
     ctx.wait()
     ctx.release_chunks()

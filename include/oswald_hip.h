@@ -151,18 +151,23 @@ int oswald_hip_chunk_upload_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b
  * sure the scratch holds blocks of max_sequence_length residues (it does) and returns. */
 int oswald_hip_reserve(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_length);
 
-/* Optional: the device buffers of `slots` chunk slots (staging copy, re-tiled residues, block tables, and -- with nq > 0 --
- * score table, re-run queue and work queues for a set of nq queries) for chunks of up to chunk_bytes bytes in ngroups groups of
- * lane_width sequences, on device dev (dev < 0: all), allocated in ONE place instead of by the first uploads and searches as
- * they come.  This is the reference's buffer creation -- its six device buffers, sized for the largest chunk, created once per
- * search INSIDE its timed region and re-used for every chunk (FPGAsearch.c:80, :85-96) -- and a caller that mirrors the
- * reference's clock calls it inside its own (the command-line tool and bench.py's `inclusive` leg do).  A hint only: a chunk that
- * needs more grows its slot as before. */
+/* Optional: the buffers of `slots` chunk slots for chunks of up to chunk_bytes bytes in ngroups groups of lane_width sequences, on
+ * device dev (dev < 0: all), made in ONE place instead of by the first uploads and searches as they come.  Two kinds, as in the
+ * reference: the slots' page-locked HOST staging (work queues, live extents, block tables, copies of n[] / disp[]) -- the
+ * reference allocates its host buffers, aligned for DMA, BEFORE its clock starts (posix_memalign, FPGAsearch.c:69-74; tick at
+ * :80) -- and their DEVICE buffers (staging copy, re-tiled residues, block tables, and -- with nq > 0 -- score table and re-run
+ * queue for a set of nq queries) -- the reference creates its six device buffers, sized for the largest chunk, once per search
+ * INSIDE its timed region and re-uses them for every chunk (clCreateBuffer, FPGAsearch.c:85-96).
+ * oswald_hip_reserve_host makes the former only; oswald_hip_reserve_chunks makes whatever of both is not there yet.  A caller that
+ * mirrors the reference's clock (the command-line tool's -m 0, bench.py's `inclusive` leg) calls _reserve_host before its clock
+ * and _reserve_chunks inside.  Hints only: a chunk that needs more grows its slot as before. */
+int oswald_hip_reserve_host(oswald_hip_ctx *ctx, int dev, uint32_t ngroups, uint32_t lane_width, uint32_t nq, uint32_t slots);
 int oswald_hip_reserve_chunks(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t lane_width,
                               uint32_t nq, uint32_t slots);
 
-/* ... and the reverse: the buffers of every chunk slot of device dev (dev < 0: all) that holds no chunk are given back (the
- * reference releases its buffers at the end of a search, FPGAsearch.c:361-368).  Waits for the device. */
+/* ... and the reverse of the device part: the DEVICE buffers of every chunk slot of device dev (dev < 0: all) that holds no chunk
+ * are given back (the reference releases its cl_mem objects at the end of a search, FPGAsearch.c:361-368; its host buffers live
+ * on).  Waits for the device. */
 int oswald_hip_release_chunks(oswald_hip_ctx *ctx, int dev);
 
 /* The largest chunk -- in bytes of b, i.e. padded residues, the unit of the command line's -k -- device dev can hold for

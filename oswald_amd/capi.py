@@ -29,7 +29,7 @@ SYMBOLS = (
     "oswald_hip_comm_unique_id", "oswald_hip_comm_init_rank", "oswald_hip_comm_info", "oswald_hip_max_chunk_size",
     "oswald_hip_host_alloc", "oswald_hip_host_free", "oswald_hip_rerun_stats",
     "oswald_hip_host_register", "oswald_hip_host_unregister", "oswald_hip_comm_destroy", "oswald_hip_reserve_chunks",
-    "oswald_hip_chunk_wait", "oswald_hip_release_chunks",
+    "oswald_hip_chunk_wait", "oswald_hip_release_chunks", "oswald_hip_reserve_host",
 )
 COMM_ID_BYTES = 128   # OSWALD_HIP_COMM_ID_BYTES
 
@@ -64,6 +64,7 @@ def load():
     lib.oswald_hip_reserve.argtypes = [vp, i32, u32]
     lib.oswald_hip_reserve_chunks.argtypes = [vp, i32, u64, u32, u32, u32, u32]
     lib.oswald_hip_release_chunks.argtypes = [vp, i32]
+    lib.oswald_hip_reserve_host.argtypes = [vp, i32, u32, u32, u32, u32]
     lib.oswald_hip_rerun_counts.argtypes = [vp, i32, C.POINTER(u64)]
     lib.oswald_hip_chunk_search.argtypes = [vp, i32, i32, vp]
     lib.oswald_hip_chunk_release.argtypes = [vp, i32, i32]
@@ -242,6 +243,10 @@ class Context:
 
     def reserve_chunks(self, chunk_bytes: int, ngroups: int, lane_width: int = 16, nq: int = 0, slots: int = 3, dev: int = -1):
         _chk(self.lib.oswald_hip_reserve_chunks(self.h, dev, chunk_bytes, ngroups, lane_width, nq, slots))
+
+    def reserve_host(self, ngroups: int, lane_width: int = 16, nq: int = 0, slots: int = 3, dev: int = -1):
+        """The slots' page-locked host staging only (before a caller's clock; reserve_chunks inside it makes the device buffers)."""
+        _chk(self.lib.oswald_hip_reserve_host(self.h, dev, ngroups, lane_width, nq, slots))
 
     def release_chunks(self, dev: int = -1):
         """Gives the buffers of every chunk slot that holds no chunk back (waits for the device)."""

@@ -86,7 +86,7 @@ struct Tunables {
     bool no_direct_table = false;      // OSWALD_HIP_NO_DIRECT_TABLE=1 (A/B and test hook): score tables leave by DMA on the download stream even when the kernels could write them
     size_t fake_free_mem = 0;          // OSWALD_HIP_FAKE_FREE_MEM=bytes: oswald_hip_max_chunk_size reckons with a device that has no more free (test hook)
     int pair_tails = 1;                // OSWALD_HIP_PAIR_TAILS=0|1|2: the rows a pair's longer query has beyond the shorter one's are padded (0: rounds 1-4) / run as the pair item's TAIL on the single-query cell where the cost model says so (1) / always (2: test hook)
-    double warm_ms = 0.0;              // OSWALD_HIP_WARM_MS=ms: oswald_hip_reserve_chunks ends with every CU of the device busy for that long (experiment: clock ramp before a first search)
+    double warm_ms = 250.0;            // OSWALD_HIP_WARM_MS=ms: how long at most oswald_hip_init keeps the devices busy behind itself (0: not at all); see Device::warm_stop
     size_t split_bytes = 32u << 20;    // OSWALD_HIP_SPLIT_BYTES=bytes: from this size on an asynchronous upload that finds its device idle is cut into head + rest (0: never; a small value: test hook)
     // planner parameters: constants in the default build, OSWALD_HIP_* sweep knobs with -DOSW_DIAG
     double pair_margin = 0.95, col_cost = 10.0, target_div = 1.25, quad_frac = 0.5, entries_per_wg = 4.0;
@@ -117,7 +117,7 @@ void Tunables::refresh()
     no_direct_table = flag("OSWALD_HIP_NO_DIRECT_TABLE");
     fake_free_mem = (size_t)num("OSWALD_HIP_FAKE_FREE_MEM", 0);
     split_bytes = (size_t)num("OSWALD_HIP_SPLIT_BYTES", (double)(32u << 20));
-    warm_ms = num("OSWALD_HIP_WARM_MS", 0.0);
+    warm_ms = std::min(num("OSWALD_HIP_WARM_MS", 250.0), 2000.0);
     pair_tails = (int)num("OSWALD_HIP_PAIR_TAILS", 1);
     g_debug_slow = flag("OSWALD_HIP_DEBUG_SLOW");
     g_fail_alloc_above = (size_t)num("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE", 0);
@@ -358,6 +358,16 @@ struct Device {
     ncclComm_t comm = nullptr;       // leader, when the context spans more than one GPU
     double dp_ms = 0, rerun16_ms = 0, rerun32_ms = 0;
     uint64_t dp_launches = 0, rerun_items = 0;
+    // The warm-up (round 6).  A GPU that has had nothing to do runs its first kernels at low clocks: the first search of a PROCESS took
+    // 1.2 ms longer than the same search a moment later (one 375-residue query against 1 M sequences: 15.0 against 13.8 ms on the
+    // device, profiles/r05_cli_q1_1m_phases.txt) -- and every run of the command-line tool is a first search.  oswald_hip_init
+    // therefore ends by starting a kernel that keeps every CU busy on a stream of its own (osw_spin), BEHIND the bring-up and
+    // beside whatever the caller does next before its clock starts (the tool: loading and page-locking the database); the first call
+    // that gives the device real work -- queries, buffers, a chunk -- tells it to stop (a word in page-locked memory the kernel
+    // polls: it is gone some 20 us later), and it stops by itself after Tunables::warm_ms.  OSWALD_HIP_WARM_MS=0: no warm-up.
+    hipStream_t stream_warm = nullptr;
+    uint32_t *warm_stop = nullptr;   // page-locked; *warm_stop = 1: leave
+    bool warm_running = false;
 };
 
 } // namespace
@@ -425,6 +435,13 @@ int offset8_of(const oswald_hip_ctx *ctx)
     return c <= 64 ? c : -1;
 }
 bool first_pass_is_q8(const oswald_hip_ctx *ctx) { return ctx->cell_bits == 8 && offset8_of(ctx) >= 0; }
+
+// the first real work of a context ends the warm-up its bring-up started (Device::warm_stop)
+void stop_warm(oswald_hip_ctx *ctx)
+{
+    for (Device &d : ctx->dev)
+        if (d.warm_running) { *(volatile uint32_t *)d.warm_stop = 1u; d.warm_running = false; }
+}
 
 int check_dev(oswald_hip_ctx *ctx, int dev)
 {
@@ -830,6 +847,19 @@ static int init_impl(int ndev, const int *device_ids, oswald_hip_ctx **out)
         }
         for (Device &d : ctx->dev) if (d.comm_rank >= 0) d.comm = comms[d.comm_rank];
     }
+    if (ctx->tun.warm_ms > 0) {
+        for (Device &d : ctx->dev) {
+            if (&ctx->dev[d.leader] != &d) continue; // (one per GPU)
+            hipError_t r = hipSetDevice(d.id);
+            if (r == hipSuccess) r = hipHostMalloc((void **)&d.warm_stop, 64, hipHostMallocPortable);
+            if (r == hipSuccess) { *d.warm_stop = 0u; r = hipStreamCreateWithFlags(&d.stream_warm, hipStreamNonBlocking); }
+            void *dp = nullptr;
+            if (r == hipSuccess) r = hipHostGetDevicePointer(&dp, d.warm_stop, 0);
+            if (r == hipSuccess) r = osw_launch_spin((uint32_t *)d.counters.p, d.grid, ctx->tun.warm_ms, (const uint32_t *)dp, d.stream_warm);
+            if (r == hipSuccess) d.warm_running = true;
+            else (void)hipGetLastError(); // (a warm-up that cannot be started is no reason to fail the bring-up)
+        }
+    }
     *out = ctx;
     return 0;
 }
@@ -837,8 +867,11 @@ static int init_impl(int ndev, const int *device_ids, oswald_hip_ctx **out)
 static int finalize_impl(oswald_hip_ctx *ctx)
 {
     if (!ctx) return 0;
+    stop_warm(ctx);
     for (Device &d : ctx->dev) {
         (void)hipSetDevice(d.id);
+        if (d.stream_warm) { (void)hipStreamSynchronize(d.stream_warm); (void)hipStreamDestroy(d.stream_warm); d.stream_warm = nullptr; }
+        if (d.warm_stop) { (void)hipHostFree(d.warm_stop); d.warm_stop = nullptr; }
         for (hipStream_t st : {d.stream, d.stream2, d.stream_copy, d.stream_up, d.stream_down}) if (st) (void)hipStreamSynchronize(st);
         release_registered(d);
         if (d.stream2) (void)hipStreamSynchronize(d.stream2);
@@ -913,6 +946,7 @@ static int set_scoring_impl(oswald_hip_ctx *ctx, const int8_t *submat, int open_
 {
     if (!ctx || !submat) return fail(OSWALD_HIP_EINVAL, "null argument");
     if (open_gap < 0 || extend_gap < 0) return fail(OSWALD_HIP_EINVAL, "gap penalties must be >= 0");
+    stop_warm(ctx);
     if (open_gap + extend_gap > 32767) return fail(OSWALD_HIP_EINVAL, "open+extend must fit int16");
     // The reference's matrices are 24 rows x 32 columns with zeros in column 23 (the dummy residue) and in the padding columns 24..31
     // (host/src/submat.c), and its preprocessing emits the codes 0..23 only.  The single-query kernels keep 24 entries per profile
@@ -941,6 +975,7 @@ static int set_queries_impl(oswald_hip_ctx *ctx, const uint8_t *a, uint64_t Q, c
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (nq > 0 && (!m || !a_disp || (Q > 0 && !a))) return fail(OSWALD_HIP_EINVAL, "null query arrays");
+    stop_warm(ctx);
     if (nq > 65535) return fail(OSWALD_HIP_EINVAL, "at most 65535 queries per set (work items carry a 16-bit query index); search in several sets");
     for (uint32_t q = 0; q < nq; ++q)
         if ((uint64_t)a_disp[q] + m[q] > Q) return fail(OSWALD_HIP_EINVAL, "query %u runs past the residue buffer (disp %u + len %u > %llu)", q, a_disp[q], m[q], (unsigned long long)Q);
@@ -1141,6 +1176,7 @@ static int upload_pieces(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_
     if (ngroups > 0 && (!b || !n || !disp)) return fail(OSWALD_HIP_EINVAL, "null chunk arrays");
     Device &d = ctx->dev[dev];
     HIP_TRY(hipSetDevice(d.id));
+    stop_warm(ctx);
     // The first chunk of a search is what nothing can hide: its copy (2.3 ms per 128 MiB over PCIe Gen5), its re-tile and the
     // plan of its search all happen before the device has anything to do.  An asynchronous upload of some size that finds its
     // device idle is therefore cut into a HEAD of whole 128-sequence blocks and the REST: the head is in the device after a
@@ -1226,7 +1262,8 @@ static int reserve_impl(oswald_hip_ctx *ctx, int dev, uint32_t max_sequence_leng
 // caller's clock starts -- instead of by the first uploads and searches: mapping a few hundred MB of device memory takes
 // milliseconds (20 ms per GB on the round-5 box: 9 ms of a 27-ms one-query search at 1 M sequences went into the first
 // upload's allocations).  A hint: a chunk that needs more grows its slot as before.
-static int reserve_chunks_impl(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
+// what: 1 = the slots' page-locked HOST staging (work queues, live extents, block table, n[] / disp[]), 2 = their DEVICE buffers
+static int reserve_slots(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots, int what)
 {
     if (!ctx) return fail(OSWALD_HIP_EINVAL, "null context");
     if (dev >= (int)ctx->dev.size()) return fail(OSWALD_HIP_ENODEV, "device index %d out of range", dev);
@@ -1234,6 +1271,7 @@ static int reserve_chunks_impl(oswald_hip_ctx *ctx, int dev, uint64_t chunk_byte
     if (chunk_bytes > 0xfff00000ull) return fail(OSWALD_HIP_EINVAL, "a chunk holds at most %llu bytes", 0xfff00000ull);
     slots = std::min<uint32_t>(slots, OSW_MAX_SLOTS);
     const uint32_t gpb = OSW_BLOCK_SEQS / W, nblocks = (ngroups + gpb - 1) / gpb;
+    if (what & 2) stop_warm(ctx); // (the host staging is made before a caller's clock starts: the warm-up goes on beside it)
     for (int i = 0; i < (int)ctx->dev.size(); ++i) {
         if (dev >= 0 && i != dev) continue;
         Device &d = ctx->dev[i];
@@ -1245,56 +1283,75 @@ static int reserve_chunks_impl(oswald_hip_ctx *ctx, int dev, uint64_t chunk_byte
             Chunk &c = d.chunks[k];
             if (c.live || c.upload_pending) continue;
             ++made;
-            // re-tiled residues: a byte per residue of every block padded to its longest group (sorted databases: ~1.02 x the chunk)
-            // + the all-dummy column groups around every block
-            const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
-            HIP_TRY(c.tiled.reserve(col4 * 64 * sizeof(uint2)));
-            HIP_TRY(c.blocks.reserve(nblocks * sizeof(OswBlock) + 16));
-            HIP_TRY(c.sub_cols_buf.reserve((size_t)nblocks * 128 * sizeof(uint16_t) + 16));
-            HIP_TRY(c.st_b.reserve(chunk_bytes + 64));
-            HIP_TRY(c.nd_pin.reserve((size_t)ngroups * 6 + 192));
-            if ((size_t)nblocks * 128 > c.sub_cols_cap) {
-                if (c.sub_cols) HIP_TRY(hipHostFree(c.sub_cols));
-                c.sub_cols = nullptr;
-                c.sub_cols_cap = 0;
-                const size_t want = (size_t)nblocks * 128 + (size_t)nblocks * 16 + 128;
-                HIP_TRY(hipHostMalloc((void **)&c.sub_cols, want * sizeof(uint16_t), hipHostMallocPortable));
-                c.sub_cols_cap = want;
-            }
-            if (nblocks > c.blocks_pin_cap) {
-                if (c.blocks_pin) HIP_TRY(hipHostFree(c.blocks_pin));
-                c.blocks_pin = nullptr;
-                c.blocks_pin_cap = 0;
-                const size_t want = (size_t)nblocks + nblocks / 8 + 16;
-                HIP_TRY(hipHostMalloc((void **)&c.blocks_pin, want * sizeof(OswBlock), hipHostMallocPortable));
-                c.blocks_pin_cap = want;
-            }
-            if (nq > 0) {
-                HIP_TRY(c.scores.reserve((size_t)nq * nblocks * OSW_BLOCK_SEQS * sizeof(int32_t) + 16));
-                HIP_TRY(c.ovf.reserve((size_t)nq * nblocks * 128 * sizeof(uint2) + 16));
-                // work queues (page-locked host memory): an entry of 8 B per (entity, sub-block) -- a few per block and query
-                const size_t entries = (size_t)nblocks * (nq + 1) * 16 + 4096;
-                for (int set = 0; set < 2; ++set) {
-                    if (entries > c.items_pin_cap[set]) {
-                        if (c.items_pin[set]) HIP_TRY(hipHostFree(c.items_pin[set]));
-                        c.items_pin[set] = nullptr;
-                        c.items_pin_cap[set] = 0;
-                        HIP_TRY(hipHostMalloc((void **)&c.items_pin[set], entries * sizeof(uint2), hipHostMallocPortable));
-                        c.items_pin_cap[set] = entries;
-                    }
+            if (what & 2) {
+                // re-tiled residues: a byte per residue of every block padded to its longest group (sorted databases: ~1.02 x the chunk)
+                // + the all-dummy column groups around every block
+                const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
+                HIP_TRY(c.tiled.reserve(col4 * 64 * sizeof(uint2)));
+                HIP_TRY(c.blocks.reserve(nblocks * sizeof(OswBlock) + 16));
+                HIP_TRY(c.sub_cols_buf.reserve((size_t)nblocks * 128 * sizeof(uint16_t) + 16));
+                HIP_TRY(c.st_b.reserve(chunk_bytes + 64));
+                if (nq > 0) {
+                    HIP_TRY(c.scores.reserve((size_t)nq * nblocks * OSW_BLOCK_SEQS * sizeof(int32_t) + 16));
+                    HIP_TRY(c.ovf.reserve(((size_t)nq * nblocks * 128 + (size_t)(nq / 2) * nblocks * 64) * sizeof(uint2) + 16));
                 }
             }
-            if (!c.ev_up) HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
-            if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
-            if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
-            if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
-        }
-        if (ctx->tun.warm_ms > 0) {
-            HIP_TRY(osw_launch_spin((uint32_t *)d.counters.p, d.grid, std::min(ctx->tun.warm_ms, 50.0), d.stream));
-            HIP_TRY(hipStreamSynchronize(d.stream));
+            if (what & 1) {
+                HIP_TRY(c.nd_pin.reserve((size_t)ngroups * 6 + 192));
+                if ((size_t)nblocks * 128 > c.sub_cols_cap) {
+                    if (c.sub_cols) HIP_TRY(hipHostFree(c.sub_cols));
+                    c.sub_cols = nullptr;
+                    c.sub_cols_cap = 0;
+                    const size_t want = (size_t)nblocks * 128 + (size_t)nblocks * 16 + 128;
+                    HIP_TRY(hipHostMalloc((void **)&c.sub_cols, want * sizeof(uint16_t), hipHostMallocPortable));
+                    c.sub_cols_cap = want;
+                }
+                if (nblocks > c.blocks_pin_cap) {
+                    if (c.blocks_pin) HIP_TRY(hipHostFree(c.blocks_pin));
+                    c.blocks_pin = nullptr;
+                    c.blocks_pin_cap = 0;
+                    const size_t want = (size_t)nblocks + nblocks / 8 + 16;
+                    HIP_TRY(hipHostMalloc((void **)&c.blocks_pin, want * sizeof(OswBlock), hipHostMallocPortable));
+                    c.blocks_pin_cap = want;
+                }
+                if (nq > 0) {
+                    // work queues: an entry of 8 B per (entity, sub-block) -- a few per block and query
+                    const size_t entries = (size_t)nblocks * (nq + 1) * 16 + 4096;
+                    for (int set = 0; set < 2; ++set) {
+                        if (entries > c.items_pin_cap[set]) {
+                            if (c.items_pin[set]) HIP_TRY(hipHostFree(c.items_pin[set]));
+                            c.items_pin[set] = nullptr;
+                            c.items_pin_cap[set] = 0;
+                            HIP_TRY(hipHostMalloc((void **)&c.items_pin[set], entries * sizeof(uint2), hipHostMallocPortable));
+                            c.items_pin_cap[set] = entries;
+                        }
+                    }
+                }
+                if (!c.ev_up) HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
+                if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
+                if (!c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&c.ev_copy, hipEventDisableTiming));
+                if (!c.ev_down) HIP_TRY(hipEventCreateWithFlags(&c.ev_down, hipEventDisableTiming));
+            }
         }
     }
     return 0;
+}
+
+// The buffers of `slots` chunk slots for chunks of up to chunk_bytes bytes in ngroups groups, made in one place instead of by the
+// first uploads and searches as they come.  The reference does this in two places: its HOST buffers -- the score tables and the
+// profiles' staging, page-aligned for DMA -- before its clock starts (posix_memalign, FPGAsearch.c:69-74, tick at :80), its six
+// DEVICE buffers behind the tick (clCreateBuffer, :85-96).  oswald_hip_reserve_host is the former: the slots' page-locked staging
+// (work queues, live extents, block tables, copies of n[] / disp[]: pinning host pages costs ~0.15 ms per MB, tools/alloc_probe.hip);
+// oswald_hip_reserve_chunks makes both -- whatever is not there yet: a caller that mirrors the reference's clock calls _host
+// before it and _chunks inside (device memory: microseconds per buffer on this runtime).  Hints: a chunk that needs more grows its slot.
+static int reserve_chunks_impl(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
+{
+    return reserve_slots(ctx, dev, chunk_bytes, ngroups, W, nq, slots, 3);
+}
+
+static int reserve_host_impl(oswald_hip_ctx *ctx, int dev, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
+{
+    return reserve_slots(ctx, dev, 0, ngroups, W, nq, slots, 1);
 }
 
 // Device memory one byte of chunk (one padded residue of the interleaved groups) takes, worst case, for each of the
@@ -1674,8 +1731,8 @@ static int search_chunk_async_impl(oswald_hip_ctx *ctx, int dev, const uint8_t *
     return r;
 }
 
-// The reverse of oswald_hip_reserve_chunks: the buffers of every chunk slot that holds no chunk go back to the device and the
-// host (the reference releases its six buffers at the end of a search, FPGAsearch.c:361-368, and creates them again inside the
+// The reverse of oswald_hip_reserve_chunks' device part: the DEVICE buffers of every chunk slot that holds no chunk go back to the device
+// (the reference releases its six buffers at the end of a search, FPGAsearch.c:361-368, and creates them again inside the
 // next search's clock, :85-96).  Waits for the device first: a released slot's last search may still be running.
 static int release_chunks_impl(oswald_hip_ctx *ctx, int dev)
 {
@@ -1691,13 +1748,9 @@ static int release_chunks_impl(oswald_hip_ctx *ctx, int dev)
             c.upload_pending = c.use_pending = c.down_pending = c.map_pending = false;
             c.set_read_pending[0] = c.set_read_pending[1] = false;
             if (c.live) continue;
+            // (the DEVICE buffers: the slot's page-locked host staging stays, like the reference's host buffers, which outlive its device
+            // buffers -- FPGAsearch.c:361-368 releases the cl_mem objects only)
             for (DevBuf *b : {&c.tiled, &c.blocks, &c.sub_cols_buf, &c.scores, &c.ovf, &c.ovf8, &c.st_b, &c.index_map_dev[0], &c.index_map_dev[1]}) b->release();
-            c.nd_pin.release(); c.map_pin[0].release(); c.map_pin[1].release();
-            if (c.sub_cols) (void)hipHostFree(c.sub_cols);
-            c.sub_cols = nullptr; c.sub_cols_cap = 0;
-            if (c.blocks_pin) (void)hipHostFree(c.blocks_pin);
-            c.blocks_pin = nullptr; c.blocks_pin_cap = 0;
-            for (int k = 0; k < 2; ++k) { if (c.items_pin[k]) (void)hipHostFree(c.items_pin[k]); c.items_pin[k] = nullptr; c.items_pin_cap[k] = 0; }
             c.items_version = ~0ull;
             c.searched = false;
         }
@@ -2200,6 +2253,11 @@ int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk)
 int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_t vD, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W, int32_t *scores_out)
 {
     return guarded("oswald_hip_search_chunk_async", [&] { return search_chunk_async_impl(ctx, dev, b, vD, n, disp, ngroups, W, scores_out); });
+}
+
+int oswald_hip_reserve_host(oswald_hip_ctx *ctx, int dev, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
+{
+    return guarded("oswald_hip_reserve_host", [&] { return reserve_host_impl(ctx, dev, ngroups, W, nq, slots); });
 }
 
 int oswald_hip_release_chunks(oswald_hip_ctx *ctx, int dev)

@@ -210,7 +210,7 @@ hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s); 
 // the int32 cell's floor table, built on the device: t[k] = {k * ge, k * ge}, k < n
 hipError_t osw_launch_floor_i32(uint2 *t, uint32_t n, uint32_t ge, hipStream_t s);
 hipError_t osw_launch_copy16(const void *src_host_pinned, void *dst, size_t bytes, hipStream_t s); // page-locked host -> device by a kernel that reads the host buffer in place
-hipError_t osw_launch_spin(uint32_t *sink, uint32_t grid, double ms, hipStream_t s); // every CU busy for `ms` (clock ramp before a first search)
+hipError_t osw_launch_spin(uint32_t *sink, uint32_t grid, double ms, const uint32_t *stop_host_pinned, hipStream_t s); // every CU busy for `ms`, or until *stop_host_pinned != 0 (the warm-up of oswald_hip_init: clocks up before a first search)
 hipError_t osw_warm_aux_kernels(hipStream_t s); // first launches of the profile / top-list kernels (bring-up)
 hipError_t osw_launch_retile(const uint8_t *b, const uint16_t *n, const uint32_t *disp, uint32_t ngroups, uint32_t W,
                              OswBlock *blocks, uint32_t nblocks, uint16_t *tiled, uint16_t *sub_cols, hipStream_t s);

@@ -1752,15 +1752,22 @@ extern "C" __global__ __launch_bounds__(256) void osw_floor_i32(uint2 *__restric
     for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) t[k] = make_uint2(k * ge, k * ge);
 }
 
-// keeps every CU issuing vector instructions for `ticks` of the 100-MHz clock (oswald_hip_reserve_chunks: see osw_launch_spin)
-extern "C" __global__ __launch_bounds__(256) void osw_spin(uint32_t *sink, uint64_t ticks)
+// keeps every CU issuing vector instructions for `ticks` of the 100-MHz clock, or until the host says stop (*stop != 0: a word in
+// page-locked host memory, looked at by one lane per workgroup every ~15 us and passed on through LDS; null: never).  Every wave
+// leaves by itself -- on the clock at the latest --, nothing waits for anything (osw_launch_spin: the warm-up of oswald_hip_init).
+extern "C" __global__ __launch_bounds__(256) void osw_spin(uint32_t *sink, uint64_t ticks, const uint32_t *stop)
 {
     OSW_SEARCH_SHAPED_VGPRS();
+    __shared__ uint32_t quit;
+    if (threadIdx.x == 0) quit = 0u;
+    __syncthreads();
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    uint32_t x = threadIdx.x, y = blockIdx.x;
+    uint32_t x = threadIdx.x, y = blockIdx.x, it = 0;
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
 #pragma unroll
         for (int k = 0; k < 64; ++k) { x = x * 1664525u + y; y = (y ^ x) + 1013904223u; }
+        if ((++it & 63u) == 0u && threadIdx.x == 0 && stop && *(const volatile uint32_t *)stop) *(volatile uint32_t *)&quit = 1u;
+        if (*(volatile uint32_t *)&quit) break;
     }
     if (x == 0x12345678u && y == 0x9abcdef0u) *sink = x; // (never: keeps the loop)
 }
@@ -2241,9 +2248,9 @@ hipError_t osw_launch_fill(void *p, uint8_t byte, size_t bytes, hipStream_t s)
     return hipSuccess;
 }
 
-hipError_t osw_launch_spin(uint32_t *sink, uint32_t grid, double ms, hipStream_t s)
+hipError_t osw_launch_spin(uint32_t *sink, uint32_t grid, double ms, const uint32_t *stop_host_pinned, hipStream_t s)
 {
-    hipLaunchKernelGGL(osw_spin, dim3(grid), dim3(256), osw_shape_lds((const void *)osw_spin), s, sink, (uint64_t)(ms * 1.0e5));
+    hipLaunchKernelGGL(osw_spin, dim3(grid), dim3(256), osw_shape_lds((const void *)osw_spin), s, sink, (uint64_t)(ms * 1.0e5), stop_host_pinned);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -931,15 +931,20 @@ int do_search(Options &o)
     // (the device's own working memory -- the kernels' spill scratch -- exists since bring-up, like the FPGA kernel's on-chip buffers since
     // init(); the buffers the reference creates INSIDE its clock -- queries, chunk arrays, profiles, scores: FPGAsearch.c:80, :85-96 --
     // are made inside ours: reserve_slots below)
-    auto reserve_slots = [&] {
+    // (... and the HOST side of the chunk slots -- page-locked staging -- before it, like the reference's posix_memalign, FPGAsearch.c:69-74)
+    auto reserve_slots = [&](bool host_only) {
         if (!device_top) return;
         for (unsigned d = 0; d < pieces.size(); ++d) { // the largest piece of the device, one slot more than it keeps in flight
             uint64_t mb = 0;
             uint32_t mg = 0;
             for (const Piece &p : pieces[d]) { mb = std::max(mb, p.bytes); mg = std::max(mg, p.ngroups); }
-            if (mb) check(oswald_hip_reserve_chunks(ctx, (int)d, mb, mg, (uint32_t)W, (uint32_t)nq, (uint32_t)std::min<size_t>(pieces[d].size() + 1, 4)), "device buffers");
+            const uint32_t slots = (uint32_t)std::min<size_t>(pieces[d].size() + 1, 4);
+            if (mb && host_only) check(oswald_hip_reserve_host(ctx, (int)d, mg, (uint32_t)W, (uint32_t)nq, slots), "host buffers");
+            else if (mb) check(oswald_hip_reserve_chunks(ctx, (int)d, mb, mg, (uint32_t)W, (uint32_t)nq, slots), "device buffers");
         }
     };
+    reserve_slots(true);
+    lap("host buffers (page-locked staging)");
 
     // OSWALD_DEBUG_REPEAT=n (with OSWALD_DEBUG_PHASES; measurement hook): the timed region is run n times; the report is the FIRST
     // pass's -- what a user gets --, the later passes (same process: clocks, caches, the runtime's queues warm) go to stderr
@@ -953,7 +958,7 @@ int do_search(Options &o)
     check(oswald_hip_set_scoring(ctx, oswald::submat_by_name(o.submat), o.open_gap, o.extend_gap, 0), "scoring setup");
     check(oswald_hip_set_queries(ctx, q.a.data(), q.Q, q.m.data(), q.a_disp.data(), (uint32_t)nq), "query upload");
     lap("  scoring + queries");
-    reserve_slots();
+    reserve_slots(false);
     lap("  device buffers (chunk slots)");
     if (device_top) {
         check(oswald_hip_topr_begin(ctx, (uint32_t)o.top), "top scores");

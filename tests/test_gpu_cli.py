@@ -189,7 +189,7 @@ def test_cli_chunk_size_is_clamped_to_device_memory(tmp_path):
     common = ["-O", "search", "-m", "0", "-r", "12", "-q", str(tmp_path / "q.fasta"), "-d", db]
     ref = subprocess.run([hostlib.CLI] + common, capture_output=True, text=True)
     big = subprocess.run([hostlib.CLI] + common + ["-k", "100000000000"], capture_output=True, text=True)
-    small = subprocess.run([hostlib.CLI] + common, capture_output=True, text=True, env=dict(os.environ, OSWALD_HIP_FAKE_FREE_MEM="9000000000"))
+    small = subprocess.run([hostlib.CLI] + common, capture_output=True, text=True, env=dict(os.environ, OSWALD_HIP_FAKE_FREE_MEM="3000000000"))
     for p in (ref, big, small):
         assert p.returncode == 0, p.stderr
     limit = lambda p: int(re.search(r"Max. chunk size in FPGA:\t(\d+) bytes", p.stdout).group(1))
@@ -198,7 +198,7 @@ def test_cli_chunk_size_is_clamped_to_device_memory(tmp_path):
     assert 0 < limit(small) < 134217728
     assert parse_report(big.stdout) == parse_report(ref.stdout) == parse_report(small.stdout)
     # the hybrid mode -- the tool's default -- cuts the database by the same clamped limit (the reference clamps in init() for every mode)
-    hyb = subprocess.run([hostlib.CLI] + [x if x != "0" else "1" for x in common], capture_output=True, text=True, env=dict(os.environ, OSWALD_HIP_FAKE_FREE_MEM="9000000000"))
+    hyb = subprocess.run([hostlib.CLI] + [x if x != "0" else "1" for x in common], capture_output=True, text=True, env=dict(os.environ, OSWALD_HIP_FAKE_FREE_MEM="3000000000"))
     assert hyb.returncode == 0, hyb.stderr
     assert limit(hyb) == limit(small) and parse_report(hyb.stdout) == parse_report(ref.stdout)
     # a device that cannot hold one group of sequences: a message, not a crash

@@ -369,7 +369,7 @@ def test_one_call_search_keeps_a_converted_residue_buffer_alive(oracle):
 
 def test_failures_come_back_as_error_codes_and_the_context_lives_on(oracle, monkeypatch):
     """(a) a device allocation that fails (OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE: a device that is full -- here the
-    spill scratch the first upload needs) is OSWALD_HIP_ENOMEM, not a dead process, and the same context searches correctly once
+    buffers of the chunk slot the first upload needs; bring-up is spared by the hook) is OSWALD_HIP_ENOMEM, not a dead process, and the same context searches correctly once
     memory is there; (b) a host allocation that THROWS inside the library (a query buffer no memory can hold: std::length_error
     out of std::vector) comes back through the C ABI as OSWALD_HIP_ENOMEM too (every entry is guarded)."""
     import ctypes
@@ -382,12 +382,12 @@ def test_failures_come_back_as_error_codes_and_the_context_lives_on(oracle, monk
     sm = submat.load("blosum62")
     a, m, ad = pack_queries(qs)
     want = expect(oracle, qs, b, n, disp, 16, sm, 10, 2)
-    monkeypatch.setenv("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE", str(256 << 20))
+    monkeypatch.setenv("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE", str(64 << 10))
     with capi.Context(1) as ctx:
         ctx.set_scoring(sm, 10, 2)
         ctx.set_queries(a, m, ad)
         with pytest.raises(capi.OswaldHipError, match="error -4"):
-            ctx.chunk_upload(b, n, disp, 16)                  # the spill scratch (> 1 GB) cannot be made
+            ctx.chunk_upload(b, n, disp, 16)                  # the slot's re-tiled residues (~250 KB) cannot be made
         monkeypatch.delenv("OSWALD_HIP_FAIL_DEVICE_ALLOC_ABOVE")
         ctx.set_scoring(sm, 10, 2)                            # (hooks are read when a context is configured)
         # (b): Q = 2^62 bytes of queries, no query: nothing is read, the copy of the buffer cannot be allocated

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, call 2: tails inside the pair launch (no planes): the tails tests first, then the whole suite, then bench lines with / without
 O=gpurun_out/r06; mkdir -p $O
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tails" 2>&1 | tee $O/tails_2.log | tail -5
+timeout -k 10 300 python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k "failures or converted" 2>&1 | tee $O/tails_2.log | tail -5
 [ ${PIPESTATUS[0]} -eq 0 ] || { echo "tails tests failed"; exit 1; }
 timeout -k 10 800 python -m pytest tests -m gpu -x -q 2>&1 | tee $O/suite_2.log | tail -5
 [ ${PIPESTATUS[0]} -eq 0 ] || { echo "suite failed"; exit 1; }
