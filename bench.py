@@ -383,6 +383,7 @@ def main():
                                          else ("torch.distributed.all_gather" if world > 1 else None), "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_ratio": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,   # counter bytes over algorithmic bytes: what the strips spill and read back
                          "kernel": kname, "kernel_ms": round(kern_s * 1e3, 3), "kernel_gcups": round(kern_gcups, 1),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launches_per_step": round(nlaunch / max(1, args.steps), 2),
                          "valu": {"ceiling_gcups": round(valu_ceiling, 0), "frac": round(kern_gcups / valu_ceiling, 4),
@@ -564,7 +565,9 @@ def measured_traffic(workload_name, nseq, dtype=None):
     kernel sources it was measured on; a stale one is not reported."""
     if nseq is None:
         return None, "PMC passes are single-GPU runs"
-    path = os.path.join(ROOT, "profiles", f"traffic_{workload_name}_{nseq}.json")
+    # a file per MODE (round 6): workload, database size, cell arithmetic, and whether the pairs' tails run (OSWALD_HIP_PAIR_TAILS, default 1)
+    tails = os.environ.get("OSWALD_HIP_PAIR_TAILS", "1")
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload_name}_{nseq}" + ("" if tails == "1" else f"_tails{tails}") + ".json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -572,6 +575,8 @@ def measured_traffic(workload_name, nseq, dtype=None):
         return None, "no PMC summary committed for this workload"
     if dtype is not None and t.get("dtype") not in (None, dtype):
         return None, f"the PMC summary committed for this workload was measured on the {t.get('dtype')} cells"
+    if t.get("pair_tails", "1") != tails:
+        return None, f"the PMC summary committed for this workload was measured with OSWALD_HIP_PAIR_TAILS={t.get('pair_tails')}"
     if t.get("source_digest") != source_digest():
         print(f"bench.py: {path} was measured on other kernel sources (digest {t.get('source_digest')} != {source_digest()}); "
               "traffic not reported -- re-run tools/profile_gpu.sh", file=sys.stderr, flush=True)
@@ -647,7 +652,7 @@ def cpu_baseline(args, a, m, a_disp, chunks, ctx, sm, wl, sum_m):
     gpu = np.concatenate([tab[:, p] for tab, p in zip(gpu_tables, picks)], axis=1)[:, order]
     equal = bool(np.array_equal(gpu, sc_cpu[:, :gpu.shape[1]]))
     nsamp = int(sum(len(p) for p in picks))
-    return {"value": round(sum_m * dres / t / 1e9, 3), "unit": "GCUPS", "cores": threads, "host_threads_visible": pyoracle.max_threads(), "cpu_model": cpu_model(), "kind": "port",
+    return {"value": round(sum_m * dres / t / 1e9, 3), "unit": "GCUPS", "cores": threads, "cores_note": f"{threads} of {os.cpu_count()} hardware threads (what the cgroup's cpu.max / the affinity mask let this process keep busy)", "host_threads_visible": pyoracle.max_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"every {stride}-th {W}-lane group of each of rank 0's {len(chunks)} chunks = of the whole benched database ({nsamp} sequences, {dres} residues, "
                       f"mean length {dres / max(nsamp, 1):.0f}) x all {len(m)} queries, {'AVX2' if W == 32 else 'SSE4.1'} int8->int16->int32 port, block 256, {t:.1f} s",
             "gpu_scores_equal_on_sample": equal,

@@ -306,6 +306,12 @@ struct Chunk {
     int map_cur = 0;
     bool map_pending = false;
     hipEvent_t ev_map[2] = {nullptr, nullptr};
+    // ... and who read device buffer k last: recorded on the search stream behind the top-list fold that reads it.  A map that is about
+    // to overwrite a buffer waits for that reader on the host (set_index(A), search, set_index(B), search, set_index(C)
+    // without a wait in between let copy C overwrite buffer A while search A's fold had not run yet; in the pipelined use the
+    // reader is long gone and the wait costs nothing)
+    hipEvent_t ev_map_read[2] = {nullptr, nullptr};
+    bool map_read_pending[2] = {false, false};
     // A chunk the library cut in two at its upload (oswald_hip_chunk_upload_async on an idle device): the caller's handle is
     // the HEAD's slot, `next` the slot of the REST (groups head_groups .. of the caller's arrays), which no handle names.
     // Every per-chunk entry point walks the chain.
@@ -658,6 +664,12 @@ int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c)
     HIP_TRY(osw_launch_topr_fold_chunk((const int32_t *)c.scores.p, c.score_stride, c.nvalid, r, ctx->nq,
                                        c.index_map ? (const uint32_t *)c.index_map_dev[c.map_cur].p : nullptr, c.first_index, (unsigned long long *)d.topr_cand.p,
                                        (const unsigned long long *)d.top_run[d.top_cur].p, (unsigned long long *)d.top_run[d.top_cur ^ 1].p, d.stream));
+    if (c.index_map) {
+        const int k = c.map_cur;
+        if (!c.ev_map_read[k]) HIP_TRY(hipEventCreateWithFlags(&c.ev_map_read[k], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c.ev_map_read[k], d.stream));
+        c.map_read_pending[k] = true;
+    }
     d.top_cur ^= 1;
     d.top_any = true;
     return 0;
@@ -897,7 +909,7 @@ static int finalize_impl(oswald_hip_ctx *ctx)
         }
         if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; } }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; if (c.ev_map_read[k]) (void)hipEventDestroy(c.ev_map_read[k]); c.ev_map_read[k] = nullptr; } }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_seq, &d.prof_seq_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
                           &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8, &d.floor_i32, &d.pair_rows, &d.tail_len, &d.tail_off,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
@@ -1220,7 +1232,12 @@ static int upload_pieces(oswald_hip_ctx *ctx, int dev, const uint8_t *b, uint64_
     const uint32_t cut = disp[head_groups];
     if (int r = upload_slot(ctx, dev, b, cut, n, disp, 0, head_groups, W, &head)) return r;
     if (int r = upload_slot(ctx, dev, b + cut, vD - cut, n + head_groups, disp + head_groups, cut, ngroups - head_groups, W, &rest)) {
-        d.chunks[head].live = false; // (its upload is queued and harmless; the slot is free again once it has landed)
+        // the head's copy from the caller's `b` is queued: it must have landed before the caller -- who sees a failed call -- may free
+        // the buffer; then the slot is free again
+        const std::string why = g_err;
+        (void)finish_upload(d, d.chunks[head]);
+        d.chunks[head].live = false;
+        g_err = why;
         return r;
     }
     d.chunks[head].next = rest;
@@ -1783,7 +1800,7 @@ static int wait_impl(oswald_hip_ctx *ctx, int dev)
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_up));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_down));
-        for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; c.down_pending = false; c.set_read_pending[0] = c.set_read_pending[1] = false; }
+        for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; c.down_pending = false; c.set_read_pending[0] = c.set_read_pending[1] = false; c.map_read_pending[0] = c.map_read_pending[1] = false; }
         release_registered(ctx->dev[i]);
     }
     return 0;
@@ -1858,6 +1875,7 @@ static int set_index_slot(Device &d, Chunk &c, uint32_t first_index, uint32_t nv
         const int k = c.map_cur ^ 1;
         if (c.ev_map[k]) HIP_TRY(hipEventSynchronize(c.ev_map[k])); // (the copy that last read this staging buffer: two maps ago)
         else HIP_TRY(hipEventCreateWithFlags(&c.ev_map[k], hipEventDisableTiming));
+        if (c.map_read_pending[k]) { HIP_TRY(hipEventSynchronize(c.ev_map_read[k])); c.map_read_pending[k] = false; } // (the fold that read device buffer k last)
         HIP_TRY(c.map_pin[k].reserve((size_t)nvalid * sizeof(uint32_t)));
         memcpy(c.map_pin[k].p, index_map, (size_t)nvalid * sizeof(uint32_t));
         // (the device buffer: the search that read it last -- of the chunk this slot held two maps ago -- is long through; a map

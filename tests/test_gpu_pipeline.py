@@ -400,3 +400,41 @@ def test_failures_come_back_as_error_codes_and_the_context_lives_on(oracle, monk
         ctx.wait()
         ctx.chunk_release(h)
         np.testing.assert_array_equal(out[:, :want.shape[1]], want[:, :out.shape[1]])
+
+
+def test_index_maps_given_in_a_row_do_not_overtake_their_readers(oracle):
+    """a resident chunk searched three times, each time under another index map and without a wait in between.  The
+    maps flip between two device buffers; the third map's copy must not land in the first map's buffer before the first search's
+    top-list fold has read it.  Every search folds its chunk's best into the running list on DATABASE keys, so the final list
+    holds each of the best sequences three times -- once per map, larger index first -- and a fold that ran on the wrong map would
+    leave the first map's entries out."""
+    from oswald_amd import capi
+    qs = synth.make_queries([300, 420, 555], seed=71)
+    L, R, O = random_db(6000, seed=72, min_len=200, max_len=900, queries=qs, homologs=2)
+    order, sl, sr, so = dblayout.sort_by_length(L, R, O)
+    b, n, disp = dblayout.interleave(sl, sr, so, 16)
+    disp = disp.astype(np.uint32)
+    nseq = len(sl)
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        h = ctx.chunk_upload(b, n, disp, 16)
+        table = np.zeros((len(qs), len(n) * 16), np.int32)
+        ctx.chunk_search(h, table)
+        ctx.wait()
+        maps = [np.arange(nseq, dtype=np.uint32) + np.uint32(k * 1000000) for k in range(3)]
+        for rep in range(3):
+            ctx.topr_begin(6)
+            for mp in maps:
+                ctx.chunk_set_index(h, 0, nseq, mp)
+                ctx.chunk_search(h, None)
+            sc, ix = ctx.topr(6)
+            for q in range(len(qs)):
+                ws, wi = dblayout.topr_reference_order(table[q, :nseq], 2)
+                want_s = np.repeat(ws, 3)
+                want_i = (wi.astype(np.int64)[:, None] + np.array([2000000, 1000000, 0])[None, :]).reshape(-1)
+                np.testing.assert_array_equal(sc[q], want_s)
+                np.testing.assert_array_equal(ix[q].astype(np.int64), want_i)
+        ctx.chunk_release(h)

@@ -25,7 +25,9 @@ if stats:
     dom = stats[-1].replace("_kernel_stats.csv", "_domain_stats.csv")
     if os.path.exists(dom):
         shutil.copy(dom, os.path.join(dst, f"r{rnd}_{label}_domain_stats.csv"))
-t = os.path.join(src, f"traffic_{wl}_{nseq}.json")
-if os.path.exists(t) and not plabel:   # (a labelled run -- other cells, other flags -- is not what bench.py's default line reports)
-    shutil.copy(t, os.path.join(dst, f"traffic_{wl}_{nseq}.json"))
+# the traffic file(s) of the run: one per MODE (tools/summarize_prof.py names them: ..._tails0.json for OSWALD_HIP_PAIR_TAILS=0); a run
+# labelled otherwise -- other cells, other flags -- is not what a bench line of that name would report
+for t in glob.glob(os.path.join(src, f"traffic_{wl}_{nseq}*.json")):
+    if not plabel or os.path.basename(t) == f"traffic_{wl}_{nseq}_{plabel}.json":
+        shutil.copy(t, os.path.join(dst, os.path.basename(t)))
 print("collected", label, "->", dst, "| trace vs bench kernel time: %+.2f %%" % (100 * c["relative_difference"]))
