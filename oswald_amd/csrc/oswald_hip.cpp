@@ -1482,8 +1482,8 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
 #ifdef OSW_DIAG
     const bool dbg_times = ctx->tun.debug_times;
     if (dbg_times) {
-        HIP_TRY(d.wg_times.reserve((size_t)d.grid * 5 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(d.wg_times.p, 0, (size_t)d.grid * 5 * sizeof(unsigned long long), d.stream));
+        HIP_TRY(d.wg_times.reserve(((size_t)d.grid * 5 + 2) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d.wg_times.p, 0, ((size_t)d.grid * 5 + 2) * sizeof(unsigned long long), d.stream));
         a.wg_times = (unsigned long long *)d.wg_times.p;
     }
 #endif
@@ -1605,11 +1605,12 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     if (dbg_times) {
         // diagnostics only (liboswald_hip_diag.so): when did the workgroups of the DP launch start / leave phase 1 / finish
         HIP_TRY(hipStreamSynchronize(d.stream));
-        std::vector<unsigned long long> t((size_t)grid * 5);
+        std::vector<unsigned long long> t((size_t)grid * 5 + 2);
         HIP_TRY(hipMemcpy(t.data(), d.wg_times.p, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         uint32_t ctr[8] = {0};
         HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
         osw_diag_report_times(t.data(), grid, ctr[4]);
+        if (t[(size_t)grid * 5 + 1]) fprintf(stderr, "[oswald_hip]   core clock inside the kernel (cycle counter / 100-MHz counter over its workgroups): %.0f MHz\n", 100.0 * (double)t[(size_t)grid * 5] / (double)t[(size_t)grid * 5 + 1]);
     }
 #endif
     return 0;
@@ -2037,6 +2038,7 @@ static int comm_init_rank_impl(oswald_hip_ctx *ctx, const void *id, size_t id_by
     if (id_bytes < sizeof(ncclUniqueId)) return fail(OSWALD_HIP_EINVAL, "the id must be the %zu bytes oswald_hip_comm_unique_id wrote", sizeof(ncclUniqueId));
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(OSWALD_HIP_EINVAL, "rank %d of %d", rank, nranks);
     if (ctx->pcomm) return fail(OSWALD_HIP_ESTATE, "the context already has a process-level communicator");
+    stop_warm(ctx); // (the communicator's bring-up works on the device: no warm-up kernel beside it)
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     HIP_TRY(hipSetDevice(ctx->dev[0].id));

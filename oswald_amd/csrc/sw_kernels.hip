@@ -1365,6 +1365,9 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 
     // (-DOSW_DIAG: when each workgroup started, left phase 1 and finished, 100 MHz ticks)
     OSW_DIAG_STAMP(threadIdx.x == 0, blockIdx.x * 4 + 0);
+#ifdef OSW_DIAG // (... and the core clock its waves ran at: cycle counter over the 100-MHz counter, summed over the workgroups behind the per-workgroup entries)
+    const unsigned long long diag_c0 = __builtin_readcyclecounter(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Which end of the (cost-sorted) queues this workgroup eats from: the first workgroup to
     // arrive on a CU takes the heavy end, later arrivals the light end, so that a long item
@@ -1480,6 +1483,12 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         set_wave_prio(0);
     }
     OSW_DIAG_STAMP(lane == 0, blockIdx.x * 4 + 2 + (wv & 1)); // waves 0/1 (or 2/3) race: any is fine
+#ifdef OSW_DIAG
+    if (p.wg_times && threadIdx.x == 0) {
+        atomicAdd(&p.wg_times[(size_t)gridDim.x * 5 + 0], __builtin_readcyclecounter() - diag_c0);
+        atomicAdd(&p.wg_times[(size_t)gridDim.x * 5 + 1], __builtin_amdgcn_s_memrealtime() - diag_r0);
+    }
+#endif
 }
 
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16(OswSearchArgs p) { pk16_body<CellPK16B, CellPK16B, false>(p); }
