@@ -181,7 +181,8 @@ struct DevBuf {
         if (bytes <= cap) return hipSuccess;
         // (a failed hipFree / hipMalloc leaves HIP's last error set; callers that recover from the failure must not see it
         // again in the next launch check: it is cleared here, the code is returned)
-        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) { (void)hipGetLastError(); return e; } p = nullptr; cap = 0; }
+        if (p && !view) { hipError_t e = hipFree(p); if (e != hipSuccess) { (void)hipGetLastError(); return e; } }
+        p = nullptr; cap = 0; view = false; // (a slice of an arena / a slot's slab that must grow becomes an allocation of its own; the slice goes back with its slab)
         size_t want = bytes + bytes / 8 + 256;
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = g_fail_alloc_above && want > g_fail_alloc_above ? hipErrorOutOfMemory : hipMalloc(&p, want);
@@ -236,6 +237,8 @@ struct Chunk {
     uint32_t max_ncols4 = 0;     // largest stored extent of a block
     uint64_t total_col4 = 0;     // stored 4-column groups incl. the pad group per block
     DevBuf tiled, blocks, sub_cols_buf, scores, ovf, ovf8;
+    DevBuf slab;                        // oswald_hip_reserve_chunks: ONE device allocation that the buffers above and st_b are slices of (a creation of the slot's buffers
+                                        // inside a caller's clock is one call into the driver per slot instead of six; a buffer that must grow later gets an allocation of its own)
     // The work queues, two sets in turn, in PAGE-LOCKED HOST memory that the kernels read in place (a wave fetches one 8-byte
     // entry per work item over the link: microseconds against items of 0.1 - 10 ms).  Round 4 copied every plan to the device on
     // the copy stream; there the few hundred KB queued BEHIND the bulk copies of the chunks coming in, and the first search of a
@@ -909,7 +912,7 @@ static int finalize_impl(oswald_hip_ctx *ctx)
         }
         if (d.comm) { (void)ncclCommDestroy(d.comm); d.comm = nullptr; }
         if (&d == &ctx->dev[0] && ctx->pcomm) { (void)ncclCommDestroy(ctx->pcomm); ctx->pcomm = nullptr; }
-        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; if (c.ev_map_read[k]) (void)hipEventDestroy(c.ev_map_read[k]); c.ev_map_read[k] = nullptr; } }
+        for (Chunk &c : d.chunks) { c.tiled.release(); c.blocks.release(); c.sub_cols_buf.release(); c.scores.release(); c.ovf.release(); c.ovf8.release(); c.index_map_dev[0].release(); c.index_map_dev[1].release(); c.slab.release(); for (int k = 0; k < 2; ++k) { if (c.ev_map[k]) (void)hipEventDestroy(c.ev_map[k]); c.ev_map[k] = nullptr; if (c.ev_map_read[k]) (void)hipEventDestroy(c.ev_map_read[k]); c.ev_map_read[k] = nullptr; } }
         for (DevBuf *b : {&d.queries, &d.qlen, &d.a_disp, &d.prof_off, &d.prof, &d.prof_alt, &d.prof_seq, &d.prof_seq_alt, &d.prof_pair_i16, &d.pair_q, &d.pair_off, &d.pair_len, &d.prof_pair, &d.submat, &d.bnd, &d.counters,
                           &d.topr_scores, &d.topr_index, &d.topr_cand, &d.wg_times, &d.scores_packed, &d.top_pages, &d.prof_pair8, &d.floor_i32, &d.pair_rows, &d.tail_len, &d.tail_off,
                           &d.top_run[0], &d.top_run[1], &d.top_gather, &d.top_final})
@@ -1304,13 +1307,20 @@ static int reserve_slots(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uin
                 // re-tiled residues: a byte per residue of every block padded to its longest group (sorted databases: ~1.02 x the chunk)
                 // + the all-dummy column groups around every block
                 const uint64_t col4 = (chunk_bytes + chunk_bytes / 16) / 512 + (uint64_t)(nblocks + 1) * OSW_TILED_PAD_GROUPS + OSW_TILED_TAIL_GROUPS;
-                HIP_TRY(c.tiled.reserve(col4 * 64 * sizeof(uint2)));
-                HIP_TRY(c.blocks.reserve(nblocks * sizeof(OswBlock) + 16));
-                HIP_TRY(c.sub_cols_buf.reserve((size_t)nblocks * 128 * sizeof(uint16_t) + 16));
-                HIP_TRY(c.st_b.reserve(chunk_bytes + 64));
-                if (nq > 0) {
-                    HIP_TRY(c.scores.reserve((size_t)nq * nblocks * OSW_BLOCK_SEQS * sizeof(int32_t) + 16));
-                    HIP_TRY(c.ovf.reserve(((size_t)nq * nblocks * 128 + (size_t)(nq / 2) * nblocks * 64) * sizeof(uint2) + 16));
+                struct Want { DevBuf *buf; size_t bytes; };
+                const Want wants[] = {{&c.tiled, (size_t)(col4 * 64 * sizeof(uint2))}, {&c.blocks, nblocks * sizeof(OswBlock) + 16}, {&c.sub_cols_buf, (size_t)nblocks * 128 * sizeof(uint16_t) + 16},
+                                      {&c.st_b, (size_t)chunk_bytes + 64}, {&c.scores, nq ? (size_t)nq * nblocks * OSW_BLOCK_SEQS * sizeof(int32_t) + 16 : 0},
+                                      {&c.ovf, nq ? ((size_t)nq * nblocks * 128 + (size_t)(nq / 2) * nblocks * 64) * sizeof(uint2) + 16 : 0}};
+                size_t need = 0;
+                for (const Want &w : wants) if (w.bytes > w.buf->cap) need += Arena::up(w.bytes + w.bytes / 8 + 256);
+                if (need > 0 && !c.slab.p) {
+                    // a fresh slot: one slab, the buffers are slices of it (with the head room their own allocations would have had)
+                    HIP_TRY(c.slab.reserve(need));
+                    size_t used = 0;
+                    for (const Want &w : wants)
+                        if (w.bytes > w.buf->cap) { const size_t sz = Arena::up(w.bytes + w.bytes / 8 + 256); w.buf->assign((char *)c.slab.p + used, sz); used += sz; }
+                } else {
+                    for (const Want &w : wants) if (w.bytes) HIP_TRY(w.buf->reserve(w.bytes)); // (a slot that has buffers: each grows by itself)
                 }
             }
             if (what & 1) {
@@ -1768,7 +1778,7 @@ static int release_chunks_impl(oswald_hip_ctx *ctx, int dev)
             if (c.live) continue;
             // (the DEVICE buffers: the slot's page-locked host staging stays, like the reference's host buffers, which outlive its device
             // buffers -- FPGAsearch.c:361-368 releases the cl_mem objects only)
-            for (DevBuf *b : {&c.tiled, &c.blocks, &c.sub_cols_buf, &c.scores, &c.ovf, &c.ovf8, &c.st_b, &c.index_map_dev[0], &c.index_map_dev[1]}) b->release();
+            for (DevBuf *b : {&c.tiled, &c.blocks, &c.sub_cols_buf, &c.scores, &c.ovf, &c.ovf8, &c.st_b, &c.index_map_dev[0], &c.index_map_dev[1], &c.slab}) b->release();
             c.items_version = ~0ull;
             c.searched = false;
         }
