@@ -1297,13 +1297,15 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
         int2 out;
         out.x = A::to_int(score.x);
         out.y = A::to_int(score.y);
+        uint32_t queued = 0u; // (tail) sequences of the lane that the pair part of the item has sent to the int32 re-run already: not twice
         if (tail) {
             const int2 before = *(const int2 *)(p.scores + (size_t)q * p.score_stride + (size_t)blk.seq0 + 2 * lam);
             out.x = out.x > before.x ? out.x : before.x;
             out.y = out.y > before.y ? out.y : before.y;
+            queued = (before.x < 0 || before.x >= A::kCeiling ? 1u : 0u) | (before.y < 0 || before.y >= A::kCeiling ? 2u : 0u);
         }
         osw_store_score2(p, q, (size_t)blk.seq0 + 2 * lam, out);
-        const uint32_t hm = (A::over(score.x) ? 1u : 0u) | (A::over(score.y) ? 2u : 0u);
+        const uint32_t hm = ((A::over(score.x) ? 1u : 0u) | (A::over(score.y) ? 2u : 0u)) & ~queued;
         if (hm) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
             p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
