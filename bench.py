@@ -359,7 +359,7 @@ def main():
         ops_row = PK_OPS_PER_ROW[cell_bits][1 if nq > 1 else 0]  # a multi-query search runs (mostly) as query pairs
         row_cycles = ROW_CYCLES[cell_bits][1 if nq > 1 else 0]
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / row_cycles) * 128.0 / 1e9
-        kname = {16: "osw_sw_s16q+osw_sw_s16(+osw_sw_i32)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
+        kname = {16: "osw_sw_s16qt|osw_sw_s16q+osw_sw_s16(+osw_sw_i32r)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
         traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None, DTYPE[cell_bits])
         cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1",
                     "hi": "escalation-heavy (int16 -> int32)", "hi8": "escalation-heavy (int8 -> int16)"}[args.workload]

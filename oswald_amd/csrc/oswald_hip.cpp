@@ -831,6 +831,8 @@ static int init_impl(int ndev, const int *device_ids, oswald_hip_ctx **out)
             a.counters = (uint32_t *)d.counters.p;
             a.counters_ovf = (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT;
             if (r == hipSuccess) r = osw_launch_s16q(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_s16qt(a, 1, d.stream);
+            if (r == hipSuccess) r = osw_launch_pk16qt(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_s16(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16q(a, 1, d.stream);
             if (r == hipSuccess) r = osw_launch_pk16(a, 1, d.stream);
@@ -1310,7 +1312,7 @@ static int reserve_slots(oswald_hip_ctx *ctx, int dev, uint64_t chunk_bytes, uin
                 struct Want { DevBuf *buf; size_t bytes; };
                 const Want wants[] = {{&c.tiled, (size_t)(col4 * 64 * sizeof(uint2))}, {&c.blocks, nblocks * sizeof(OswBlock) + 16}, {&c.sub_cols_buf, (size_t)nblocks * 128 * sizeof(uint16_t) + 16},
                                       {&c.st_b, (size_t)chunk_bytes + 64}, {&c.scores, nq ? (size_t)nq * nblocks * OSW_BLOCK_SEQS * sizeof(int32_t) + 16 : 0},
-                                      {&c.ovf, nq ? ((size_t)nq * nblocks * 128 + (size_t)(nq / 2) * nblocks * 64) * sizeof(uint2) + 16 : 0}};
+                                      {&c.ovf, nq ? ((size_t)nq * nblocks * 128 + (size_t)(nq / 2) * nblocks * 128) * sizeof(uint2) + 16 : 0}};
                 size_t need = 0;
                 for (const Want &w : wants) if (w.bytes > w.buf->cap) need += Arena::up(w.bytes + w.bytes / 8 + 256);
                 if (need > 0 && !c.slab.p) {
@@ -1513,7 +1515,8 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     if (ctx->profiling) HIP_TRY(hipEventRecord(ev.a, d.stream));
     const bool frame = first_pass_is_frame(ctx);
     const auto launch_single = frame ? osw_launch_s16 : osw_launch_pk16;
-    const auto launch_pair = frame ? osw_launch_s16q : osw_launch_pk16q;
+    // (a launch whose queue holds SHORT items runs the kernel that carries the single-query cell for their tails beside the pair cell)
+    const auto launch_pair = c.nitems_short > 0 ? (frame ? osw_launch_s16qt : osw_launch_pk16qt) : (frame ? osw_launch_s16q : osw_launch_pk16q);
     OswSearchArgs as = a; // single queries on the int16 cells: {S, 1} entries (`a` itself stays on the plain integer profile for the int32 kernel)
     as.prof = (const uint2 *)d.prof_seq.p;
     if (frame) { as.prof = (const uint2 *)d.prof_seq_alt.p; as.prof_fb = (const uint2 *)d.prof_seq.p; }

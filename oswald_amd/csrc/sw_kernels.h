@@ -199,6 +199,8 @@ hipError_t osw_launch_i32r(const OswSearchArgs &a, uint32_t regions, hipStream_t
 hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_s16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
+hipError_t osw_launch_s16qt(const OswSearchArgs &a, uint32_t grid, hipStream_t s);   // the query-pair kernels whose queue may hold SHORT items (tails, OswSearchArgs::hand)
+hipError_t osw_launch_pk16qt(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_q8(const OswSearchArgs &a, uint32_t grid, hipStream_t s);
 hipError_t osw_launch_build_pair_profile8(const uint2 *prof, const uint32_t *prof_off, const uint16_t *qlen, const uint32_t *pair_q,
                                           const uint32_t *pair_off, const uint16_t *pair_len, uint32_t npairs, uint32_t max_rowblocks,

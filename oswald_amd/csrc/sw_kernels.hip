@@ -1306,9 +1306,15 @@ static __device__ __forceinline__ void pk16_finish(const OswSearchArgs &p, uint3
         }
         osw_store_score2(p, q, (size_t)blk.seq0 + 2 * lam, out);
         const uint32_t hm = ((A::over(score.x) ? 1u : 0u) | (A::over(score.y) ? 2u : 0u)) & ~queued;
-        if (hm) {
+        // (an entry per sequence: the re-run gives an entry to one workgroup, and the two sequences of a lane -- neighbours in a length-sorted
+        // database: two near-copies of one query -- in one entry would run one after the other: `hi`'s int32 tier 8.0 instead of 4.2 ms)
+        if (hm & 1u) {
             const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
-            p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, hm), B);
+            p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, 1u), B);
+        }
+        if (hm & 2u) {
+            const uint32_t k = atomicAdd(&p.counters_ovf[0], 1u);
+            p.ovf_items[k] = make_uint2(OSW_ITEM_PACK(q, lam, 6u, 2u), B);
         }
     }
 }
@@ -1353,8 +1359,11 @@ static __device__ __forceinline__ bool osw_frame_cell_takes(uint32_t cols, uint3
 // Main kernel: packed int16.
 // ---------------------------------------------------------------------------
 // C = the cell; CF = the cell for the blocks C cannot take (CF = C: none)
-// TC / TCF (query-pair kernels): the single-query cells that run the tails of SHORT pair items (OswSearchArgs::hand)
-template <class C, class CF, bool PAIR, class TC = C, class TCF = CF>
+// TAILS (query-pair kernels): the queue may hold SHORT pair items (OswSearchArgs::hand), whose tails run on the single-query cells TC / TCF.
+// A kernel of its own beside the plain pair kernel: with the single-query cell's code beside the pair cell's the compiler spills more
+// item-level state around the rounds (SGPR spills 95 -> 118, scratch 12 -> 52 B), which items of a hundred rounds feel (`hi`: 2 %);
+// a launch without SHORT items runs the plain kernel.
+template <class C, class CF, bool PAIR, bool TAILS = false, class TC = C, class TCF = CF>
 static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
 {
     __shared__ uint2 lds_prof[OSW_WG_THREADS / 64][OSW_LDS_ROWS16 * 8 + OSW_LDS_SKEW8]; // + one entry per lane group (fill_profile_slice)
@@ -1363,7 +1372,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t slot = blockIdx.x * (OSW_WG_THREADS / 64) + wv;
     uint2 *bnd_wave = p.bnd + (size_t)slot * p.bnd_stride;
-    [[maybe_unused]] uint2 *hand_wave = PAIR && p.hand ? p.hand + (size_t)slot * p.bnd_stride : nullptr; // (null: the queue holds no SHORT item)
+    [[maybe_unused]] uint2 *hand_wave = PAIR && TAILS && p.hand ? p.hand + (size_t)slot * p.bnd_stride : nullptr; // (null: the queue holds no SHORT item)
 
     // (-DOSW_DIAG: when each workgroup started, left phase 1 and finished, 100 MHz ticks)
     OSW_DIAG_STAMP(threadIdx.x == 0, blockIdx.x * 4 + 0);
@@ -1440,18 +1449,23 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
         // (separate instantiations of the item code: the ordinary items run the one without any hand-over state -- kept through the rounds, that
         // state costs the query-pair kernel 3 % on many-round items: registers it does not have)
         bool shorty = false;
-        if constexpr (PAIR) shorty = OSW_ITEM_HALVES(item.x) == OSW_ITEM_SHORT; // (the planner's choice, item by item)
+        if constexpr (PAIR && TAILS) shorty = OSW_ITEM_HALVES(item.x) == OSW_ITEM_SHORT; // (the planner's choice, item by item)
         for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
             v2s score;
             if constexpr (PAIR) {
-                const OswHand hand = {hand_wave, shorty ? (uint32_t)p.pair_rows[q] : 0u, (p.qlen[q] + 3u) / 4u, 0u}; // (pair_rows: only a launch with SHORT items has it)
                 if (cf_only) {
-                    if (shorty) score = run_item<CF, true, 1>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, hand);
-                    else score = run_item<CF, true, 0>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
+                    if constexpr (TAILS) {
+                        const OswHand hand = {hand_wave, shorty ? (uint32_t)p.pair_rows[q] : 0u, (p.qlen[q] + 3u) / 4u, 0u};
+                        if (shorty) score = run_item<CF, true, 1>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb, hand);
+                        else score = run_item<CF, true, 0>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
+                    } else score = run_item<CF, true, 0>(p, p.prof_fb, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_fb, p.ge_fb);
                     pk16q_finish<typename CF::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 } else {
-                    if (shorty) score = run_item<C, true, 1>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, hand);
-                    else score = run_item<C, true, 0>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
+                    if constexpr (TAILS) {
+                        const OswHand hand = {hand_wave, shorty ? (uint32_t)p.pair_rows[q] : 0u, (p.qlen[q] + 3u) / 4u, 0u};
+                        if (shorty) score = run_item<C, true, 1>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk, hand);
+                        else score = run_item<C, true, 0>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
+                    } else score = run_item<C, true, 0>(p, p.prof, q, B, blk, sigma, lg, lane, half, shared, lds_region, bnd_wave, p.goe_pk, p.ge_pk);
                     pk16q_finish<typename C::Arith>(p, q, B, blk, sigma, lg, lane, half, score);
                 }
             } else {
@@ -1464,7 +1478,7 @@ static __device__ __forceinline__ void pk16_body(const OswSearchArgs &p)
                 }
             }
         }
-        if constexpr (PAIR) {
+        if constexpr (PAIR && TAILS) {
             // (wave-uniform, and for a workgroup item the same in its four waves: one entity, one geometry)
             const uint32_t mt = shorty ? __builtin_amdgcn_readfirstlane((uint32_t)p.tail_len[q * OSW_TAIL_GEOMS + lg]) : 0u;
             if (mt) {
@@ -1497,12 +1511,14 @@ extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS vo
 
 // Query pairs: `items` / `qlen` / `prof` / `prof_off` describe pairs (length = the longer query,
 // profile = packed (A, B) scores); pair_q maps a pair to its two query rows of the score table.
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true, CellPK16B, CellPK16B>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16q(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_pk16qt(OswSearchArgs p) { pk16_body<CellPK16BQ, CellPK16BQ, true, true, CellPK16B, CellPK16B>(p); } // ... whose queue may hold SHORT items
 
 // Column-frame cell (6.5 instructions per row) with the plain biased cell for the blocks it cannot take:
 // `prof` holds S + ge, goe_pk the gap OPEN penalty; prof_fb / goe_fb / ge_fb serve the plain cell.
 extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16(OswSearchArgs p) { pk16_body<CellPK16S, CellPK16B, false>(p); }
-extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true, CellPK16S, CellPK16B>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16q(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true>(p); }
+extern "C" __global__ __launch_bounds__(OSW_WG_THREADS, 3) OSW_COMPILER_VGPRS void osw_sw_s16qt(OswSearchArgs p) { pk16_body<CellPK16SQ, CellPK16BQ, true, true, CellPK16S, CellPK16B>(p); } // ... whose queue may hold SHORT items
 
 // ---------------------------------------------------------------------------
 // The int32 re-run of ONE (query, sequence) on the TWELVE waves of a workgroup.  A sequence that reaches the int16 cells'
@@ -2166,6 +2182,20 @@ hipError_t osw_launch_pk16(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 hipError_t osw_launch_pk16q(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
 {
     hipLaunchKernelGGL(osw_sw_pk16q, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_pk16qt(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_pk16qt, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
+    OSW_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t osw_launch_s16qt(const OswSearchArgs &a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(osw_sw_s16qt, dim3(grid), dim3(OSW_WG_THREADS), 0, s, a);
     OSW_LAUNCH_CHECK();
     return hipSuccess;
 }

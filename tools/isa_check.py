@@ -31,10 +31,10 @@ STAMP = os.path.join(ROOT, "oswald_amd", "liboswald_hip.isa.json")
 # budget of their launch bounds, and the scratch bytes per lane tolerated OUTSIDE the column loops (loop-invariant state
 # parked before a round; inside the loops check_vmem_windows allows none)
 GROUPS = (
-    dict(kernels=("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_s16", "osw_sw_s16q"), define="OSW_INFLIGHT", file="sw_kernels.hip",
+    dict(kernels=("osw_sw_pk16", "osw_sw_pk16q", "osw_sw_pk16qt", "osw_sw_s16", "osw_sw_s16q", "osw_sw_s16qt"), define="OSW_INFLIGHT", file="sw_kernels.hip",
          budget=168,   # three waves per SIMD; the compiler gets 140, the asm statements 27 fixed ones (v158 is spare; v148, v149 unused)
          scratch=64, min_asm_uses=1000, nfixed=27),   # (spills of item-level values around the rounds: never inside a column loop, check_vmem_windows;
-                                                     # round 6: 52 B in osw_sw_s16q, which holds the single-query cell for its tails beside the pair cell)
+                                                     # round 6: 52 B in osw_sw_s16qt, which holds the single-query cell for its tails beside the pair cell)
     dict(kernels=("osw_sw_i32",), define="OSW_INFLIGHT", file="sw_kernels.hip",
          budget=168,   # the hand-scheduled int32 cell (cell_bits = 32): the int16 kernels' column loop and register budget
          scratch=0, min_asm_uses=500, nfixed=27),
@@ -179,17 +179,20 @@ def check_cell_shape(isa):
     bad = []
     for k in GROUPS[0]["kernels"]:
         c = counts.get(k, {})
-        single = not k.endswith("q")
+        single = not k.endswith(("q", "qt"))
+        tails = k.endswith("qt")
         if c.get("v_perm_b32", 0):
             bad.append("%s has %d v_perm_b32" % (k, c["v_perm_b32"]))
         if single and c.get("v_pk_mad_i16", 0) < 300:
             bad.append("%s has %d v_pk_mad_i16 (one per row of every unrolled strip height expected)" % (k, c.get("v_pk_mad_i16", 0)))
-        if not single:
-            # the query-pair ROW adds with a 32-bit add; the v_pk_mad_i16 a pair kernel holds since round 6 are the rows of the single-query
-            # cell that runs the TAILS of its SHORT items (OswSearchArgs::hand): whole unrolled strip sets of 312 rows (4 + 8 + .. + 48),
-            # and beside them at least the eight pair instantiations (two cells x ordinary / SHORT x two passes) at 3.5 maxima per row
+        if not single and not tails and c.get("v_pk_mad_i16", 0):
+            bad.append("%s has %d v_pk_mad_i16 (the query-pair row adds with a 32-bit add)" % (k, c["v_pk_mad_i16"]))
+        if tails:
+            # the query-pair ROW adds with a 32-bit add; the v_pk_mad_i16 of a ...qt kernel are the rows of the single-query cell that runs the
+            # TAILS of its SHORT items (OswSearchArgs::hand): whole unrolled strip sets of 312 rows (4 + 8 + .. + 48), and beside them at least
+            # the pair instantiations (cells x ordinary / SHORT x two passes) at 3.5 maxima per row
             mad, mx = c.get("v_pk_mad_i16", 0), c.get("v_pk_maximum3_f16", 0)
-            if mad % 312 or mad > 4 * 312 or mx - 3.5 * mad < 3.5 * 312 * (8 if k == "osw_sw_s16q" else 4):  # (osw_sw_pk16q: one cell)
+            if mad == 0 or mad % 312 or mad > 4 * 312 or mx - 3.5 * mad < 3.5 * 312 * (8 if k == "osw_sw_s16qt" else 4):  # (osw_sw_pk16qt: one cell)
                 bad.append("%s has %d v_pk_mad_i16 and %d v_pk_maximum3_f16 (tail rows come in sets of 312; the pair rows add with a 32-bit add)" % (k, mad, mx))
         if c.get("ds_read_b64", 0) or c.get("ds_read2_b64", 0) or c.get("ds_read_b128", 0) < 100:
             bad.append("%s reads its profile with %d ds_read_b128, %d ds_read_b64" % (k, c.get("ds_read_b128", 0), c.get("ds_read_b64", 0)))

@@ -16,7 +16,7 @@ def source_digest():
             h.update(f.read())
     return h.hexdigest()[:16]
 
-DP = ("osw_sw_s16q", "osw_sw_s16", "osw_sw_pk16q", "osw_sw_pk16", "osw_sw_q8")  # first-pass DP kernels (int16 cells; 8-bit cells + their int16 re-run)
+DP = ("osw_sw_s16qt", "osw_sw_s16q", "osw_sw_s16", "osw_sw_pk16qt", "osw_sw_pk16q", "osw_sw_pk16", "osw_sw_q8")  # first-pass DP kernels (int16 cells; 8-bit cells + their int16 re-run)
 RERUN32 = ("osw_sw_i32r", "osw_sw_i32")   # the int32 re-run of a search (round 4: its own kernel, workgroups of twelve waves); cell_bits 32 runs osw_sw_i32
 KERNELS = DP + RERUN32 + ("osw_topr", "osw_retile", "osw_block_extent", "osw_build_profile")
 
