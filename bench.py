@@ -142,6 +142,10 @@ def main():
     # this pool's host driver supports dmabuf IPC only: without it RCCL's exchange of buffers between the ranks' processes fails
     # (hipIpcGetMemHandle: invalid argument).  The image exports it; a launcher that built its own environment may not have.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        # the library's bring-up ends with a warm-up kernel that keeps every CU busy until the first real work: meant for a
+        # one-shot tool's first search; here the warm-up steps do that job, and the ranks' collectives' own bring-up should find the GPUs free
+        os.environ.setdefault("OSWALD_HIP_WARM_MS", "0")
     if world == 1 and args.gpus > 1:
         # started without a launcher: start the ranks ourselves (before anything touches the GPU) and leave with their code
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
