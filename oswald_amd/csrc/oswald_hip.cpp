@@ -1618,12 +1618,14 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
     if (dbg_times) {
         // diagnostics only (liboswald_hip_diag.so): when did the workgroups of the DP launch start / leave phase 1 / finish
         HIP_TRY(hipStreamSynchronize(d.stream));
-        std::vector<unsigned long long> t((size_t)grid * 5 + 2);
+        // (the launch the stamps are of: the single-query launch, or -- a set without single queries -- the query-pair launch)
+        const uint32_t g_rep = c.nitems + c.nitems_wg > 0 ? grid : std::min<uint32_t>(grid_cap, (c.nitems_q + 3) / 4 + c.nitems_q_wg);
+        std::vector<unsigned long long> t((size_t)g_rep * 5 + 2);
         HIP_TRY(hipMemcpy(t.data(), d.wg_times.p, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         uint32_t ctr[8] = {0};
         HIP_TRY(hipMemcpy(ctr, (uint32_t *)d.counters.p + OSW_CTR_BLOCKS * OSW_CTR_COUNT, sizeof ctr, hipMemcpyDeviceToHost));
-        osw_diag_report_times(t.data(), grid, ctr[4]);
-        if (t[(size_t)grid * 5 + 1]) fprintf(stderr, "[oswald_hip]   core clock inside the kernel (cycle counter / 100-MHz counter over its workgroups): %.0f MHz\n", 100.0 * (double)t[(size_t)grid * 5] / (double)t[(size_t)grid * 5 + 1]);
+        osw_diag_report_times(t.data(), g_rep, ctr[4]);
+        if (t[(size_t)g_rep * 5 + 1]) fprintf(stderr, "[oswald_hip]   core clock inside the kernel (cycle counter / 100-MHz counter over its workgroups): %.0f MHz\n", 100.0 * (double)t[(size_t)g_rep * 5] / (double)t[(size_t)g_rep * 5 + 1]);
     }
 #endif
     return 0;
