@@ -438,3 +438,57 @@ def test_index_maps_given_in_a_row_do_not_overtake_their_readers(oracle):
                 np.testing.assert_array_equal(sc[q], want_s)
                 np.testing.assert_array_equal(ix[q].astype(np.int64), want_i)
         ctx.chunk_release(h)
+
+
+def test_buffer_life_cycle_of_a_search(oracle):
+    """ABI 5: the reference's buffer life cycle -- host buffers before the clock (FPGAsearch.c:69-74 -> oswald_hip_reserve_host), device
+    buffers inside it (:85-96 -> oswald_hip_reserve_chunks), release behind it (:361-368 -> oswald_hip_release_chunks) -- three searches
+    in a row in one context, each creating its device buffers anew; a chunk that is still held keeps its buffers through a release;
+    scores and top lists are the oracle's every time."""
+    from oswald_amd import capi
+    qs = synth.make_queries([90, 137, 250, 301], seed=81)
+    bfull, nfull, dfull, parts = _chunks(2500, qs, 150000, seed=82)
+    assert len(parts) >= 4
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = _want("life cycle", oracle, qs, bfull, nfull, dfull, sm, 10, 2)
+    nvalid = sum(p[4] for p in parts)
+    big_b = max(p[0].size for p in parts)
+    big_g = max(len(p[1]) for p in parts)
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.reserve_host(big_g, 16, len(qs), 3)                      # before the "clock"
+        held = None
+        for rep in range(3):
+            ctx.set_queries(a, m, ad)
+            ctx.reserve_chunks(big_b, big_g, 16, len(qs), 3)         # inside it: the slots' device buffers
+            ctx.topr_begin(5)
+            outs = []
+            for k, (b, n, disp, s0, nv) in enumerate(parts):
+                h = ctx.chunk_upload(b, n, disp, 16, wait=False)
+                ctx.chunk_set_index(h, s0, nv)
+                out = np.full((len(qs), len(n) * 16), -3, np.int32)
+                ctx.chunk_search(h, out)
+                outs.append(out)
+                if rep == 0 and k == 0:
+                    held = (h, out.shape)                             # this chunk stays resident through the releases below
+                else:
+                    ctx.chunk_release(h)
+            sc, ix = ctx.topr(5)
+            ctx.wait()
+            got = np.concatenate(outs, axis=1)
+            np.testing.assert_array_equal(got[:, :want.shape[1]], want[:, :got.shape[1]])
+            for q in range(len(qs)):
+                ws, wi = dblayout.topr_reference_order(want[q, :nvalid], 5)
+                np.testing.assert_array_equal(sc[q], ws)
+                np.testing.assert_array_equal(ix[q], wi)
+            ctx.release_chunks()                                      # behind it
+            # the chunk that is still held was not touched: searched again, the same scores
+            again = np.full(held[1], -3, np.int32)
+            ctx.chunk_search(held[0], again)
+            ctx.wait()
+            np.testing.assert_array_equal(again, outs[0] if rep == 0 else first)
+            if rep == 0:
+                first = again.copy()
+        ctx.chunk_release(held[0])
+        ctx.release_chunks()
