@@ -492,3 +492,51 @@ def test_buffer_life_cycle_of_a_search(oracle):
                 first = again.copy()
         ctx.chunk_release(held[0])
         ctx.release_chunks()
+
+
+@pytest.mark.parametrize("tables", ["page-locked: written by the kernels", "pageable"])
+def test_tails_through_the_pipeline(oracle, monkeypatch, tables):
+    """The tails of SHORT pair items (every eligible item: OSWALD_HIP_PAIR_TAILS=2) on the paths the parity tests do not take: a
+    first chunk cut in two by the library, searches queued behind uploads in flight, score tables in page-locked memory that the
+    kernels write directly (the tail folds its best into what the pair part stored -- in both tables), slots re-used, the
+    context-level top list on database keys."""
+    from oswald_amd import capi
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "2")
+    monkeypatch.setenv("OSWALD_HIP_SPLIT_BYTES", "30000")
+    qs = synth.make_queries([70, 131, 188, 260, 340, 415], seed=91)          # three pairs, tails of 61 / 72 / 75 rows, no single query
+    bfull, nfull, dfull, parts = _chunks(3000, qs, 200000, seed=92)
+    assert len(parts) >= 4
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = _want("tails pipeline", oracle, qs, bfull, nfull, dfull, sm, 10, 2)
+    nvalid = sum(p[4] for p in parts)
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2)
+        ctx.set_queries(a, m, ad)
+        for rep in range(3):
+            if tables.startswith("page-locked"):
+                bufs = [capi.HostBuffer((len(qs), len(p[1]) * 16), np.int32) for p in parts]
+                outs = [hb.a for hb in bufs]
+            else:
+                bufs, outs = [], [np.empty((len(qs), len(p[1]) * 16), np.int32) for p in parts]
+            for o in outs:
+                o[...] = -3
+            ctx.topr_begin(7)
+            hs = [ctx.chunk_upload(*parts[0][:3], 16, wait=False)]
+            ctx.chunk_set_index(hs[0], parts[0][3], parts[0][4])
+            for k in range(len(parts)):
+                ctx.chunk_search(hs[k], outs[k])
+                if k + 1 < len(parts):
+                    hs.append(ctx.chunk_upload(*parts[k + 1][:3], 16, wait=False))
+                    ctx.chunk_set_index(hs[k + 1], parts[k + 1][3], parts[k + 1][4])
+                ctx.chunk_release(hs[k])
+            sc, ix = ctx.topr(7)
+            ctx.wait()
+            got = np.concatenate([np.array(o) for o in outs], axis=1)
+            np.testing.assert_array_equal(got[:, :want.shape[1]], want[:, :got.shape[1]])
+            wsc, wix = _toplists(want, nvalid, 7)
+            np.testing.assert_array_equal(sc, wsc)
+            np.testing.assert_array_equal(ix.astype(np.int64), wix)
+            for hb in bufs:
+                hb.close()
