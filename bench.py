@@ -102,6 +102,8 @@ def parse():
                     help="who carries the top-r gather between the ranks: lib = the C ABI itself (ncclAllGather inside oswald_hip_topr on a communicator "
                          "made by oswald_hip_comm_init_rank; torch.distributed only hands the id round and keeps time), torch = torch.distributed.all_gather "
                          "of the ranks' lists; auto = lib over RCCL, torch for the gloo rehearsal")
+    ap.add_argument("--per-chunk-launches", action="store_true", help="the resident steps search the rank's chunks one by one (oswald_hip_chunk_search, rounds 1-5) instead of as one "
+                                                                    "launch over all of them (oswald_hip_search_resident)")
     ap.add_argument("--comm", action="store_true", help="N = 1: give the one rank a process-level RCCL communicator all the same (the gather path of N > 1 at world size 1)")
     ap.add_argument("--write-top-reference-run", action="store_true", help="N = 1 only: write tests/reference_runs/bench_top_<workload>_<nseq>.json (this run's merged top list)")
     return ap.parse_args()
@@ -292,18 +294,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # The database is RESIDENT in these steps: the rank's chunks are searched as ONE launch (oswald_hip_search_resident, round 6: every
+    # launch boundary costs a ramp, a ragged end and, for short launches, clock); --per-chunk-launches: one by one, as a caller that
+    # streams chunks in must (the `inclusive` leg and the command-line tool do)
+    one_launch = len(chunks) > 1 and not args.per_chunk_launches
+
+    def search_all():
+        if one_launch:
+            ctx.search_resident([c["h"] for c in chunks])
+        else:
+            for c in chunks:
+                ctx.chunk_search(c["h"], None)
+
     def step():
-        # every chunk's search queues the selection of its top r behind it and folds it into the GPU's running list
+        # every search queues the selection of its chunks' top r behind it and folds it into the GPU's running list
         # (oswald_hip_topr_begin); oswald_hip_topr waits for the device once.  gather == "lib": it also all-gathers the
         # ranks' lists over RCCL and folds them on the GPU -- the list it returns is the job's; "torch": it returns the
         # rank's list and torch.distributed.all_gather carries the lists between the ranks
         ctx.topr_begin(args.top)
         if gather == "lib":
-            for c in chunks:
-                ctx.chunk_search(c["h"], None)
+            search_all()
             sc, ix = ctx.topr(args.top)
             return sc, np.where(ix == 0xFFFFFFFF, -1, ix.astype(np.int64))
-        return multigpu.rank_step(chunks, lambda c: ctx.chunk_search(c["h"], None), None, nq, args.top, index_base, dist,
+        search_all()
+        return multigpu.rank_step(chunks, lambda c: None, None, nq, args.top, index_base, dist,
                                   coll_dev if dist is not None else None, collect_rank=lambda: ctx.topr(args.top))
 
     coll_ranks = None
@@ -364,7 +378,7 @@ def main():
         row_cycles = ROW_CYCLES[cell_bits][1 if nq > 1 else 0]
         valu_ceiling = N_CU * SIMD_PER_CU * (CLOCK_HZ / row_cycles) * 128.0 / 1e9
         kname = {16: "osw_sw_s16qt|osw_sw_s16q+osw_sw_s16(+osw_sw_i32r)", 32: "osw_sw_i32", 8: "osw_sw_q8+osw_sw_pk16(+osw_sw_i32)"}[cell_bits]
-        traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None, DTYPE[cell_bits])
+        traffic, traffic_note = measured_traffic(args.workload, nseq_total if world == 1 else None, DTYPE[cell_bits], nlaunch / max(1, args.steps))
         cfg_name = {"c2": "C2" if nseq_total == 100000 and world == 1 else "C4" if nseq_total == 1000000 else "C2-shaped", "c3": "C3", "c5": "C5", "q1": "Q1",
                     "hi": "escalation-heavy (int16 -> int32)", "hi8": "escalation-heavy (int8 -> int16)"}[args.workload]
         if cfg_name == "C4" and world == 1:
@@ -384,7 +398,8 @@ def main():
                        "top": args.top, "sharding": shard_note, "shard_rule": args.shard_rule, "collective_backend": ("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 or gather == "lib" else None,
                        "collective_note": gather_note, "collective_ranks": coll_ranks,
                        "collective_via": ("liboswald_hip.so: ncclAllGather of nq x r tagged keys inside oswald_hip_topr, folded on the GPU (RCCL %d)" % ctx.comm_info()["rccl_version"]) if gather == "lib"
-                                         else ("torch.distributed.all_gather" if world > 1 else None), "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk},
+                                         else ("torch.distributed.all_gather" if world > 1 else None), "chunks_rank0": len(chunks), "max_chunk_bytes": args.max_chunk,
+                       "resident_search": ("one launch over the rank's %d resident chunks (oswald_hip_search_resident)" % len(chunks)) if one_launch else "one launch per chunk (oswald_hip_chunk_search)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_ratio": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,   # counter bytes over algorithmic bytes: what the strips spill and read back
@@ -562,7 +577,7 @@ def top_oracle_pin(plan, shard, queries, sm, wl, top, chunks):
     return pin
 
 
-def measured_traffic(workload_name, nseq, dtype=None):
+def measured_traffic(workload_name, nseq, dtype=None, launches_per_step=None):
     """HBM bytes per launch of the DP kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
     runs, see tools/profile_gpu.sh and DESIGN.md for the unit and the gfx950 correction) committed under
     profiles/ for this exact workload -- and for THIS kernel source: the summary carries a digest of the
@@ -579,6 +594,8 @@ def measured_traffic(workload_name, nseq, dtype=None):
         return None, "no PMC summary committed for this workload"
     if dtype is not None and t.get("dtype") not in (None, dtype):
         return None, f"the PMC summary committed for this workload was measured on the {t.get('dtype')} cells"
+    if launches_per_step is not None and (t.get("launches_per_step") is None or abs(float(t["launches_per_step"]) - launches_per_step) > 0.01):
+        return None, f"the PMC summary committed for this workload was measured at {t.get('launches_per_step')} launches per step (this run: {launches_per_step:g})"
     if t.get("pair_tails", "1") != tails:
         return None, f"the PMC summary committed for this workload was measured with OSWALD_HIP_PAIR_TAILS={t.get('pair_tails')}"
     if t.get("source_digest") != source_digest():

@@ -186,6 +186,15 @@ int oswald_hip_max_chunk_size(oswald_hip_ctx *ctx, int dev, uint32_t nq, uint32_
  * host-side overflow re-computation, FPGAsearch.c:204-274. */
 int oswald_hip_chunk_search(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *scores_out);
 
+/* All queries against SEVERAL chunks that are resident on device dev, as ONE launch (ABI 5, round 6).  For a database that STAYS on
+ * the device -- a service that answers query sets against it; bench.py's resident steps -- : every launch boundary costs a ramp, a ragged
+ * end and, for short launches, clock (one launch instead of three: 7 % for one query against 1 M sequences, 1.2 % for twenty).  The
+ * chunks' uploads must have landed (the call waits for them); their order is the order of the score columns and of the folds into the
+ * top lists (oswald_hip_topr_begin / _chunk_set_index as for oswald_hip_chunk_search).  scores_out: null, or int32 [nq][sum of the
+ * chunks' ngroups * lane_width], valid after oswald_hip_wait.  A caller that streams chunks in (the reference's loop, FPGAsearch.c:132-238)
+ * searches them one by one with oswald_hip_chunk_search, each behind its upload; the reference has no resident mode. */
+int oswald_hip_search_resident(oswald_hip_ctx *ctx, int dev, const int *chunks, uint32_t nchunks, int32_t *scores_out);
+
 /* Gives the chunk's slot back.  Returns once the chunk's upload has landed (the caller's b / n / disp are free); a
  * search of the chunk may still be running -- the next upload into the slot waits for it on the device. */
 int oswald_hip_chunk_release(oswald_hip_ctx *ctx, int dev, int chunk);

@@ -29,7 +29,7 @@ SYMBOLS = (
     "oswald_hip_comm_unique_id", "oswald_hip_comm_init_rank", "oswald_hip_comm_info", "oswald_hip_max_chunk_size",
     "oswald_hip_host_alloc", "oswald_hip_host_free", "oswald_hip_rerun_stats",
     "oswald_hip_host_register", "oswald_hip_host_unregister", "oswald_hip_comm_destroy", "oswald_hip_reserve_chunks",
-    "oswald_hip_chunk_wait", "oswald_hip_release_chunks", "oswald_hip_reserve_host",
+    "oswald_hip_chunk_wait", "oswald_hip_release_chunks", "oswald_hip_reserve_host", "oswald_hip_search_resident",
 )
 COMM_ID_BYTES = 128   # OSWALD_HIP_COMM_ID_BYTES
 
@@ -64,6 +64,7 @@ def load():
     lib.oswald_hip_reserve.argtypes = [vp, i32, u32]
     lib.oswald_hip_reserve_chunks.argtypes = [vp, i32, u64, u32, u32, u32, u32]
     lib.oswald_hip_release_chunks.argtypes = [vp, i32]
+    lib.oswald_hip_search_resident.argtypes = [vp, i32, C.POINTER(i32), u32, vp]
     lib.oswald_hip_reserve_host.argtypes = [vp, i32, u32, u32, u32, u32]
     lib.oswald_hip_rerun_counts.argtypes = [vp, i32, C.POINTER(u64)]
     lib.oswald_hip_chunk_search.argtypes = [vp, i32, i32, vp]
@@ -258,6 +259,14 @@ class Context:
             assert out.dtype == np.int32 and out.flags.c_contiguous
             self._keep.append(out)
         _chk(self.lib.oswald_hip_chunk_search(self.h, dev, chunk, _ptr(out)))
+
+    def search_resident(self, chunks, out: np.ndarray | None = None, dev: int = 0):
+        """All queries against several resident chunks as ONE launch; `out` (int32 [nq][sum of the chunks' ngroups*W]) is valid after wait()."""
+        hs = (C.c_int * len(chunks))(*[int(h) for h in chunks])
+        if out is not None:
+            assert out.dtype == np.int32 and out.flags.c_contiguous
+            self._keep.append(out)
+        _chk(self.lib.oswald_hip_search_resident(self.h, dev, hs, len(chunks), _ptr(out)))
 
     def chunk_wait(self, chunk: int, dev: int = 0):
         """Blocks until the chunk's last search is through (whatever has been queued behind it)."""

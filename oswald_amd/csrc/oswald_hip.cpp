@@ -226,7 +226,7 @@ struct PinBuf {
 struct Arena {
     DevBuf slab;
     size_t used = 0;
-    static size_t up(size_t n) { return (n + 255) & ~(size_t)255; }
+    static size_t up(size_t n) { return (n + 511) & ~(size_t)511; } // (512: a slot's `tiled` slice must lie a whole number of 4-column groups from any other, see Group)
     void *take(size_t bytes) { void *r = (char *)slab.p + used; used += up(bytes); return r; }
 };
 
@@ -320,11 +320,27 @@ struct Chunk {
     // Every per-chunk entry point walks the chain.
     int next = -1;
     bool is_cont = false;               // this slot is the rest of another slot's chunk
+    bool is_group = false;              // not a slot: the combined view of several resident chunks (Device::group, oswald_hip_search_resident)
 };
 
 // Slots a device keeps at most before an upload GROWS the largest free one instead of opening another: three resident chunks
 // (one searched, two coming in) and the two pieces of a first chunk cut at its upload.
 #define OSW_MAX_SLOTS 5
+
+// Several RESIDENT chunks searched as ONE launch (oswald_hip_search_resident, round 6).  Every launch boundary costs a ramp, a ragged end
+// and -- short launches -- clock (DESIGN 4 "Single queries": one launch instead of three is worth 7 % to a one-query search of 1 M
+// sequences, 1.2 % to twenty queries).  The kernels address a chunk through its block table, and nothing in them says that the blocks of
+// a table lie in ONE allocation: the group's table lists the blocks of all members with their column offsets counted from the lowest
+// `tiled` address among them (32-bit offsets of 512 B: a span of 2 TB) and their sequences' columns in ONE score table; `g` is a chunk
+// in everything but its residues -- combined live extents, work queues planned over all blocks, score table, re-run queues.
+struct Group {
+    std::vector<int> members;           // slots (chains flattened)
+    std::vector<uint64_t> up_seq;       // ... and which upload each held when the group was made
+    std::vector<uint32_t> col0, blk0;   // a member's first column of the group's score table / first block of its block table
+    std::vector<uint16_t> sub_cols_host; // combined live extents (what g.sub_cols points at)
+    Chunk g;
+    bool valid = false;
+};
 
 struct EventPair { hipEvent_t a, b, c, d; bool c_used; }; // a..b: all DP launches of a chunk search; c..d: the int16 re-run of the 8-bit pass (c_used); d..b: the int32 re-run
 
@@ -374,6 +390,7 @@ struct Device {
     // beside whatever the caller does next before its clock starts (the tool: loading and page-locking the database); the first call
     // that gives the device real work -- queries, buffers, a chunk -- tells it to stop (a word in page-locked memory the kernel
     // polls: it is gone some 20 us later), and it stops by itself after Tunables::warm_ms.  OSWALD_HIP_WARM_MS=0: no warm-up.
+    std::unique_ptr<Group> group;     // the last group searched (its tables and plan are kept while the members stay as they are)
     hipStream_t stream_warm = nullptr;
     uint32_t *warm_stop = nullptr;   // page-locked; *warm_stop = 1: leave
     bool warm_running = false;
@@ -653,18 +670,20 @@ int queue_topr(oswald_hip_ctx *ctx, Device &d, Chunk &c, uint32_t nvalid, uint32
 // Context-level top-r (oswald_hip_topr_begin): select the top r of the chunk just searched on its device, as tagged
 // DATABASE keys, and fold them into the device's running list -- all queued on the device's stream behind the search:
 // the caller is not made to wait, nothing leaves the device, and the chunk may be released right after.
-int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c)
+int topr_after_search(oswald_hip_ctx *ctx, Device &d, Chunk &c, const int32_t *scores = nullptr, uint32_t stride = 0, bool searched = false)
 {
+    // (scores / stride: where the chunk's scores are -- its own table, or its columns of the table of a search over several resident chunks)
+    if (!scores) { scores = (const int32_t *)c.scores.p; stride = c.score_stride; searched = c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg != 0; }
     if (ctx->topr_r == 0 || !c.has_index || ctx->nq == 0) return 0;
     const uint32_t r = ctx->topr_r;
     if (ctx->topr_queries_version != ctx->queries_version)
         return fail(OSWALD_HIP_ESTATE, "the query set changed since oswald_hip_topr_begin: call it again before searching");
     if (c.nvalid > c.ngroups * c.W) return fail(OSWALD_HIP_EINVAL, "chunk index: nvalid %u exceeds the chunk's %u lanes", c.nvalid, c.ngroups * c.W);
-    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0 || c.nvalid == 0) return 0; // nothing was searched: nothing to add
+    if (!searched || c.nvalid == 0) return 0; // nothing was searched: nothing to add
     if (!d.top_run[0].p || !d.top_run[1].p) return fail(OSWALD_HIP_ESTATE, "oswald_hip_topr_begin has not prepared device %d", d.id);
     if (c.map_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_map[c.map_cur], 0)); c.map_pending = false; } // the chunk's index map has landed
     HIP_TRY(d.topr_cand.reserve((size_t)ctx->nq * osw_topr_parts(c.nvalid) * r * sizeof(unsigned long long)));
-    HIP_TRY(osw_launch_topr_fold_chunk((const int32_t *)c.scores.p, c.score_stride, c.nvalid, r, ctx->nq,
+    HIP_TRY(osw_launch_topr_fold_chunk(scores, stride, c.nvalid, r, ctx->nq,
                                        c.index_map ? (const uint32_t *)c.index_map_dev[c.map_cur].p : nullptr, c.first_index, (unsigned long long *)d.topr_cand.p,
                                        (const unsigned long long *)d.top_run[d.top_cur].p, (unsigned long long *)d.top_run[d.top_cur ^ 1].p, d.stream));
     if (c.index_map) {
@@ -881,6 +900,8 @@ static int init_impl(int ndev, const int *device_ids, oswald_hip_ctx **out)
     return 0;
 }
 
+static void free_group(Device &d);
+
 static int finalize_impl(oswald_hip_ctx *ctx)
 {
     if (!ctx) return 0;
@@ -890,6 +911,7 @@ static int finalize_impl(oswald_hip_ctx *ctx)
         if (d.stream_warm) { (void)hipStreamSynchronize(d.stream_warm); (void)hipStreamDestroy(d.stream_warm); d.stream_warm = nullptr; }
         if (d.warm_stop) { (void)hipHostFree(d.warm_stop); d.warm_stop = nullptr; }
         for (hipStream_t st : {d.stream, d.stream2, d.stream_copy, d.stream_up, d.stream_down}) if (st) (void)hipStreamSynchronize(st);
+        free_group(d);
         release_registered(d);
         if (d.stream2) (void)hipStreamSynchronize(d.stream2);
         if (d.stream_copy) { (void)hipStreamSynchronize(d.stream_copy); (void)hipStreamDestroy(d.stream_copy); d.stream_copy = nullptr; }
@@ -1444,7 +1466,7 @@ static int search_plan(oswald_hip_ctx *ctx, Device &d, Chunk &c, PhaseTimer &pt,
 // table_dev: the caller's score table as the device addresses it (columns of this slot: already offset), or null
 static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht, int32_t *table_dev, size_t table_stride)
 {
-    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return topr_after_search(ctx, d, c); }
+    if (c.nitems + c.nitems_wg + c.nitems_q + c.nitems_q_wg == 0) { c.searched = true; return c.is_group ? 0 : topr_after_search(ctx, d, c); }
     if (!d.bnd.p || d.bnd_stride == 0) return fail(OSWALD_HIP_ESTATE, "device %d has no spill scratch (an earlier allocation failed)", d.id);
     if (c.down_pending) { HIP_TRY(hipStreamWaitEvent(d.stream, c.ev_down, 0)); c.down_pending = false; } // the table of the slot's last search is still on its way out
 
@@ -1610,8 +1632,9 @@ static int search_launch(oswald_hip_ctx *ctx, Device &d, Chunk &c, HoldTimer &ht
         c.set_read_pending[k] = true;
     }
     ht.lap("search: launches");
-    if (int r = topr_after_search(ctx, d, c)) return r;
+    if (!c.is_group) { if (int r = topr_after_search(ctx, d, c)) return r; } // (a group's members fold their columns: search_resident_impl)
     ht.lap("search: top-r launches");
+    if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c.ev_use, d.stream)); // an upload into this slot waits for it
     c.use_pending = true;
 #ifdef OSW_DIAG
@@ -1724,6 +1747,159 @@ static int chunk_search_impl(oswald_hip_ctx *ctx, int dev, int chunk, int32_t *s
     return 0;
 }
 
+// All queries against SEVERAL resident chunks of a device as ONE launch (see Group).  The chunks' uploads must have landed -- the plan is
+// made on the live extents of all of them: this is the entry for a database that STAYS on the device; a caller that streams chunks in
+// searches them one by one (oswald_hip_chunk_search), each behind its upload.  Top lists: every member that has an index folds its
+// columns of the group's score table into the device's running list, in the order given.  scores_out (or null): int32 [nq][sum of the
+// members' ngroups * W], the members' columns side by side in the order given (a plain download: the entry is for top lists).
+static int search_resident_impl(oswald_hip_ctx *ctx, int dev, const int *handles, uint32_t nhandles, int32_t *scores_out)
+{
+    if (int r = check_dev(ctx, dev)) return r;
+    if (!handles || nhandles == 0) return fail(OSWALD_HIP_EINVAL, "no chunk handles");
+    Device &d = ctx->dev[dev];
+    HIP_TRY(hipSetDevice(d.id));
+    stop_warm(ctx);
+    if (ctx->topr_r && ctx->topr_queries_version != ctx->queries_version)
+        return fail(OSWALD_HIP_ESTATE, "the query set changed since oswald_hip_topr_begin: call it again before searching");
+    std::vector<int> members;
+    for (uint32_t i = 0; i < nhandles; ++i) {
+        if (int r = check_chunk(ctx, dev, handles[i])) return r;
+        for (int k = handles[i]; k >= 0; k = d.chunks[k].next) {
+            if (std::find(members.begin(), members.end(), k) != members.end()) return fail(OSWALD_HIP_EINVAL, "chunk handle %d given twice", handles[i]);
+            members.push_back(k);
+        }
+    }
+    for (int k : members) if (int r = finish_upload(d, d.chunks[k])) return r;
+    if (int r = sync_queries(ctx, d)) return r;
+    if (!d.group) d.group.reset(new Group);
+    Group &G = *d.group;
+    Chunk &g = G.g;
+    bool same = G.valid && G.members == members;
+    for (size_t i = 0; same && i < members.size(); ++i) same = G.up_seq[i] == d.chunks[members[i]].up_seq;
+    if (!same) {
+        G.valid = false;
+        // whoever still reads the group's tables -- a search of the group as it was -- is through
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream2));
+        HIP_TRY(hipStreamSynchronize(d.stream_down));
+        g.use_pending = g.down_pending = g.set_read_pending[0] = g.set_read_pending[1] = false;
+        const uint32_t W = d.chunks[members[0]].W;
+        uintptr_t base = ~(uintptr_t)0;
+        uint64_t nblocks = 0, stride = 0, ngroups = 0;
+        for (int k : members) {
+            const Chunk &c = d.chunks[k];
+            if (c.W != W) return fail(OSWALD_HIP_EINVAL, "the chunks of a combined search must have one lane width (%u and %u)", W, c.W);
+            if (c.nblocks) base = std::min(base, (uintptr_t)c.tiled.p);
+            nblocks += c.nblocks; stride += c.score_stride; ngroups += c.ngroups;
+        }
+        if (nblocks >= 0x7fffffffull || stride >= 0xffffffffull || ngroups >= 0xffffffffull)
+            return fail(OSWALD_HIP_EINVAL, "too many sequences for one combined search (%llu blocks)", (unsigned long long)nblocks);
+        g.is_group = true;
+        g.live = true;
+        g.W = W;
+        g.ngroups = (uint32_t)ngroups;
+        g.nblocks = (uint32_t)nblocks;
+        g.score_stride = (uint32_t)stride;
+        g.max_ncols4 = 0;
+        g.ncols4_alloc.clear();
+        G.col0.clear(); G.blk0.clear(); G.up_seq.clear();
+        G.sub_cols_host.assign((size_t)nblocks * 128, 0);
+        // the members' block tables as the DEVICE holds them (their re-tile wrote the live extents), offsets moved into the group's frame
+        std::vector<OswBlock> all(nblocks);
+        uint32_t b0 = 0, c0 = 0;
+        for (int k : members) {
+            const Chunk &c = d.chunks[k];
+            G.blk0.push_back(b0); G.col0.push_back(c0); G.up_seq.push_back(c.up_seq);
+            if (c.nblocks) {
+                HIP_TRY(hipMemcpy(all.data() + b0, c.blocks.p, (size_t)c.nblocks * sizeof(OswBlock), hipMemcpyDeviceToHost));
+                const uintptr_t delta = (uintptr_t)c.tiled.p - base;
+                if (delta % 512u) return fail(OSWALD_HIP_ERUNTIME, "chunk buffers are not 512-byte aligned to each other");
+                const uint64_t d4 = delta / 512u;
+                for (uint32_t B = 0; B < c.nblocks; ++B) {
+                    OswBlock &blk = all[b0 + B];
+                    if ((uint64_t)blk.col4_off + d4 > 0xfffffff0ull) return fail(OSWALD_HIP_EINVAL, "the chunks of a combined search lie too far apart in device memory");
+                    blk.col4_off = (uint32_t)(blk.col4_off + d4);
+                    blk.seq0 += c0;
+                }
+                memcpy(G.sub_cols_host.data() + (size_t)b0 * 128, c.sub_cols, (size_t)c.nblocks * 128 * sizeof(uint16_t));
+                g.ncols4_alloc.insert(g.ncols4_alloc.end(), c.ncols4_alloc.begin(), c.ncols4_alloc.end());
+                g.max_ncols4 = std::max(g.max_ncols4, c.max_ncols4);
+            }
+            b0 += c.nblocks;
+            c0 += c.score_stride;
+        }
+        g.sub_cols = G.sub_cols_host.data(); // (plain host memory: only the planner reads it; never given to hipHostFree, see free_group)
+        g.sub_cols_cap = G.sub_cols_host.size();
+        g.tiled.assign((void *)base, ~(size_t)0 >> 1); // a view: the members own their residues
+        HIP_TRY(g.blocks.reserve((size_t)nblocks * sizeof(OswBlock) + 16));
+        HIP_TRY(g.sub_cols_buf.reserve((size_t)nblocks * 128 * sizeof(uint16_t) + 16));
+        if (nblocks > g.blocks_pin_cap) {
+            if (g.blocks_pin) HIP_TRY(hipHostFree(g.blocks_pin));
+            g.blocks_pin = nullptr;
+            g.blocks_pin_cap = 0;
+            const size_t want = (size_t)nblocks + nblocks / 8 + 16;
+            HIP_TRY(hipHostMalloc((void **)&g.blocks_pin, want * sizeof(OswBlock), hipHostMallocPortable));
+            g.blocks_pin_cap = want;
+        }
+        if (nblocks) memcpy(g.blocks_pin, all.data(), (size_t)nblocks * sizeof(OswBlock));
+        HIP_TRY(osw_launch_copy16(g.blocks_pin, g.blocks.p, (size_t)nblocks * sizeof(OswBlock), d.stream));
+        for (size_t i = 0; i < members.size(); ++i) {
+            const Chunk &c = d.chunks[members[i]];
+            if (c.nblocks) HIP_TRY(hipMemcpyAsync((uint16_t *)g.sub_cols_buf.p + (size_t)G.blk0[i] * 128, c.sub_cols_buf.p, (size_t)c.nblocks * 128 * sizeof(uint16_t), hipMemcpyDeviceToDevice, d.stream));
+        }
+        g.items_version = ~0ull;
+        g.items_exact = false;
+        G.members = members;
+        G.valid = true;
+    }
+    if (int r = build_items(ctx, d, g, true)) return r;
+    HoldTimer ht(g_debug_slow);
+    if (int r = search_launch(ctx, d, g, ht, nullptr, 0)) return r;
+    const bool searched = g.nitems + g.nitems_wg + g.nitems_q + g.nitems_q_wg != 0;
+    for (size_t i = 0; i < members.size(); ++i) {
+        Chunk &c = d.chunks[members[i]];
+        if (int r = topr_after_search(ctx, d, c, (const int32_t *)g.scores.p + G.col0[i], g.score_stride, searched)) return r;
+        // the member's residues are in use until here: an upload into its slot waits for it; its OWN score table was not written
+        if (!c.ev_use) HIP_TRY(hipEventCreateWithFlags(&c.ev_use, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c.ev_use, d.stream));
+        c.use_pending = true;
+        c.searched = false;
+    }
+    if (scores_out && ctx->nq && searched) {
+        size_t out_stride = 0;
+        for (int k : members) out_stride += (size_t)d.chunks[k].ngroups * d.chunks[k].W;
+        if (!g.ev_down) HIP_TRY(hipEventCreateWithFlags(&g.ev_down, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g.ev_use, d.stream));
+        HIP_TRY(hipStreamWaitEvent(d.stream_down, g.ev_use, 0));
+        size_t oc = 0;
+        for (size_t i = 0; i < members.size(); ++i) {
+            const Chunk &c = d.chunks[members[i]];
+            const size_t row = (size_t)c.ngroups * c.W;
+            for (uint32_t q = 0; q < ctx->nq && row; ++q)
+                HIP_TRY(hipMemcpyAsync(scores_out + (size_t)q * out_stride + oc, (const int32_t *)g.scores.p + (size_t)q * g.score_stride + G.col0[i], row * sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, d.stream_down));
+            oc += row;
+        }
+        HIP_TRY(hipEventRecord(g.ev_down, d.stream_down));
+        g.down_pending = true;
+    }
+    return 0;
+}
+
+// what a Group holds beyond its members' buffers (oswald_hip_finalize)
+static void free_group(Device &d)
+{
+    if (!d.group) return;
+    Chunk &g = d.group->g;
+    for (hipEvent_t *e : {&g.ev_use, &g.ev_down, &g.ev_set_read[0], &g.ev_set_read[1]}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    for (int k = 0; k < 2; ++k) { if (g.items_pin[k]) (void)hipHostFree(g.items_pin[k]); g.items_pin[k] = nullptr; }
+    if (g.blocks_pin) (void)hipHostFree(g.blocks_pin);
+    g.blocks_pin = nullptr;
+    g.sub_cols = nullptr; // (a std::vector's memory)
+    for (DevBuf *b : {&g.tiled, &g.blocks, &g.sub_cols_buf, &g.scores, &g.ovf, &g.ovf8}) b->release();
+    d.group.reset();
+}
+
 static int chunk_release_impl(oswald_hip_ctx *ctx, int dev, int chunk)
 {
     if (int r = check_chunk(ctx, dev, chunk)) return r;
@@ -1817,6 +1993,7 @@ static int wait_impl(oswald_hip_ctx *ctx, int dev)
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream));
         HIP_TRY(hipStreamSynchronize(ctx->dev[i].stream_down));
         for (Chunk &c : ctx->dev[i].chunks) { c.upload_pending = false; c.use_pending = false; c.down_pending = false; c.set_read_pending[0] = c.set_read_pending[1] = false; c.map_read_pending[0] = c.map_read_pending[1] = false; }
+        if (ctx->dev[i].group) { Chunk &g = ctx->dev[i].group->g; g.use_pending = g.down_pending = g.set_read_pending[0] = g.set_read_pending[1] = false; }
         release_registered(ctx->dev[i]);
     }
     return 0;
@@ -2293,6 +2470,11 @@ int oswald_hip_search_chunk_async(oswald_hip_ctx *ctx, int dev, const uint8_t *b
 int oswald_hip_reserve_host(oswald_hip_ctx *ctx, int dev, uint32_t ngroups, uint32_t W, uint32_t nq, uint32_t slots)
 {
     return guarded("oswald_hip_reserve_host", [&] { return reserve_host_impl(ctx, dev, ngroups, W, nq, slots); });
+}
+
+int oswald_hip_search_resident(oswald_hip_ctx *ctx, int dev, const int *chunks, uint32_t nchunks, int32_t *scores_out)
+{
+    return guarded("oswald_hip_search_resident", [&] { return search_resident_impl(ctx, dev, chunks, nchunks, scores_out); });
 }
 
 int oswald_hip_release_chunks(oswald_hip_ctx *ctx, int dev)

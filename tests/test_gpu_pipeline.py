@@ -540,3 +540,68 @@ def test_tails_through_the_pipeline(oracle, monkeypatch, tables):
             np.testing.assert_array_equal(ix.astype(np.int64), wix)
             for hb in bufs:
                 hb.close()
+
+
+@pytest.mark.parametrize("mode", ["int16, tails forced", "int16, padded pairs", "8-bit first pass", "int32 cells", "one query"])
+def test_resident_chunks_searched_as_one_launch(oracle, monkeypatch, mode):
+    """oswald_hip_search_resident: several resident chunks -- one of them cut in two by the library at its upload -- searched as ONE
+    launch through a combined block table (column offsets counted from the lowest `tiled` address among the chunks, one score table).
+    Score columns and the context-level top lists (first index for some members, an index map for one) are the oracle's; again with
+    the group's tables and plan kept; again after one member has been released and uploaded anew (the group is made again); and the
+    chunks searched one by one afterwards give the same."""
+    from oswald_amd import capi
+    monkeypatch.setenv("OSWALD_HIP_PAIRS", "2")
+    monkeypatch.setenv("OSWALD_HIP_SPLIT_BYTES", "30000")
+    monkeypatch.setenv("OSWALD_HIP_PAIR_TAILS", "0" if "padded" in mode else "2")
+    bits = 8 if mode.startswith("8") else 32 if mode.startswith("int32") else 16
+    qs = synth.make_queries([150] if mode == "one query" else [70, 131, 188, 260, 340, 415], seed=95)
+    bfull, nfull, dfull, parts = _chunks(3200, qs, 220000, seed=96)
+    assert len(parts) >= 4
+    sm = submat.load("blosum62")
+    a, m, ad = pack_queries(qs)
+    want = _want("resident " + ("1" if len(qs) == 1 else "6"), oracle, qs, bfull, nfull, dfull, sm, 10, 2)
+    nvalid = sum(p[4] for p in parts)
+    rng = np.random.default_rng(3)
+    with capi.Context(1) as ctx:
+        ctx.set_scoring(sm, 10, 2, bits)
+        ctx.set_queries(a, m, ad)
+        hs = []
+        for k, (b, n, disp, s0, nv) in enumerate(parts):
+            hs.append(ctx.chunk_upload(b, n, disp, 16, wait=(k != 0)))      # the first one asynchronously on an idle device: cut in two
+        ctx.wait()
+
+        def index_all():
+            for k, (b, n, disp, s0, nv) in enumerate(parts):
+                ctx.chunk_set_index(hs[k], s0, nv, (np.arange(nv, dtype=np.uint32) + s0) if k == 1 else None)
+
+        def check(out, sc, ix):
+            np.testing.assert_array_equal(out[:, :want.shape[1]], want[:, :out.shape[1]])
+            wsc, wix = _toplists(want, nvalid, 9)
+            np.testing.assert_array_equal(sc, wsc)
+            np.testing.assert_array_equal(ix.astype(np.int64), wix)
+
+        for rep in range(4):
+            if rep == 2:   # one member leaves and comes back (another upload: the group must be made again)
+                ctx.chunk_release(hs[2])
+                hs[2] = ctx.chunk_upload(*parts[2][:3], 16)
+            ctx.topr_begin(9)
+            index_all()
+            out = np.full((len(qs), sum(len(p[1]) for p in parts) * 16), -3, np.int32)
+            ctx.search_resident(hs, out)
+            sc, ix = ctx.topr(9)
+            ctx.wait()
+            check(out, sc, ix)
+        # ... and one by one
+        ctx.topr_begin(9)
+        index_all()
+        outs = [np.full((len(qs), len(p[1]) * 16), -3, np.int32) for p in parts]
+        for k in range(len(parts)):
+            ctx.chunk_search(hs[k], outs[k])
+        sc, ix = ctx.topr(9)
+        ctx.wait()
+        check(np.concatenate(outs, axis=1), sc, ix)
+        # a handle given twice, an empty list: errors, not faults
+        with pytest.raises(capi.OswaldHipError):
+            ctx.search_resident([hs[0], hs[0]])
+        for h in hs:
+            ctx.chunk_release(h)

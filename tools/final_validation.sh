@@ -27,6 +27,8 @@ bench)
   python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
   b c4_1gpu --steps 20 --warmup 5
   OSWALD_HIP_PAIR_TAILS=0 b c4_1gpu_notails --steps 20 --warmup 5 --cpu-seconds 0
+  b c4_1gpu_per_chunk --steps 20 --warmup 5 --cpu-seconds 0 --per-chunk-launches
+  b q1_1m_per_chunk --workload q1 --nseq 1000000 --steps 20 --warmup 5 --cpu-seconds 0 --per-chunk-launches
   b c4_1gpu_comm --steps 20 --warmup 5 --comm --cpu-seconds 0
   b c2 --nseq 100000 --steps 20 --warmup 5
   b c3_int8 --workload c3 --steps 10 --warmup 2

@@ -185,7 +185,7 @@ try:
     # ... and to the MODE it was measured in (round 6: a file is keyed by workload, database size, cell arithmetic and whether the pairs' tails run)
     tails = os.environ.get("OSWALD_HIP_PAIR_TAILS", "1")
     t = dict(summary["traffic"], workload=wl, nseq=int(nseq), source_digest=source_digest(), dtype=(b or {}).get("dtype"), pair_tails=tails,
-             algorithmic_bytes_per_launch=((b or {}).get("roofline") or {}).get("algorithmic_bytes_per_launch"),
+             algorithmic_bytes_per_launch=((b or {}).get("roofline") or {}).get("algorithmic_bytes_per_launch"), launches_per_step=((b or {}).get("roofline") or {}).get("launches_per_step"),
              source=f"tools/profile_gpu.sh {wl} {nseq} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), bench.py's default cells for the workload, OSWALD_HIP_PAIR_TAILS={tails}")
     with open(os.path.join(out, f"traffic_{wl}_{nseq}" + ("" if tails == "1" else f"_tails{tails}") + ".json"), "w") as f:
         json.dump(t, f, indent=1)
