@@ -73,6 +73,11 @@ if f:
     for k in range(k0, k1):
         rs = [dp[kn][k] for kn in dp if len(dp[kn]) == nstep]
         spans.append(max(int(r["End_Timestamp"]) for r in rs) - min(int(r["Start_Timestamp"]) for r in rs))
+    for kn in DP:   # ... and how long a launch of the RESIDENT steps takes (the figure the per-dispatch counters belong to)
+        if kn + "_trace" in summary and len(dp[kn]) == nstep and k1 > k0:
+            dd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in dp[kn][k0:k1]]
+            summary[kn + "_trace"]["resident_launches"] = len(dd)
+            summary[kn + "_trace"]["resident_avg_ms"] = sum(dd) / len(dd) / 1e6
     if spans:
         summary["dp_step_span"] = {"steps": len(spans), "dispatch_groups": [k0, k1], "avg_ms": sum(spans) / len(spans) / 1e6, "min_ms": min(spans) / 1e6, "max_ms": max(spans) / 1e6,
                                    "what": "pair kernel + single-query kernel (concurrent) + osw_sw_i32 of one search; compare with bench.py roofline.kernel_ms"}
@@ -92,10 +97,26 @@ def pmc(sub):
             continue  # bring-up launch on empty queues (one workgroup)
         c = r["Counter_Name"]
         v = float(r["Counter_Value"])
-        e = res.setdefault(name, {}).setdefault(c, [0.0, set()])
-        e[0] += v
-        e[1].add(r.get("Dispatch_Id"))
-    return {k: {c: {"sum": v[0], "dispatches": len(v[1]), "per_dispatch": v[0] / max(1, len(v[1]))} for c, v in d.items()} for k, d in res.items()}
+        e = res.setdefault(name, {}).setdefault(c, {})
+        did = int(r.get("Dispatch_Id") or 0)
+        e[did] = e.get(did, 0.0) + v
+    # The search kernels' dispatches of the RESIDENT steps only (round 6): bench.py runs its warm-up and timed steps first and its
+    # upload-inclusive passes -- other launches: a chunk at a time, the first one cut in two -- behind them; until round 5 a "per dispatch"
+    # figure averaged over both kinds (and understated what a resident launch moves: the inclusive passes' launches are smaller and more).
+    b = bench_line(sub)
+    keep = None
+    if b:
+        keep = int(round((b["roofline"].get("launches_per_step") or 1) * (int(b["warmup"]) + int(b["steps"]))))
+    out = {}
+    for k, d in res.items():
+        out[k] = {}
+        for c, byid in d.items():
+            ids = sorted(byid)
+            if keep and k in DP + RERUN32:
+                ids = ids[:keep]
+            tot = sum(byid[i] for i in ids)
+            out[k][c] = {"sum": tot, "dispatches": len(ids), "per_dispatch": tot / max(1, len(ids))}
+    return out
 
 
 def calib(sub, counter, kernel):
@@ -140,9 +161,19 @@ def clk_per_dispatch():
         if int(r.get("Grid_Size", "0") or 0) <= int(r.get("Workgroup_Size", "256") or 256):
             continue  # bring-up launch on empty queues
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        if dur >= 1000000:  # >= 1 ms
-            res.setdefault(name, []).append((float(r["Counter_Value"]), dur))
-    return res
+        res.setdefault(name, []).append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"]), dur))
+    # the dispatches of the resident steps only (see pmc()), and of those the ones of 1 ms and more
+    b = bench_line("clk")
+    keep = int(round((b["roofline"].get("launches_per_step") or 1) * (int(b["warmup"]) + int(b["steps"])))) if b else None
+    out = {}
+    for name, lst in res.items():
+        lst.sort()
+        if keep:
+            lst = lst[:keep]
+        sel = [(v, dur) for _, v, dur in lst if dur >= 1000000]
+        if sel:
+            out[name] = sel
+    return out
 clk = {}
 for kn, lst in clk_per_dispatch().items():
     tr = summary.get(kn + "_trace")
@@ -158,9 +189,10 @@ if clk:
     if nv:
         # VALU issue rate of the dominant kernel in cycles of the clock it actually ran at, per SIMD (1024 SIMDs); 2.0 = the
         # SIMD-32 raw issue rate of a wave64 instruction (MI355X_MICROARCH.md)
-        cyc = clk[dom]["ghz"] * 1e9 * clk[dom]["trace_avg_ms"] * 1e-3 * 1024.0 / nv
-        summary["valu_issue"] = {"kernel": dom, "valu_wave_instructions": nv, "cycles_per_instruction_per_simd_at_effective_clock": cyc,
-                                 "cycles_per_instruction_per_simd_at_2p4GHz": 2.4e9 * clk[dom]["trace_avg_ms"] * 1e-3 * 1024.0 / nv,
+        ms = (summary.get(dom + "_trace") or {}).get("resident_avg_ms") or clk[dom]["trace_avg_ms"]  # (a launch of the resident steps: what `nv` is counted over)
+        cyc = clk[dom]["ghz"] * 1e9 * ms * 1e-3 * 1024.0 / nv
+        summary["valu_issue"] = {"kernel": dom, "valu_wave_instructions": nv, "launch_ms": ms, "cycles_per_instruction_per_simd_at_effective_clock": cyc,
+                                 "cycles_per_instruction_per_simd_at_2p4GHz": 2.4e9 * ms * 1e-3 * 1024.0 / nv,
                                  "raw_issue_fraction": 2.0 / cyc}
 try:
     fs = sum(summary["pmc_fetch"].get(k, {}).get("FETCH_SIZE", {}).get("per_dispatch", 0.0) for k in DP + RERUN32)
