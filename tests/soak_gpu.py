@@ -19,6 +19,7 @@ disp = disp.astype(np.uint32)
 mats = ["blosum62", "pam250", "blosum45", "blosum80"]
 ctx = capi.Context(1)
 h = None
+parts_h = None
 t0 = time.time()
 bad = 0
 cells = 0
@@ -41,7 +42,18 @@ for it in range(iters):
     out = np.zeros((len(qs), len(n) * 16), np.int32)
     ctx.chunk_search(h, out); ctx.wait()
     out2 = np.zeros_like(out)
-    ctx.chunk_search(h, out2); ctx.wait()
+    if it % 2:
+        ctx.chunk_search(h, out2); ctx.wait()
+    else:
+        # the same database as three resident chunks searched as ONE launch (oswald_hip_search_resident): the same table, columns side by side
+        if parts_h is None:
+            plan3 = dblayout.chunk_plan(n, 16, int(b.size) // 3 + 1, 1)
+            parts_h = []
+            for g0, g1 in plan3:
+                pb, pn, pd = dblayout.interleave(sl, sr, so, 16, g_begin=g0, g_end=g1)
+                parts_h.append(ctx.chunk_upload(pb, pn, pd.astype(np.uint32), 16))
+            assert len(parts_h) >= 3
+        ctx.search_resident(parts_h, out2); ctx.wait()
     want, _ = pyoracle.search_chunk_simd(a, m, ad, b, n, disp, 16, sm, go, ge)
     ok = np.array_equal(out, want) and np.array_equal(out, out2)
     cells += int(m.astype(np.int64).sum()) * int(sl.astype(np.int64).sum())
